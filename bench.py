@@ -1,0 +1,186 @@
+#!/usr/bin/env python3
+"""bench.py — end-to-end 640x480 inference throughput (img/s) + hough-vote kernel roofline.
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: launched by the driver as `python -m torch.distributed.run --nproc-per-node N ... bench.py ...`)
+
+Workload (BASELINE.json configs[1]): ResNet18-FPN + all four heads, batch = 1 frame of 640x480
+per GPU per step, HV_NUM_OF_HYPOTHESES = 1000 (config.INFERENCE), random-init weights
+(torch.manual_seed(0)), synthetic data.  One step is one pass of the hot path over one frame:
+
+    image -> encoder -> 4 FPN decoders -> 4 heads -> class compression          (on the synthetic image)
+          -> aggregation (CC + per-instance means) -> RANSAC hough voting -> RT (on the synthetic
+             post-network "vote bench" frame: 6 elliptical instances — random-init weights give no
+             usable instances)
+          -> [N > 1] RCCL all-gather of the per-instance pose records
+
+All inputs are resident in HBM before the timed region.  Weak scaling: every rank runs its own
+frame per step; `value` = N * K / max-over-ranks(time).
+
+Extra objects on the JSON line:
+  roofline      the hough-vote launch sequence (fpc_ransac_voting_v3): algorithmic bytes
+                n_instances * 12*H*W per call / HIP-event time of the call on its stream,
+                against the 8 TB/s HBM peak of MI355X_MICROARCH.md
+  cpu_baseline  the same step on the host: torch-CPU backbone + the C oracle's post-network path
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+if REPO not in sys.path:
+    sys.path.insert(0, REPO)
+
+HBM_PEAK_GBPS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured float4 copy)
+H, W = 480, 640
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--hn", type=int, default=1000, help="HV_NUM_OF_HYPOTHESES (1000 = config.INFERENCE)")
+    ap.add_argument("--encoder", default="resnet18")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--vote-only", action="store_true", help="time only the post-network stages (profiling aid)")
+    return ap.parse_args()
+
+
+def cpu_baseline(model_cpu, image, cat_cpu, hn, inv_k):
+    """One frame on the host: torch CPU backbone (+class compression) and the oracle's C
+    restatement of aggregation / voting / RT.  Bounded: one frame, a few seconds."""
+    from oracle import oracle as orc
+    orc.build()
+    threads = torch.get_num_threads()
+    with torch.no_grad():
+        t0 = time.perf_counter()
+        logits = model_cpu.pure_model_forward(image)
+        model_cpu.class_compression(logits)
+        t_net = time.perf_counter() - t0
+    cat_np = {k: v.numpy() for k, v in cat_cpu.items()}
+    t0 = time.perf_counter()
+    agg = orc.aggregate(cat_np)
+    vertex = agg["xy"].transpose(0, 2, 3, 1)[:, :, :, None, :]
+    xy = orc.ransac_voting_layer_v3(agg["instance_masks"], vertex, hn, seed=1)
+    orc.pose_rt(agg["quaternion"], xy[:, 0], agg["z"], inv_k)
+    t_post = time.perf_counter() - t0
+    return {"value": round(1.0 / (t_net + t_post), 4), "unit": "img/s", "cores": threads, "kind": "port",
+            "sample": f"1 frame: torch-CPU ResNet18-FPN forward + class compression on {threads} threads "
+                      f"({t_net * 1e3:.0f} ms) + oracle/fpc_oracle.c aggregation, hn={hn} voting and RT on 1 thread "
+                      f"({t_post * 1e3:.0f} ms); host has {os.cpu_count()} logical CPUs",
+            "net_ms": round(t_net * 1e3, 1), "post_ms": round(t_post * 1e3, 1)}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch N>1 with `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N`")
+        raise SystemExit(f"--gpus {args.gpus} does not match WORLD_SIZE {world}")
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    import fastposecnn_amd.lib as L
+    from fastposecnn_amd import config, synth, parallel, _native
+    _native.lib()      # fail loudly if the HIP library is missing
+
+    hp = config.INFERENCE()
+    hp.RUNTIME_TIMING = False
+    hp.HV_NUM_OF_HYPOTHESES = args.hn
+    hp.ENCODER = args.encoder
+    torch.manual_seed(0)
+    model = L.pose_regressor.MODELS[hp.MODEL].load_from_ckpt(None, hp).eval()
+    model_gpu = model.to(dev)
+    image = synth.make_image(rank)[None]                      # per-rank frame (weak scaling)
+    cat_cpu, _ = synth.make_vote_frame(rank)
+    x = image.to(dev)
+    cat = {k: v.to(dev) for k, v in cat_cpu.items()}
+    n_inst = int((torch.unique(cat_cpu["mask"]) != 0).sum())
+    cap = 64
+
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+    vote_ms = []
+
+    def step(timed):
+        with torch.no_grad():
+            if not args.vote_only:
+                logits = model_gpu.pure_model_forward(x)
+                model_gpu.class_compression(logits)
+            agg = model_gpu.aggregate(cat)
+            if timed:
+                ev[0].record()
+            agg = model_gpu.hough_voting(agg)
+            if timed:
+                ev[1].record()
+            agg = model_gpu.perform_RT_calculation(agg)
+            if world > 1:
+                parallel.all_gather_pose_records(agg, rank, cap)
+        return agg
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step(False)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step(False)
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    # vote roofline: separate, untimed-for-throughput loop with HIP events around the vote call
+    for _ in range(max(5, min(args.steps, 30))):
+        step(True)
+        ev[1].synchronize()
+        vote_ms.append(ev[0].elapsed_time(ev[1]))
+    vote_ms.sort()
+    vote_t = vote_ms[len(vote_ms) // 2] * 1e-3
+    alg_bytes = n_inst * 12 * H * W
+    achieved = alg_bytes / vote_t / 1e9
+
+    if rank == 0:
+        line = {
+            "metric": "img/s end-to-end 640x480 inference; hough-vote kernel HBM GB/s vs roofline",
+            "value": round(world * args.steps / dt, 3), "unit": "img/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{args.encoder}-FPN + all heads, batch=1 640x480 per GPU, hn={args.hn}, "
+                                   f"{n_inst} instances/frame (vote-bench fixture), random-init weights",
+                       "global_batch": world, "parallelism": f"image-sharded dp{world}" if world > 1 else "single GPU",
+                       "vote_only": bool(args.vote_only)},
+            "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": None,
+                         "kernel": "fpc_ransac_voting_v3 launch sequence (k_chunk_count..k_select_refine)",
+                         "algorithmic_bytes_per_launch": alg_bytes, "launch_ms": round(vote_t * 1e3, 4),
+                         "note": "HIP events on the launch stream around the whole call; at hn=1000 the count "
+                                 "kernel is VALU-bound (DESIGN.md)"},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(model.to("cpu"), image, cat_cpu, args.hn,
+                                                torch.inverse(torch.from_numpy(hp.NUMPY_INTRINSICS).float()).numpy())
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

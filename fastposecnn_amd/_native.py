@@ -1,0 +1,98 @@
+"""ctypes binding of libfpc_hip.so (C ABI in include/fpc.h).
+
+PyTorch is used for device memory and streams only: every call passes raw device
+pointers (`tensor.data_ptr()`) and the current HIP stream.  There is NO fallback: if the
+library is missing or a call fails, a RuntimeError is raised.
+"""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libfpc_hip.so")
+
+_lib = None
+
+_vp = ctypes.c_void_p
+_i = ctypes.c_int
+_i64 = ctypes.c_int64
+_u64 = ctypes.c_uint64
+_f = ctypes.c_float
+_sz = ctypes.c_size_t
+
+_SIGNATURES = {
+    "fpc_abi_version": (ctypes.c_int, []),
+    "fpc_error_string": (ctypes.c_char_p, [_i]),
+    "fpc_last_hip_error": (ctypes.c_char_p, []),
+    "fpc_generate_hypothesis": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
+    "fpc_voting_for_hypothesis": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _f, _vp]),
+    "fpc_ransac_workspace_bytes": (_sz, [_i, _i, _i, _i]),
+    "fpc_ransac_voting_v3": (_i, [_vp, _vp, _i64, _i64, _i64, _i64, _i, _i, _i, _i, _vp, _vp, _u64, _f, _i, _i,
+                                  _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "fpc_class_compress": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "fpc_cc_workspace_bytes": (_sz, [_i, _i, _i]),
+    "fpc_cc_label": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _i, _vp, _sz, _vp]),
+    "fpc_aggregate_workspace_bytes": (_sz, [_i]),
+    "fpc_aggregate": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz,
+                           _vp]),
+    "fpc_pose_rt": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp]),
+}
+
+EXPORTED = tuple(_SIGNATURES)
+
+
+def lib():
+    """Load the HIP library or raise.  Never returns a substitute."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"fastposecnn_amd: {LIB_PATH} is missing — build it with `python -m fastposecnn_amd.build` "
+                "(hipcc --offload-arch=gfx950). There is no CPU fallback for the HIP hot path.")
+        L = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGNATURES.items():
+            fn = getattr(L, name)
+            fn.restype = res
+            fn.argtypes = args
+        if L.fpc_abi_version() != 1:
+            raise RuntimeError("fastposecnn_amd: libfpc_hip.so ABI version mismatch")
+        _lib = L
+    return _lib
+
+
+def check(rc, what):
+    if rc != 0:
+        L = lib()
+        msg = L.fpc_error_string(rc).decode()
+        hip = L.fpc_last_hip_error().decode()
+        raise RuntimeError(f"fastposecnn_amd: {what} failed: {msg} (code {rc}){' — HIP: ' + hip if hip else ''}")
+
+
+def ptr(t):
+    """Raw device pointer of a tensor (None -> NULL)."""
+    return None if t is None else t.data_ptr()
+
+
+def stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def require_gpu(*tensors, what="this op"):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError(f"fastposecnn_amd: {what} runs only on GPU tensors (HIP kernels, no CPU fallback)")
+
+
+_workspaces = {}
+
+
+def workspace(tag, device, nbytes):
+    """Persistent, grow-only, 256-byte-aligned device scratch per (tag, device, stream)."""
+    key = (tag, device.index, stream())
+    ws = _workspaces.get(key)
+    if ws is None or ws.numel() < nbytes:
+        ws = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
+        assert ws.data_ptr() % 256 == 0
+        _workspaces[key] = ws
+    return ws

@@ -1,0 +1,55 @@
+"""Build libfpc_hip.so (gfx950) in-tree with hipcc.  `python -m fastposecnn_amd.build`.
+
+hipcc cross-compiles without a GPU; the .so is git-ignored but travels with the gpurun
+snapshot.  -ffp-contract=off: every float op is separately rounded, matching the CPU oracle
+bit for bit on the integer-valued outputs (inlier counts, winners, class ids, labels).
+"""
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+OBJ = os.path.join(CSRC, "_obj")
+LIB = os.path.join(HERE, "libfpc_hip.so")
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+ARCH = "gfx950"
+FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-ffp-contract=off", "-fno-fast-math",
+         "-Wall", "-Wno-unused-function", "-I", os.path.join(HERE, "..", "include")]
+
+
+def sources():
+    return sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hip"))
+
+
+def _deps_mtime():
+    hdrs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hpp")]
+    inc = os.path.join(HERE, "..", "include")
+    hdrs += [os.path.join(inc, f) for f in os.listdir(inc)]
+    return max(os.path.getmtime(h) for h in hdrs)
+
+
+def _compile(src, dep_mtime, force, extra):
+    obj = os.path.join(OBJ, os.path.basename(src)[:-4] + ".o")
+    if not force and os.path.exists(obj) and os.path.getmtime(obj) >= max(os.path.getmtime(src), dep_mtime):
+        return obj
+    subprocess.check_call([HIPCC, *FLAGS, *extra, "-c", src, "-o", obj])
+    return obj
+
+
+def build(force=False, verbose=False, extra=()):
+    os.makedirs(OBJ, exist_ok=True)
+    srcs = sources()
+    dep = _deps_mtime()
+    with ThreadPoolExecutor(max_workers=min(6, len(srcs))) as ex:
+        objs = list(ex.map(lambda s: _compile(s, dep, force, list(extra)), srcs))
+    if force or not os.path.exists(LIB) or os.path.getmtime(LIB) < max(os.path.getmtime(o) for o in objs):
+        subprocess.check_call([HIPCC, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", LIB, *objs])
+    if verbose:
+        print("built", LIB)
+    return LIB
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv, verbose=True)

@@ -1,0 +1,22 @@
+"""Drop-in for the reference's `lib` package (F/lib/__init__.py:1-10).
+
+Like the reference, the directory itself is put on sys.path and the modules are imported
+under their bare names (`gpu_tensor_funcs`, `aggregation_layer`, `hough_voting`,
+`pose_regressor`, `ransac_voting_gpu_layer.*`), so `train.py` / `evaluate.py` /
+`inference.py` keep working with `import lib` pointed at this directory.
+loss / matching / metrics are outside the hot path and are not shipped.
+"""
+import os
+import sys
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_ROOT = os.path.dirname(os.path.dirname(_HERE))
+if _ROOT not in sys.path:
+    sys.path.append(_ROOT)          # makes `fastposecnn_amd` importable when only lib/ was on the path
+if _HERE not in sys.path:
+    sys.path.insert(0, _HERE)
+
+import gpu_tensor_funcs as gtf  # noqa: E402
+import aggregation_layer  # noqa: E402
+import hough_voting  # noqa: E402
+import pose_regressor  # noqa: E402

@@ -1,0 +1,79 @@
+"""Drop-in for F/lib/aggregation_layer.py (AggregationLayer, :33-183) on libfpc_hip.so.
+
+forward(cat_data) returns the same AggData keys, dtypes and instance order as the reference
+(instances numbered by connected-component label: image by image, raster order of each
+component's first pixel).  One device->host read (the instance count N, needed to shape the
+outputs) replaces the reference's per-sample torch.unique / boolean-index synchronisations and
+the torch->cupy->torch hop.
+"""
+import torch
+import torch.nn as nn
+
+from fastposecnn_amd import _native as nat
+
+import hough_voting as hv
+
+
+class AggregationLayer(nn.Module):
+
+    def __init__(self, HPARAM, classes):
+        super().__init__()
+        self.HPARAM = HPARAM
+        self.classes = classes  # including background
+        self.hough_voting_layer = hv.HoughVotingLayer(self.HPARAM)
+        # 4-connectivity inside an image, nothing across the batch axis (reference :43-59)
+        self.s = torch.zeros((3, 3, 3), dtype=torch.bool)
+        self.s[1, 1, :] = True
+        self.s[1, :, 1] = True
+
+    def batchwise_break_segmentation_mask(self, class_mask, return_device_count=False):
+        """class_mask: bool/int [B,H,W] (foreground where != 0) -> (labels i32 [B,H,W], N)."""
+        nat.require_gpu(class_mask, what="AggregationLayer")
+        B, H, W = class_mask.shape
+        dev = class_mask.device
+        cm = class_mask if class_mask.dtype == torch.int64 else class_mask.to(torch.int64)
+        cm = cm.contiguous()
+        labels = torch.empty((B, H, W), dtype=torch.int32, device=dev)
+        n_dev = torch.zeros(1, dtype=torch.int32, device=dev)
+        L = nat.lib()
+        with torch.cuda.device(dev):
+            ws = nat.workspace("cc", dev, L.fpc_cc_workspace_bytes(B, H, W))
+            nat.check(L.fpc_cc_label(nat.ptr(cm), B, H, W, nat.ptr(labels), nat.ptr(n_dev), None, 0, nat.ptr(ws),
+                                     ws.numel(), nat.stream()), "fpc_cc_label")
+        if return_device_count:
+            return labels, n_dev
+        return labels, int(n_dev.item())
+
+    def forward(self, cat_data):
+        cat_mask = cat_data['mask']
+        nat.require_gpu(cat_mask, what="AggregationLayer")
+        dev = cat_mask.device
+        cm = cat_mask.to(torch.int64).contiguous()
+        B, H, W = cm.shape
+        labels, N = self.batchwise_break_segmentation_mask(cm)
+
+        f32 = dict(dtype=torch.float32, device=dev)
+        out = {
+            'class_ids': torch.empty((N,), dtype=torch.int64, device=dev),
+            'instance_masks': torch.empty((N, H, W), **f32),
+            'sample_ids': torch.empty((N,), dtype=torch.int64, device=dev),
+            'quaternion': torch.empty((N, 4), **f32),
+            'scales': torch.empty((N, 3), **f32),
+            'xy': torch.empty((N, 2, H, W), **f32),
+            'z': torch.empty((N, 1), **f32),
+        }
+        if N == 0:
+            # the reference returns float class ids for an empty batch (aggregation_layer.py:116)
+            out['class_ids'] = torch.empty((0,), **f32)
+            return out
+        q, s, xy, z = (t if (t.dtype == torch.float32 and t.is_contiguous()) else t.float().contiguous()
+                       for t in (cat_data['quaternion'], cat_data['scales'], cat_data['xy'], cat_data['z']))
+        L = nat.lib()
+        with torch.cuda.device(dev):
+            ws = nat.workspace("agg", dev, L.fpc_aggregate_workspace_bytes(N))
+            nat.check(L.fpc_aggregate(nat.ptr(labels), nat.ptr(cm), nat.ptr(q), nat.ptr(s), nat.ptr(xy), nat.ptr(z),
+                                      B, H, W, N, nat.ptr(out['class_ids']), nat.ptr(out['sample_ids']),
+                                      nat.ptr(out['instance_masks']), nat.ptr(out['quaternion']),
+                                      nat.ptr(out['scales']), nat.ptr(out['z']), nat.ptr(out['xy']),
+                                      nat.ptr(ws), ws.numel(), nat.stream()), "fpc_aggregate")
+        return out

@@ -1,0 +1,28 @@
+"""Drop-in for HoughVotingLayer.forward (F/lib/hough_voting.py:33-63).
+Lines :68-579 of the reference file are an older pure-torch voting scheme that is commented out
+of forward (:48) and unreachable; it is not provided."""
+import torch
+import torch.nn as nn
+
+import ransac_voting_gpu_layer.ransac_voting_gpu as rvg
+
+
+class HoughVotingLayer(nn.Module):
+
+    def __init__(self, HPARAM):
+        super().__init__()
+        self.HPARAM = HPARAM
+
+    def forward(self, agg_data):
+        uv_img = agg_data['xy']                # [n,2,H,W] masked vote field
+        mask = agg_data['instance_masks']      # [n,H,W]
+        # [n,H,W,1,2] strided VIEW of the two planes — read in place by the kernel
+        reshaped_uv_img = torch.unsqueeze(uv_img.permute(0, 2, 3, 1), dim=3)
+        output = rvg.ransac_voting_layer_v3(
+            mask=mask,
+            vertex=reshaped_uv_img,
+            round_hyp_num=self.HPARAM.HV_NUM_OF_HYPOTHESES,
+        )
+        good_output = torch.squeeze(output, dim=1)
+        agg_data.update({'hypothesis': output, 'pruned_hypothesis': output, 'xy': good_output, 'xy_mask': uv_img})
+        return agg_data

@@ -1,0 +1,91 @@
+"""Drop-in for RV/ransac_voting_gpu.py's live surface: `ransac_voting_layer_v3` (:518-607)
+and `b_inv` (:503-516).  The other 13 variants of the reference are never called from
+FastPoseCNN and are not provided.
+
+`ransac_voting_layer_v3` keeps the reference signature.  The whole per-instance Python loop —
+mask compaction, pair sampling, hypothesis generation, voting, arg-max, winner re-vote and the
+2x2 normal-equation solve — runs as one enqueue of HIP kernels for the entire batch
+(fastposecnn_amd/csrc/ransac.hip); no device->host synchronisation happens here.
+`confidence` / `max_iter` are accepted and ignored: the reference re-votes the SAME samples
+every round (idxs is drawn once, :552) so its result does not depend on them.
+
+Keyword-only extensions (not in the reference): `idxs` (i32 [b,hn,vn,2]) injects the RANSAC
+pairs, `keep` (u8/bool [b,h,w]) injects the > max_num thinning selection, `seed` fixes the
+built-in counter-based sampler (include/fpc_rng.h; default: drawn from torch's CPU generator,
+so torch.manual_seed() makes runs repeatable), `return_debug` also returns per-instance
+diagnostics (tn, win_idx, win_count, inlier_count, hyp, counts).
+"""
+import torch
+
+from fastposecnn_amd import _native as nat
+
+
+def b_inv(b_mat):
+    """Batched inverse with pseudo-inverse fallback on singular input (reference :503-516)."""
+    try:
+        return torch.linalg.inv(b_mat)
+    except RuntimeError:  # singular
+        return torch.pinverse(b_mat)
+
+
+def ransac_voting_layer_v3(mask, vertex, round_hyp_num, inlier_thresh=0.999, confidence=0.99, max_iter=20,
+                           min_num=5, max_num=30000, *, idxs=None, keep=None, seed=None, return_debug=False):
+    """
+    :param mask:      [b,h,w]   foreground where != 0
+    :param vertex:    [b,h,w,vn,2]  (any strides; the permuted view of hough_voting.py:51 is read in place)
+    :param round_hyp_num: hypotheses per instance
+    :return: [b,vn,2]  (x = column, y = row)
+    """
+    nat.require_gpu(mask, vertex, what="ransac_voting_layer_v3")
+    b, h, w, vn, two = vertex.shape
+    if two != 2 or tuple(mask.shape) != (b, h, w):
+        raise RuntimeError("ransac_voting_layer_v3: mask [b,h,w] / vertex [b,h,w,vn,2] shape mismatch")
+    hn = int(round_hyp_num)
+    dev = mask.device
+    out = torch.zeros((b, vn, 2), dtype=torch.float32, device=dev)
+    dbg = []
+    if b == 0:
+        # the reference's torch.cat([]) guard (:602-605)
+        return (out, dbg) if return_debug else out
+    if mask.dtype != torch.float32 or not mask.is_contiguous():
+        mask = mask.to(torch.float32).contiguous()
+    if vertex.dtype != torch.float32:
+        vertex = vertex.float()
+    if keep is not None:
+        keep = keep.to(torch.uint8).contiguous()
+    if seed is None:
+        seed = int(torch.randint(0, 2 ** 62, (1,)).item())
+    L = nat.lib()
+    es = vertex.element_size()
+    with torch.cuda.device(dev):
+        ws = nat.workspace("ransac", dev, L.fpc_ransac_workspace_bytes(b, h, w, hn))
+        for vi in range(vn):
+            v = vertex[:, :, :, vi, :]
+            sn, sh, sw, sc = v.stride()
+            ii = None
+            if idxs is not None:
+                ii = idxs[:, :, vi, :].to(device=dev, dtype=torch.int32).contiguous()
+                if tuple(ii.shape) != (b, hn, 2):
+                    raise RuntimeError("ransac_voting_layer_v3: idxs must be [b,hn,vn,2]")
+            xy = out[:, vi, :] if vn == 1 else torch.empty((b, 2), dtype=torch.float32, device=dev)
+            d = None
+            if return_debug:
+                d = dict(tn=torch.empty(b, dtype=torch.int32, device=dev),
+                         win_idx=torch.empty(b, dtype=torch.int32, device=dev),
+                         win_count=torch.empty(b, dtype=torch.int32, device=dev),
+                         inlier_count=torch.empty(b, dtype=torch.int32, device=dev),
+                         hyp=torch.empty((b, hn, 2), dtype=torch.float32, device=dev),
+                         counts=torch.empty((b, hn), dtype=torch.int32, device=dev))
+            nat.check(L.fpc_ransac_voting_v3(
+                nat.ptr(mask), v.data_ptr(), sn, sh, sw, sc, b, h, w, hn, nat.ptr(ii), nat.ptr(keep),
+                (seed + vi) & (2 ** 64 - 1), float(inlier_thresh), int(min_num), int(max_num), nat.ptr(xy),
+                nat.ptr(d["tn"]) if d else None, nat.ptr(d["win_idx"]) if d else None,
+                nat.ptr(d["win_count"]) if d else None, nat.ptr(d["inlier_count"]) if d else None,
+                nat.ptr(d["hyp"]) if d else None, nat.ptr(d["counts"]) if d else None,
+                nat.ptr(ws), ws.numel(), nat.stream()), "fpc_ransac_voting_v3")
+            if vn != 1:
+                out[:, vi, :] = xy
+            if d:
+                dbg.append(d)
+    del es
+    return (out, dbg) if return_debug else out

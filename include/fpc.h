@@ -1,0 +1,129 @@
+/* fpc.h — C ABI of libfpc_hip.so: the MI355X (gfx950) implementation of
+ * FastPoseCNN's per-frame post-network hot path.
+ *
+ * This is the drop-in boundary.  Plain pointers and sizes only; no torch types.
+ * Every pointer marked "device" must be device-accessible memory of the GPU
+ * that is current on the calling thread; every function
+ *   - allocates nothing and frees nothing (caller-owned buffers + workspace),
+ *   - enqueues its kernels on `stream` (a hipStream_t, passed as void*; NULL is
+ *     the default stream) and returns without synchronising,
+ *   - returns FPC_OK or a negative FPC_E* code — it never exits the process
+ *     (the reference's gpuAssert calls exit(), RV/src/cuda_common.h:17-26).
+ *
+ * Reference interfaces replaced (paths under /root/reference/source_code/FastPoseCNN,
+ * RV = lib/ransac_voting_gpu_layer):
+ *   fpc_generate_hypothesis      RV/src/ransac_voting.cpp:20-31  (+ kernel RV/src/ransac_voting_kernel.cu:11-86)
+ *   fpc_voting_for_hypothesis    RV/src/ransac_voting.cpp:41-55  (+ kernel .cu:88-167)
+ *   fpc_ransac_voting_v3         RV/ransac_voting_gpu.py:518-607 (ransac_voting_layer_v3 + b_inv :503-516)
+ *   fpc_class_compress           lib/pose_regressor.py:445-457, lib/gpu_tensor_funcs.py:37-99
+ *   fpc_cc_label                 lib/aggregation_layer.py:160-183 (cupyx / scipy ndimage.label)
+ *   fpc_aggregate                lib/aggregation_layer.py:61-158
+ *   fpc_pose_rt                  lib/gpu_tensor_funcs.py:204-253, 306-326
+ * The Python-side bindings a maintainer would add are shown in INTEGRATION.md.
+ */
+#ifndef FPC_H_
+#define FPC_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FPC_ABI_VERSION 1
+
+#define FPC_OK 0
+#define FPC_EINVAL (-1)      /* bad argument (shape, null pointer, ...) */
+#define FPC_EWORKSPACE (-2)  /* workspace too small / misaligned */
+#define FPC_ELAUNCH (-3)     /* HIP reported a launch error (hipGetLastError) */
+#define FPC_EDEVICE (-4)     /* not running on a gfx950 device / no device */
+
+typedef void* fpc_stream_t;  /* hipStream_t */
+
+int fpc_abi_version(void);
+const char* fpc_error_string(int code);
+/* Text of the last HIP error seen by this thread's failing call ("" if none). */
+const char* fpc_last_hip_error(void);
+
+/* ---- B1: the reference extension's two live entry points ------------------
+ * direct f32 [tn,vn,2], coords f32 [tn,2] (x = column, y = row), idxs i32 [hn,vn,2]
+ * -> hyp f32 [hn,vn,2].  hyp is fully written (zero where the pair is degenerate,
+ * as the reference's zero-initialised result tensor).  All device, contiguous. */
+int fpc_generate_hypothesis(const float* direct, const float* coords, const int32_t* idxs,
+                            float* hyp, int tn, int vn, int hn, fpc_stream_t stream);
+
+/* inliers u8 [hn,vn,tn] is caller-owned and only ever written with 1
+ * (the caller pre-zeroes it, RV/ransac_voting_gpu.py:562). */
+int fpc_voting_for_hypothesis(const float* direct, const float* coords, const float* hyp,
+                              uint8_t* inliers, int tn, int vn, int hn, float inlier_thresh,
+                              fpc_stream_t stream);
+
+/* ---- B2: fused ransac_voting_layer_v3 for one keypoint channel ------------
+ * mask    f32 [n,H,W] contiguous, foreground iff != 0
+ * vertex  base pointer of the [n,H,W,(vn),2] view for the chosen keypoint, with
+ *         ELEMENT strides vs_n, vs_h, vs_w, vs_c (the reference passes a permuted
+ *         view of two planes, lib/hough_voting.py:51 — no copy is needed)
+ * idxs    i32 [n,hn,2] injected pair indices, or NULL -> include/fpc_rng.h stream(seed)
+ * keep    u8 [n,H,W] injected thinning selection (used only where fg > max_num), or NULL
+ * out_xy  f32 [n,2]
+ * optional diagnostics (NULL to skip): out_tn, out_win_idx, out_win_count,
+ *         out_inl_count i32 [n]; out_hyp f32 [n,hn,2]; out_counts i32 [n,hn]
+ * ws      device workspace of at least fpc_ransac_workspace_bytes(n,H,W,hn) bytes,
+ *         256-byte aligned.  Contents are scratch. */
+size_t fpc_ransac_workspace_bytes(int n, int H, int W, int hn);
+int fpc_ransac_voting_v3(const float* mask, const float* vertex,
+                         int64_t vs_n, int64_t vs_h, int64_t vs_w, int64_t vs_c,
+                         int n, int H, int W, int hn,
+                         const int32_t* idxs, const uint8_t* keep, uint64_t seed,
+                         float inlier_thresh, int min_num, int max_num,
+                         float* out_xy, int32_t* out_tn, int32_t* out_win_idx,
+                         int32_t* out_win_count, int32_t* out_inl_count,
+                         float* out_hyp, int32_t* out_counts,
+                         void* ws, size_t ws_bytes, fpc_stream_t stream);
+
+/* ---- class compression ------------------------------------------------------
+ * mask_logits f32 [B,C,HW]; quat [B,4(C-1),HW]; scales [B,3(C-1),HW]; xy [B,2(C-1),HW];
+ * z [B,(C-1),HW]; cat_mask_in i64 [B,HW] or NULL (NULL: arg-max of log-softmax, first
+ * maximal index on ties; mask_logits may be NULL when cat_mask_in is given).
+ * -> cat_mask i64 [B,HW], oq [B,4,HW], os [B,3,HW], oxy [B,2,HW], oz [B,HW]. */
+int fpc_class_compress(const float* mask_logits, const float* quat, const float* scales,
+                       const float* xy, const float* z, const int64_t* cat_mask_in,
+                       int B, int C, int HW,
+                       int64_t* cat_mask, float* oq, float* os, float* oxy, float* oz,
+                       fpc_stream_t stream);
+
+/* ---- connected components ---------------------------------------------------
+ * cat_mask i64 [B,H,W]; foreground iff != 0; 4-connectivity inside an image, none
+ * across images.  labels i32 [B,H,W]: 0 background, 1..N numbered in raster order of
+ * each component's first pixel, continuing across the batch (scipy.ndimage.label order).
+ * n_out: DEVICE i32[1] receiving N.  root_pix: DEVICE i32 [cap] (nullable) receiving the
+ * linear index (over B*H*W) of each component's first pixel for labels 1..min(N,cap). */
+size_t fpc_cc_workspace_bytes(int B, int H, int W);
+int fpc_cc_label(const int64_t* cat_mask, int B, int H, int W,
+                 int32_t* labels, int32_t* n_out, int32_t* root_pix, int cap,
+                 void* ws, size_t ws_bytes, fpc_stream_t stream);
+
+/* ---- aggregation ------------------------------------------------------------
+ * labels i32 [B,H,W] from fpc_cc_label, N instances (host value, read back by the
+ * caller), categorical planes quat [B,4,HW], scales [B,3,HW], xy [B,2,HW], z [B,HW].
+ * -> class_ids i64 [N], sample_ids i64 [N], inst_masks f32 [N,HW] (nullable),
+ *    oq [N,4], os [N,3], oz [N], oxy f32 [N,2,HW] (nullable). */
+size_t fpc_aggregate_workspace_bytes(int N);
+int fpc_aggregate(const int32_t* labels, const int64_t* cat_mask,
+                  const float* quat, const float* scales, const float* xy, const float* z,
+                  int B, int H, int W, int N,
+                  int64_t* class_ids, int64_t* sample_ids, float* inst_masks,
+                  float* oq, float* os, float* oz, float* oxy,
+                  void* ws, size_t ws_bytes, fpc_stream_t stream);
+
+/* ---- pose assembly ----------------------------------------------------------
+ * q f32 [n,4] scalar-last, xy [n,2], z [n], kinv f32 [9] row-major (device)
+ * -> R [n,9], T [n,3], RT [n,16]. */
+int fpc_pose_rt(const float* q, const float* xy, const float* z, const float* kinv, int n,
+                float* R, float* T, float* RT, fpc_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FPC_H_ */

@@ -1,0 +1,338 @@
+"""GPU parity: libfpc_hip.so (through the reference-shaped Python API, i.e. through the C ABI)
+against the CPU oracle on identical inputs, against the committed golden vectors, and at full
+640x480 size through size-independent properties.
+
+Bars (BASELINE.json north_star): integer / index outputs bit-exact (class ids, labels, instance
+order, pixel counts, inlier counts, winning hypothesis); floating point within 1e-4.
+"""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    return torch.device("cuda:0")
+
+
+@pytest.fixture(scope="module")
+def lib(dev):
+    import fastposecnn_amd.lib as L          # puts the drop-in modules on sys.path
+    from fastposecnn_amd import _native
+    _native.lib()                             # raises if libfpc_hip.so is missing: no silent fallback
+    return L
+
+
+def T(a, dev):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+
+# ----------------------------------------------------------------------------- B1 kernels
+
+def test_b1_kernels_bit_exact(lib, oracle, dev):
+    import ransac_voting_gpu_layer.ransac_voting as ext
+    rng = np.random.default_rng(0)
+    for tn, vn, hn in [(500, 1, 64), (1777, 3, 130), (5, 1, 7)]:
+        coords = np.stack([rng.integers(0, 640, tn), rng.integers(0, 480, tn)], 1).astype(np.float32)
+        ang = rng.uniform(0, 2 * np.pi, (tn, vn))
+        direct = np.stack([np.cos(ang), np.sin(ang)], -1).astype(np.float32)
+        direct[::17] = 0                                       # zero votes (norm1 skip)
+        direct[1::2, 0] = direct[0, 0]                         # many exactly parallel pairs
+        idxs = rng.integers(0, tn, (hn, vn, 2)).astype(np.int32)
+        idxs[0, :, 1] = idxs[0, :, 0]                          # identical pair -> degenerate
+        hyp = ext.generate_hypothesis(T(direct, dev), T(coords, dev), T(idxs, dev))
+        want = oracle.generate_hypothesis(direct, coords, idxs)
+        assert np.array_equal(hyp.cpu().numpy(), want)
+        inl = torch.zeros((hn, vn, tn), dtype=torch.uint8, device=dev)
+        ext.voting_for_hypothesis(T(direct, dev), T(coords, dev), hyp, inl, 0.999)
+        winl = np.zeros((hn, vn, tn), np.uint8)
+        oracle.voting_for_hypothesis(direct, coords, want, winl, 0.999)
+        assert np.array_equal(inl.cpu().numpy(), winl)
+        inl.fill_(7)                                           # only ever writes 1
+        ext.voting_for_hypothesis(T(direct, dev), T(coords, dev), hyp, inl, 0.999)
+        assert set(torch.unique(inl).tolist()) <= {1, 7}
+
+
+def test_b1_input_checks(lib, dev):
+    import ransac_voting_gpu_layer.ransac_voting as ext
+    d = torch.zeros((4, 1, 2), device=dev); c = torch.zeros((4, 2), device=dev)
+    i = torch.zeros((3, 1, 2), dtype=torch.int32, device=dev)
+    with pytest.raises(RuntimeError):
+        ext.generate_hypothesis(d.cpu(), c, i)                 # CHECK_CUDA
+    with pytest.raises(RuntimeError):
+        ext.generate_hypothesis(torch.zeros((4, 1, 4), device=dev)[:, :, ::2], c, i)   # CHECK_CONTIGUOUS
+    with pytest.raises(NotImplementedError):
+        ext.generate_hypothesis_vanishing_point(d, c, i)
+
+
+# ----------------------------------------------------------------------------- fused v3
+
+def _run_v3(lib, dev, mask, vertex, hn, **kw):
+    import ransac_voting_gpu_layer.ransac_voting_gpu as rvg
+    out, dbg = rvg.ransac_voting_layer_v3(T(mask, dev), vertex, hn, return_debug=True, **kw)
+    torch.cuda.synchronize()
+    return out.cpu().numpy(), [{k: v.cpu().numpy() for k, v in d.items()} for d in dbg]
+
+
+def _assert_v3_equal(out, dbg, want, wdbg):
+    for k in ("tn", "win_idx", "win_count", "inlier_count"):
+        assert np.array_equal(dbg[0][k], wdbg[0][k]), k
+    assert np.array_equal(dbg[0]["hyp"], wdbg[0]["hyp"])       # same divisions, bit for bit
+    assert np.array_equal(dbg[0]["counts"], wdbg[0]["counts"]) # every one of the hn x tn decisions agrees
+    np.testing.assert_allclose(out, want, atol=1e-4, rtol=0)
+
+
+def test_v3_golden_small(lib, oracle, dev):
+    g = load_golden("vote_small.npz")
+    xy = T(g["xy"], dev)
+    vertex = xy.permute(0, 2, 3, 1).unsqueeze(3)               # strided view, as hough_voting.py:51
+    out, dbg = _run_v3(lib, dev, g["mask"], vertex, int(g["hn"]), idxs=T(g["idxs"], dev))
+    want, wdbg = oracle.ransac_voting_layer_v3(g["mask"], g["xy"].transpose(0, 2, 3, 1)[:, :, :, None, :],
+                                               int(g["hn"]), idxs=g["idxs"], return_debug=True)
+    _assert_v3_equal(out, dbg, want, wdbg)
+    np.testing.assert_allclose(out, g["expected"], atol=2e-3, rtol=0)      # the reference's own driver
+    assert np.array_equal(out[3], np.zeros((1, 2))) and np.array_equal(out[4], np.zeros((1, 2)))
+    assert abs(out[6, 0, 1] - 2.0 / 3.0) < 1e-6                # rank-1 normal equations -> pinverse
+
+
+def test_v3_golden_thinning(lib, oracle, dev):
+    g = load_golden("vote_thin.npz")
+    vertex = T(g["xy"], dev).permute(0, 2, 3, 1).unsqueeze(3)
+    out, dbg = _run_v3(lib, dev, g["mask"], vertex, int(g["hn"]), idxs=T(g["idxs"], dev), keep=T(g["keep"], dev),
+                       max_num=int(g["max_num"]))
+    want, wdbg = oracle.ransac_voting_layer_v3(g["mask"], g["xy"].transpose(0, 2, 3, 1)[:, :, :, None, :],
+                                               int(g["hn"]), idxs=g["idxs"], keep=g["keep"],
+                                               max_num=int(g["max_num"]), return_debug=True)
+    _assert_v3_equal(out, dbg, want, wdbg)
+    np.testing.assert_allclose(out, g["expected"], atol=2e-3, rtol=0)
+
+
+def test_v3_golden_fullres(lib, oracle, dev):
+    g = load_golden("vote_fullres.npz")
+    H, W = int(g["H"]), int(g["W"])
+    mask = np.zeros((2, H * W), np.float32); xy = np.zeros((2, 2, H * W), np.float32)
+    for i in range(2):
+        mask[i, g[f"pix{i}"]] = 1
+        xy[i, 0, g[f"pix{i}"]] = g[f"dir{i}"][:, 0]; xy[i, 1, g[f"pix{i}"]] = g[f"dir{i}"][:, 1]
+    mask = mask.reshape(2, H, W); xy = xy.reshape(2, 2, H, W)
+    vertex = T(xy, dev).permute(0, 2, 3, 1).unsqueeze(3)
+    out, dbg = _run_v3(lib, dev, mask, vertex, int(g["hn"]), idxs=T(g["idxs"], dev))
+    want, wdbg = oracle.ransac_voting_layer_v3(mask, xy.transpose(0, 2, 3, 1)[:, :, :, None, :], int(g["hn"]),
+                                               idxs=g["idxs"], return_debug=True)
+    _assert_v3_equal(out, dbg, want, wdbg)
+    np.testing.assert_allclose(out, g["expected"], atol=2e-3, rtol=0)
+
+
+def test_v3_builtin_sampler_matches_oracle_stream(lib, oracle, dev):
+    """No injected idxs: the HIP sampler and the oracle share include/fpc_rng.h, so equal seeds
+    give equal samples, and the built-in > max_num thinning keeps the same pixels."""
+    g = load_golden("vote_small.npz")
+    vertex = T(g["xy"], dev).permute(0, 2, 3, 1).unsqueeze(3)
+    for kw in (dict(seed=11), dict(seed=12, max_num=100)):
+        out, dbg = _run_v3(lib, dev, g["mask"], vertex, 200, **kw)
+        want, wdbg = oracle.ransac_voting_layer_v3(g["mask"], g["xy"].transpose(0, 2, 3, 1)[:, :, :, None, :], 200,
+                                                   return_debug=True, **kw)
+        _assert_v3_equal(out, dbg, want, wdbg)
+    assert (dbg[0]["tn"][:2] < (g["mask"][:2] != 0).sum((1, 2))).all()       # thinned
+
+
+def test_v3_edge_shapes(lib, dev):
+    import ransac_voting_gpu_layer.ransac_voting_gpu as rvg
+    out = rvg.ransac_voting_layer_v3(torch.zeros((0, 8, 8), device=dev), torch.zeros((0, 8, 8, 1, 2), device=dev), 16)
+    assert tuple(out.shape) == (0, 1, 2)
+    out = rvg.ransac_voting_layer_v3(torch.zeros((2, 9, 7), device=dev), torch.zeros((2, 9, 7, 1, 2), device=dev), 16)
+    assert torch.equal(out.cpu(), torch.zeros((2, 1, 2)))
+    with pytest.raises(RuntimeError):
+        rvg.ransac_voting_layer_v3(torch.zeros((1, 8, 8)), torch.zeros((1, 8, 8, 1, 2)), 16)   # CPU tensors: no fallback
+    # vn = 2 keypoints, odd plane size (scalar tail of the 4-pixel chunks), bool mask
+    H, W = 13, 11
+    yy, xx = np.mgrid[0:H, 0:W].astype(np.float32)
+    v = np.zeros((1, H, W, 2, 2), np.float32)
+    for k, (cx, cy) in enumerate([(4.5, 6.25), (8.0, 3.0)]):
+        d = np.stack([cx - xx, cy - yy], -1); d /= np.maximum(np.linalg.norm(d, axis=-1, keepdims=True), 1e-9)
+        v[0, :, :, k, :] = d
+    out = rvg.ransac_voting_layer_v3(torch.ones((1, H, W), dtype=torch.bool, device=dev), T(v, dev), 64, seed=1)
+    np.testing.assert_allclose(out.cpu().numpy()[0], [[4.5, 6.25], [8.0, 3.0]], atol=1e-3)
+
+
+# ----------------------------------------------------------------------------- class compression
+
+def test_class_compress_golden_and_oracle(lib, oracle, dev):
+    import gpu_tensor_funcs as gtf
+    g = load_golden("class_compress.npz")
+    C = int(g["num_classes"])
+    logits_np = {k[3:]: v for k, v in g.items() if k.startswith("in_")}
+    logits = {k: T(v, dev) for k, v in logits_np.items()}
+    cat = gtf.class_compression_fused(C, logits)
+    want = oracle.class_compress(logits_np, C)
+    assert cat["mask"].dtype == torch.int64
+    assert np.array_equal(cat["mask"].cpu().numpy(), g["out_mask"])         # ids bit-exact vs the reference
+    assert np.array_equal(cat["mask"].cpu().numpy(), want["mask"])
+    for k in ("scales", "z"):
+        assert np.array_equal(cat[k].cpu().numpy(), g["out_" + k])          # pure selection: exact
+    for k in ("quaternion", "xy"):
+        assert cat[k].shape == tuple(g["out_" + k].shape)
+        np.testing.assert_allclose(cat[k].cpu().numpy(), g["out_" + k], atol=1e-6, rtol=1e-6)
+        np.testing.assert_allclose(cat[k].cpu().numpy(), want[k], atol=1e-6, rtol=1e-6)
+    # reference signature with a caller-supplied mask
+    cat2 = gtf.class_compress(C, T(g["in2_mask"], dev), logits)
+    assert "mask" not in cat2
+    for k in ("quaternion", "scales", "xy", "z"):
+        np.testing.assert_allclose(cat2[k].cpu().numpy(), g["out2_" + k], atol=1e-6, rtol=1e-6)
+
+
+def test_class_compress_fullsize_properties(lib, dev):
+    import gpu_tensor_funcs as gtf
+    torch.manual_seed(3)
+    B, C, H, W = 2, 7, 480, 640
+    logits = {"mask": torch.randn(B, C, H, W, device=dev), "quaternion": torch.randn(B, 24, H, W, device=dev),
+              "scales": torch.randn(B, 18, H, W, device=dev), "xy": torch.randn(B, 12, H, W, device=dev),
+              "z": torch.randn(B, 6, H, W, device=dev)}
+    cat = gtf.class_compression_fused(C, logits)
+    ref_mask = torch.argmax(torch.nn.LogSoftmax(dim=1)(logits["mask"]), dim=1)
+    assert (cat["mask"] != ref_mask).sum().item() <= 2          # only rounding-level ties may differ
+    fg = cat["mask"] != 0
+    qn = cat["quaternion"].norm(dim=1)
+    assert torch.allclose(qn[fg], torch.ones_like(qn[fg]), atol=1e-5) and (qn[~fg] == 0).all()
+    sel = torch.gather(logits["z"], 1, (cat["mask"] - 1).clamp(min=0).unsqueeze(1)).squeeze(1) * fg
+    assert torch.equal(cat["z"], sel)
+    # idempotence of the compression given its own mask
+    again = gtf.class_compress(C, cat["mask"], logits)
+    for k in ("quaternion", "scales", "xy", "z"):
+        assert torch.equal(again[k], cat[k])
+
+
+# ----------------------------------------------------------------------------- connected components
+
+@pytest.mark.parametrize("shape,p", [((3, 37, 53), 0.55), ((2, 64, 64), 0.6), ((1, 480, 640), 0.58), ((4, 40, 56), 0.3)])
+def test_cc_label_matches_oracle(lib, oracle, dev, shape, p):
+    import aggregation_layer as al
+    rng = np.random.default_rng(shape[1])
+    fg = rng.random(shape) < p
+    fg[0, :, 0] = True; fg[-1, -1, :] = True                   # long vertical / horizontal runs
+    layer = al.AggregationLayer(None, 7)
+    labels, N = layer.batchwise_break_segmentation_mask(T(fg, dev))
+    want, M = oracle.cc_label(fg)
+    assert N == M and labels.dtype == torch.int32
+    assert np.array_equal(labels.cpu().numpy(), want)
+
+
+def test_cc_label_structures(lib, oracle, dev):
+    import aggregation_layer as al
+    layer = al.AggregationLayer(None, 7)
+    H, W = 96, 128
+    fg = np.zeros((3, H, W), bool)
+    fg[0] = True                                               # one component covering the frame
+    yy, xx = np.mgrid[0:H, 0:W]
+    fg[1] = ((xx // 3 + yy // 3) % 2 == 0)                     # checkerboard of 3x3 cells: diagonal contacts only
+    fg[2] = ((xx % 8 < 4) | (yy == H - 1))                     # comb: teeth joined by the LAST row (late merges)
+    labels, N = layer.batchwise_break_segmentation_mask(T(fg, dev))
+    want, M = oracle.cc_label(fg)
+    assert N == M and np.array_equal(labels.cpu().numpy(), want)
+    labels, N = layer.batchwise_break_segmentation_mask(torch.zeros((2, 8, 8), dtype=torch.bool, device=dev))
+    assert N == 0 and int(labels.abs().sum()) == 0
+
+
+# ----------------------------------------------------------------------------- aggregation / pose
+
+def test_aggregate_golden(lib, oracle, dev):
+    import aggregation_layer as al
+    g = load_golden("aggregate.npz")
+    cat = {k[3:]: T(v, dev) for k, v in g.items() if k.startswith("in_")}
+    agg = al.AggregationLayer(None, 7).forward(cat)
+    assert np.array_equal(agg["class_ids"].cpu().numpy(), g["out_class_ids"].astype(np.int64))
+    assert np.array_equal(agg["sample_ids"].cpu().numpy(), g["out_sample_ids"])
+    assert np.array_equal(agg["instance_masks"].cpu().numpy(), g["out_instance_masks"])
+    assert np.array_equal(agg["xy"].cpu().numpy(), g["out_xy"])
+    for k in ("quaternion", "scales", "z"):
+        assert tuple(agg[k].shape) == g["out_" + k].shape
+        np.testing.assert_allclose(agg[k].cpu().numpy(), g["out_" + k], atol=1e-5, rtol=1e-5)
+    e = load_golden("aggregate_empty.npz")
+    agg0 = al.AggregationLayer(None, 7).forward({k: torch.zeros_like(v) for k, v in cat.items()})
+    for k in ("class_ids", "sample_ids", "instance_masks", "quaternion", "scales", "xy", "z"):
+        assert tuple(agg0[k].shape) == e["out_" + k].shape, k
+
+
+def test_pose_rt_golden(lib, oracle, dev):
+    import gpu_tensor_funcs as gtf
+    g = load_golden("pose_rt.npz")
+    R, Tt, RT = gtf.batchwise_get_RT(T(g["q"], dev), T(g["xy"], dev), T(g["z"], dev), T(g["Kinv"], dev))
+    wR, wT, wRT = oracle.pose_rt(g["q"], g["xy"], g["z"], g["Kinv"])
+    np.testing.assert_allclose(R.cpu().numpy(), wR, atol=1e-6); np.testing.assert_allclose(Tt.cpu().numpy(), wT, atol=1e-6, rtol=1e-6)
+    np.testing.assert_allclose(RT.cpu().numpy(), wRT, atol=1e-5, rtol=1e-6)
+    np.testing.assert_allclose(R.cpu().numpy(), g["R"], atol=1e-5)
+    np.testing.assert_allclose(Tt.cpu().numpy(), g["T"], atol=1e-5, rtol=1e-5)
+    np.testing.assert_allclose(RT.cpu().numpy(), g["RT"], atol=1e-4, rtol=1e-5)
+
+
+def test_pipeline_golden(lib, oracle, dev):
+    """logits -> class compression -> aggregation -> hough voting -> RT against the reference run."""
+    import gpu_tensor_funcs as gtf
+    import aggregation_layer as al
+    import ransac_voting_gpu_layer.ransac_voting_gpu as rvg
+    g = load_golden("pipeline.npz")
+    C, hn = int(g["num_classes"]), int(g["hn"])
+    logits = {k[7:]: T(v, dev) for k, v in g.items() if k.startswith("logits_")}
+    cat = gtf.class_compression_fused(C, logits)
+    assert np.array_equal(cat["mask"].cpu().numpy(), g["cat_mask"])
+    agg = al.AggregationLayer(None, C).forward(cat)
+    assert np.array_equal(agg["class_ids"].cpu().numpy(), g["agg_class_ids"].astype(np.int64))
+    assert np.array_equal(agg["sample_ids"].cpu().numpy(), g["agg_sample_ids"])
+    assert np.array_equal(agg["instance_masks"].cpu().numpy(), g["agg_instance_masks"])
+    vertex = agg["xy"].permute(0, 2, 3, 1).unsqueeze(3)
+    hyp = rvg.ransac_voting_layer_v3(agg["instance_masks"], vertex, hn, idxs=T(g["idxs"], dev))
+    np.testing.assert_allclose(hyp.cpu().numpy(), g["agg_hypothesis"], atol=2e-3)
+    agg.update({"xy": hyp.squeeze(1)})
+    agg = gtf.samplewise_get_RT(agg, T(g["Kinv"], dev))
+    for k, tol in (("R", 1e-4), ("T", 1e-4), ("RT", 1e-4), ("quaternion", 1e-4), ("scales", 1e-4), ("z", 1e-2)):
+        np.testing.assert_allclose(agg[k].cpu().numpy(), g["agg_" + k], atol=tol, rtol=1e-5)
+
+
+# ----------------------------------------------------------------------------- full size
+
+def test_fullsize_vote_bench_frame(lib, oracle, dev):
+    """The 640x480 bench fixture (6 instances, hn = 1000): HIP == oracle on every integer output,
+    fused counts == column sums of the B1 inlier matrix, and the centres are recovered."""
+    import aggregation_layer as al
+    import ransac_voting_gpu_layer.ransac_voting_gpu as rvg
+    import ransac_voting_gpu_layer.ransac_voting as ext
+    from fastposecnn_amd import synth
+    cat_cpu, centres = synth.make_vote_frame(0)
+    cat = {k: v.to(dev) for k, v in cat_cpu.items()}
+    agg = al.AggregationLayer(None, 7).forward(cat)
+    want_agg = oracle.aggregate({k: v.numpy() for k, v in cat_cpu.items()})
+    assert np.array_equal(agg["class_ids"].cpu().numpy(), want_agg["class_ids"])
+    assert np.array_equal(agg["instance_masks"].cpu().numpy(), want_agg["instance_masks"])
+    assert np.array_equal(agg["xy"].cpu().numpy(), want_agg["xy"])
+    for k in ("quaternion", "scales", "z"):
+        np.testing.assert_allclose(agg[k].cpu().numpy(), want_agg[k], atol=1e-5, rtol=1e-5)
+    hn = 1000
+    vertex = agg["xy"].permute(0, 2, 3, 1).unsqueeze(3)
+    out, dbg = rvg.ransac_voting_layer_v3(agg["instance_masks"], vertex, hn, seed=2026, return_debug=True)
+    want, wdbg = oracle.ransac_voting_layer_v3(want_agg["instance_masks"],
+                                               want_agg["xy"].transpose(0, 2, 3, 1)[:, :, :, None, :], hn, seed=2026,
+                                               return_debug=True)
+    d = {k: v.cpu().numpy() for k, v in dbg[0].items()}
+    for k in ("tn", "win_idx", "win_count", "inlier_count", "counts"):
+        assert np.array_equal(d[k], wdbg[0][k]), k
+    assert np.array_equal(d["hyp"], wdbg[0]["hyp"])
+    np.testing.assert_allclose(out.cpu().numpy(), want, atol=1e-4, rtol=0)
+    # size-independent cross-check through the B1 path for the largest instance
+    i = int(np.argmax(d["tn"]))
+    m = agg["instance_masks"][i].bool()
+    coords = torch.nonzero(m).float()[:, [1, 0]].contiguous()
+    direct = vertex[i].masked_select(m[:, :, None, None]).view(-1, 1, 2).contiguous()
+    hyp = dbg[0]["hyp"][i].view(hn, 1, 2).contiguous()
+    inl = torch.zeros((hn, 1, coords.shape[0]), dtype=torch.uint8, device=dev)
+    ext.voting_for_hypothesis(direct, coords, hyp, inl, 0.999)
+    assert torch.equal(inl.sum(2).view(-1).int(), dbg[0]["counts"][i])
+    order = np.argsort([c[2] for c in centres])                 # centres listed by class 1..6
+    got = {int(c): xy for c, xy in zip(agg["class_ids"].cpu().numpy(), out.cpu().numpy()[:, 0])}
+    for j in order:
+        cx, cy, cls, n = centres[j]
+        assert abs(got[cls][0] - cx) < 0.5 and abs(got[cls][1] - cy) < 0.5
