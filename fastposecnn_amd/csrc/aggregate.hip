@@ -33,62 +33,103 @@ static AggWs agg_carve(void* base, int N) {
     return w;
 }
 
+constexpr int kAggIters = 16;                 // 256 threads x 16 = 4096 pixels per workgroup
+constexpr int kAggPx = 256 * kAggIters;
+constexpr int kAggRecs = 4 * kAggIters;       // one record per (iteration, wave)
+
+__device__ __forceinline__ void agg_flush(int i, const double* v, int n, uint32_t c, int b, double* sums,
+                                          int32_t* cnt, uint32_t* cls_min, int32_t* sample) {
+#pragma unroll
+    for (int a = 0; a < 8; ++a) unsafeAtomicAdd(&sums[(size_t)i * 8 + a], v[a]);
+    atomicAdd(&cnt[i], n);
+    atomicMin(&cls_min[i], c);
+    sample[i] = b;
+}
+
+// grid (ceil(HW/4096), B).  A wave whose 64 pixels carry one label (the common case) reduces
+// them with shuffles into one LDS record; the workgroup then merges its <= 64 records per label
+// in a fixed order and issues ONE set of global atomics per (workgroup, label).  Waves that
+// straddle several labels fall back to per-lane atomics.
 __global__ __launch_bounds__(256) void k_agg_accum(const int32_t* __restrict__ labels,
                                                    const int64_t* __restrict__ cm, const float* __restrict__ quat,
                                                    const float* __restrict__ scales, const float* __restrict__ z,
                                                    int HW, int N, double* __restrict__ sums,
                                                    int32_t* __restrict__ cnt, uint32_t* __restrict__ cls_min,
                                                    int32_t* __restrict__ sample) {
+    __shared__ int s_label[kAggRecs];
+    __shared__ int s_n[kAggRecs];
+    __shared__ uint32_t s_cls[kAggRecs];
+    __shared__ double s_v[kAggRecs][8];
     int b = blockIdx.y;
-    int lane = threadIdx.x & (kWave - 1);
-    for (int p0 = blockIdx.x * 1024; p0 < HW; p0 += gridDim.x * 1024) {
+    int lane = threadIdx.x & (kWave - 1), w = threadIdx.x / kWave;
+    int p0 = blockIdx.x * kAggPx;
 #pragma unroll 1
-        for (int it = 0; it < 4; ++it) {
-            int p = p0 + it * 256 + threadIdx.x;
-            int l = 0;
-            if (p < HW) l = labels[(size_t)b * HW + p];
-            if (l > N) l = 0;
-            bool act = l > 0;
-            unsigned long long m = __ballot(act);
-            if (m == 0) continue;
+    for (int it = 0; it < kAggIters; ++it) {
+        int p = p0 + it * 256 + threadIdx.x;
+        int l = 0;
+        if (p < HW) l = labels[(size_t)b * HW + p];
+        if (l > N) l = 0;
+        bool act = l > 0;
+        unsigned long long m = __ballot(act);
+        int rec = it * 4 + w;
+        if (m == 0) {
+            if (lane == 0) s_label[rec] = 0;
+            continue;
+        }
+        double v[8];
+        uint32_t c = 0xFFFFFFFFu;
+        if (act) {
+            size_t o = (size_t)b * HW + p;
+            long long cc = cm[o];
+            if (cc != 0) c = (uint32_t)cc;
+#pragma unroll
+            for (int a = 0; a < 4; ++a) v[a] = (double)quat[((size_t)b * 4 + a) * HW + p];
+#pragma unroll
+            for (int a = 0; a < 3; ++a) v[4 + a] = (double)scales[((size_t)b * 3 + a) * HW + p];
+            v[7] = (double)z[o];
+        } else {
+#pragma unroll
+            for (int a = 0; a < 8; ++a) v[a] = 0.0;
+        }
+        int first = __builtin_amdgcn_readlane(l, __ffsll((long long)m) - 1);
+        bool uniform = __ballot(act && l != first) == 0;
+        if (uniform) {
+#pragma unroll
+            for (int a = 0; a < 8; ++a) v[a] = wave_reduce_add(v[a]);
+#pragma unroll
+            for (int o = kWave / 2; o > 0; o >>= 1) c = min(c, (uint32_t)__shfl_down((int)c, o, kWave));
+            if (lane == 0) {
+                s_label[rec] = first;
+                s_n[rec] = __popcll(m);
+                s_cls[rec] = c;
+#pragma unroll
+                for (int a = 0; a < 8; ++a) s_v[rec][a] = v[a];
+            }
+        } else {
+            if (lane == 0) s_label[rec] = 0;
+            if (act) agg_flush(l - 1, v, 1, c, b, sums, cnt, cls_min, sample);
+        }
+    }
+    __syncthreads();
+    int r = threadIdx.x;
+    if (r < kAggRecs) {
+        int l = s_label[r];
+        bool lead = l > 0;
+        for (int k = 0; k < r && lead; ++k) lead = s_label[k] != l;
+        if (lead) {
             double v[8];
-            uint32_t c = 0xFFFFFFFFu;
-            if (act) {
-                size_t o = (size_t)b * HW + p;
-                long long cc = cm[o];
-                if (cc != 0) c = (uint32_t)cc;
 #pragma unroll
-                for (int a = 0; a < 4; ++a) v[a] = (double)quat[((size_t)b * 4 + a) * HW + p];
+            for (int a = 0; a < 8; ++a) v[a] = s_v[r][a];
+            int n = s_n[r];
+            uint32_t c = s_cls[r];
+            for (int k = r + 1; k < kAggRecs; ++k) {
+                if (s_label[k] != l) continue;
 #pragma unroll
-                for (int a = 0; a < 3; ++a) v[4 + a] = (double)scales[((size_t)b * 3 + a) * HW + p];
-                v[7] = (double)z[o];
-            } else {
-#pragma unroll
-                for (int a = 0; a < 8; ++a) v[a] = 0.0;
+                for (int a = 0; a < 8; ++a) v[a] += s_v[k][a];
+                n += s_n[k];
+                c = min(c, s_cls[k]);
             }
-            int first = __builtin_amdgcn_readlane(l, __ffsll((long long)m) - 1);
-            bool uniform = __ballot(act && l != first) == 0;
-            if (uniform) {
-#pragma unroll
-                for (int a = 0; a < 8; ++a) v[a] = wave_reduce_add(v[a]);
-#pragma unroll
-                for (int o = kWave / 2; o > 0; o >>= 1) c = min(c, (uint32_t)__shfl_down((int)c, o, kWave));
-                if (lane == 0) {
-                    int i = first - 1;
-#pragma unroll
-                    for (int a = 0; a < 8; ++a) unsafeAtomicAdd(&sums[(size_t)i * 8 + a], v[a]);
-                    atomicAdd(&cnt[i], __popcll(m));
-                    atomicMin(&cls_min[i], c);
-                    sample[i] = b;
-                }
-            } else if (act) {
-                int i = l - 1;
-#pragma unroll
-                for (int a = 0; a < 8; ++a) unsafeAtomicAdd(&sums[(size_t)i * 8 + a], v[a]);
-                atomicAdd(&cnt[i], 1);
-                atomicMin(&cls_min[i], c);
-                sample[i] = b;
-            }
+            agg_flush(l - 1, v, n, c, b, sums, cnt, cls_min, sample);
         }
     }
 }
@@ -186,7 +227,7 @@ extern "C" int fpc_aggregate(const int32_t* labels, const int64_t* cat_mask, con
     if (e == hipSuccess) e = hipMemsetAsync((char*)ws + w.ff_off, 0xFF, w.ff_bytes, s);
     if (e != hipSuccess) { set_hip_error(e); return FPC_ELAUNCH; }
     int gx = cdiv(HW, 1024);
-    hipLaunchKernelGGL(k_agg_accum, dim3(gx, B), dim3(256), 0, s, labels, cat_mask, quat, scales, z, HW, N, w.sums,
+    hipLaunchKernelGGL(k_agg_accum, dim3(cdiv(HW, kAggPx), B), dim3(256), 0, s, labels, cat_mask, quat, scales, z, HW, N, w.sums,
                        w.cnt, w.cls_min, w.sample);
     hipLaunchKernelGGL(k_agg_finalize, dim3(cdiv(N, 64)), dim3(64), 0, s, N, w.sums, w.cnt, w.cls_min, w.sample,
                        class_ids, sample_ids, oq, os, oz);

@@ -29,12 +29,25 @@ __device__ __forceinline__ int cc_find(const int32_t* L, int a) {
     }
 }
 
+// find with path halving: every visited node is re-pointed at its grandparent.  atomicMin keeps
+// parents monotonically decreasing under concurrent unions, so no cycle can form.
+__device__ __forceinline__ int cc_find_halve(int32_t* L, int a) {
+    while (true) {
+        int pa = L[a];
+        if (pa == a) return a;
+        int gpa = L[pa];
+        if (gpa == pa) return pa;
+        atomicMin(&L[a], gpa);
+        a = gpa;
+    }
+}
+
 // Parents only ever decrease; a stale read yields an older ancestor and the loop
 // repairs any link it displaces (old != a -> keep uniting old with b).
 __device__ __forceinline__ void cc_unite(int32_t* L, int a, int b) {
     while (true) {
-        a = cc_find(L, a);
-        b = cc_find(L, b);
+        a = cc_find_halve(L, a);
+        b = cc_find_halve(L, b);
         if (a == b) return;
         if (a < b) { int t = a; a = b; b = t; }
         int old = atomicMin(&L[a], b);
@@ -87,7 +100,7 @@ __global__ __launch_bounds__(256) void k_cc_merge(int W, int HW, long long total
     }
 }
 
-__global__ __launch_bounds__(256) void k_cc_flatten(long long total, const int32_t* __restrict__ L,
+__global__ __launch_bounds__(256) void k_cc_flatten(long long total, int32_t* __restrict__ L,
                                                     int32_t* __restrict__ R, int32_t* __restrict__ blk_cnt) {
     __shared__ int scratch[4];
     long long g0 = (long long)blockIdx.x * kCcBlock;
@@ -98,7 +111,7 @@ __global__ __launch_bounds__(256) void k_cc_flatten(long long total, const int32
         if (g >= total) continue;
         int r = -1;
         if (L[g] >= 0) {
-            r = cc_find(L, (int)g);
+            r = cc_find_halve(L, (int)g);
             roots += (r == (int)g);
         }
         R[g] = r;

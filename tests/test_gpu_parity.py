@@ -336,3 +336,46 @@ def test_fullsize_vote_bench_frame(lib, oracle, dev):
     for j in order:
         cx, cy, cls, n = centres[j]
         assert abs(got[cls][0] - cx) < 0.5 and abs(got[cls][1] - cy) < 0.5
+
+
+# ----------------------------------------------------------------------------- vote filter soundness
+
+@pytest.mark.parametrize("case", ["perfect", "noise", "scaled", "parallel_mix"])
+@pytest.mark.parametrize("thresh", [0.5, 0.999, 0.99999])
+def test_v3_filter_never_changes_the_answer(lib, oracle, dev, case, thresh):
+    """k_count_hi only bounds the counts; k_select must still return exactly the winner of the
+    exhaustive vote (lowest index on ties), also on tie-heavy and ill-conditioned inputs."""
+    rng = np.random.default_rng(hash((case, thresh)) % 2 ** 32)
+    H, W, n, hn = 72, 88, 3, 160
+    yy, xx = np.mgrid[0:H, 0:W].astype(np.float32)
+    mask = np.zeros((n, H, W), np.float32); xy = np.zeros((n, 2, H, W), np.float32)
+    for i, (cx, cy) in enumerate([(30.25, 20.5), (60.0, 50.0), (44.4, 36.6)]):
+        m = ((xx - cx) ** 2 + (yy - cy) ** 2) <= (10 + 4 * i) ** 2
+        d = np.stack([cx - xx, cy - yy]); nrm = np.maximum(np.sqrt((d ** 2).sum(0)), 1e-9)
+        v = d / nrm
+        if case == "noise":                       # pure noise: low counts, many ties, far hypotheses
+            a = rng.uniform(0, 2 * np.pi, (H, W)); v = np.stack([np.cos(a), np.sin(a)])
+        elif case == "scaled":                    # un-normalised votes over 6 decades, some exactly zero
+            v = v * (10.0 ** rng.uniform(-3, 3, (H, W))); v[:, rng.random((H, W)) < 0.1] = 0
+        elif case == "parallel_mix":              # mostly one direction (+-): near-parallel pairs, huge |h|
+            a = rng.normal(0.3, 1e-4, (H, W)) + np.pi * (rng.random((H, W)) < 0.5)
+            v = np.stack([np.cos(a), np.sin(a)])
+        mask[i] = m; xy[i] = (v * m).astype(np.float32)
+    vertex = T(xy, dev).permute(0, 2, 3, 1).unsqueeze(3)
+    out, dbg = _run_v3(lib, dev, mask, vertex, hn, seed=5, inlier_thresh=thresh)
+    want, wdbg = oracle.ransac_voting_layer_v3(mask, xy.transpose(0, 2, 3, 1)[:, :, :, None, :], hn, seed=5,
+                                               inlier_thresh=thresh, return_debug=True)
+    for k in ("tn", "win_idx", "win_count", "inlier_count", "counts"):
+        assert np.array_equal(dbg[0][k], wdbg[0][k]), k
+    assert np.array_equal(dbg[0]["hyp"], wdbg[0]["hyp"], equal_nan=True)
+    np.testing.assert_allclose(out, want, atol=1e-4, rtol=1e-6)
+
+
+def test_v3_exact_mode_for_nonpositive_threshold(lib, oracle, dev):
+    g = load_golden("vote_small.npz")
+    vertex = T(g["xy"], dev).permute(0, 2, 3, 1).unsqueeze(3)
+    for th in (0.0, -0.5):
+        out, dbg = _run_v3(lib, dev, g["mask"], vertex, 64, seed=3, inlier_thresh=th)
+        want, wdbg = oracle.ransac_voting_layer_v3(g["mask"], g["xy"].transpose(0, 2, 3, 1)[:, :, :, None, :], 64,
+                                                   seed=3, inlier_thresh=th, return_debug=True)
+        _assert_v3_equal(out, dbg, want, wdbg)

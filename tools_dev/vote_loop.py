@@ -1,0 +1,47 @@
+"""Tight loop over fpc_ransac_voting_v3 (and optionally cc/agg) on the bench fixture: steady-state kernel
+times without Python gaps.  python tools_dev/vote_loop.py [--hn 1000] [--iters 300] [--frames 1]"""
+import argparse, os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import fastposecnn_amd.lib as L
+from fastposecnn_amd import synth, _native as nat
+import aggregation_layer as al
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--hn", type=int, default=1000)
+ap.add_argument("--iters", type=int, default=300)
+ap.add_argument("--frames", type=int, default=1)
+ap.add_argument("--agg", action="store_true")
+a = ap.parse_args()
+dev = torch.device("cuda:0")
+cat_cpu, _ = synth.make_vote_batch(range(a.frames))
+cat = {k: v.to(dev) for k, v in cat_cpu.items()}
+layer = al.AggregationLayer(None, 7)
+agg = layer.forward(cat)
+mask = agg["instance_masks"]; xy = agg["xy"]
+n, H, W = mask.shape
+vertex = xy.permute(0, 2, 3, 1)
+sn, sh, sw, sc = vertex.stride()
+lib = nat.lib()
+ws = torch.empty(lib.fpc_ransac_workspace_bytes(n, H, W, a.hn), dtype=torch.uint8, device=dev)
+out = torch.empty((n, 2), device=dev)
+st = torch.cuda.current_stream().cuda_stream
+
+def vote(seed):
+    nat.check(lib.fpc_ransac_voting_v3(mask.data_ptr(), vertex.data_ptr(), sn, sh, sw, sc, n, H, W, a.hn, None, None,
+                                       seed, 0.999, 5, 30000, out.data_ptr(), None, None, None, None, None, None,
+                                       ws.data_ptr(), ws.numel(), st), "vote")
+
+for i in range(20):
+    vote(i)
+    if a.agg: layer.forward(cat)
+torch.cuda.synchronize()
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+t0 = time.perf_counter(); e0.record()
+for i in range(a.iters):
+    vote(100 + i)
+    if a.agg: layer.forward(cat)
+e1.record(); torch.cuda.synchronize()
+dt = time.perf_counter() - t0
+ms = e0.elapsed_time(e1) / a.iters
+print(f"n={n} hn={a.hn} per-call {ms*1e3:.1f} us (wall {dt/a.iters*1e6:.1f} us)  alg {n*12*H*W/ms/1e6:.1f} GB/s  out0={out[0].tolist()}")
