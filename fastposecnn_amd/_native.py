@@ -37,6 +37,20 @@ _SIGNATURES = {
     "fpc_aggregate": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz,
                            _vp]),
     "fpc_pose_rt": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp]),
+    "fpc_net_create": (_i, [ctypes.c_char_p, _i, _i, _i, _i, ctypes.POINTER(_vp)]),
+    "fpc_net_destroy": (None, [_vp]),
+    "fpc_net_param_count": (_i, [_vp]),
+    "fpc_net_param_name": (ctypes.c_char_p, [_vp, _i]),
+    "fpc_net_param_numel": (_i64, [_vp, _i]),
+    "fpc_net_workspace_bytes": (_sz, [_vp]),
+    "fpc_net_load_params": (_i, [_vp, _vp, _i, _vp, _sz, _vp]),
+    "fpc_net_forward": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "fpc_net_tensor": (_i, [_vp, ctypes.c_char_p, ctypes.POINTER(_vp), ctypes.POINTER(_i), ctypes.POINTER(_i),
+                            ctypes.POINTER(_i)]),
+    "fpc_conv2d_workspace_bytes": (_sz, [_i, _i, _i, _i, _i, _i, _i]),
+    "fpc_conv2d_plan": (_i, [_i, _i, _i, _i, _i, _i, _i, _i, _i, _i, ctypes.POINTER(_i)]),
+    "fpc_conv2d": (_i, [_vp, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i,
+                        _i, _i, _i, _i, _i, _vp, _sz, _vp]),
 }
 
 EXPORTED = tuple(_SIGNATURES)

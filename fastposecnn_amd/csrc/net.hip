@@ -1,0 +1,548 @@
+// net.hip — the backbone engine behind fpc_net_* (include/fpc.h): a native plan of
+// PoseRegressor.pure_model_forward + Model.class_compression
+// (F/lib/pose_regressor.py:709-743, 445-457) for inference.
+//
+// The graph is the one segmentation_models_pytorch builds for FastPoseCNN
+// (encoder = ResNet BasicBlock x {2,2,2,2} or {3,4,6,3}; four FPN decoders, merge "add";
+// four 1x1 heads + x4 bilinear), see fastposecnn_amd/lib/backbone.py.  The plan owns no device
+// memory: packed weights, activations and split-K scratch live in one caller-provided workspace.
+// Launch order per frame (R18): stem conv, max-pool, 16 encoder convs (+3 downsample 1x1) with
+// BatchNorm / residual / ReLU in their epilogues, then the FOUR decoders as grouped launches:
+// 4 lateral 1x1 convs (FPN top-down add in the epilogue), 7 3x3 convs (GroupNorm partial sums in
+// the epilogue), 7 GroupNorm finalisations, 3 GN+ReLU+x2-upsample passes, 1 merge+head kernel,
+// 1 x4-upsample + class-compression kernel.
+#include <math.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+#include "net_kernels.hpp"
+
+namespace fpc {
+
+struct PackedConv {
+    int Cin = 0, Cout = 0, Kh = 1, Kw = 1, stride = 1, pad = 0;
+    int K = 0, Kpad = 0, Npad = 0;
+    int p_w = -1;            // parameter index of the OIHW weight
+    int p_bn = -1;           // first of (weight, bias, running_mean, running_var) or -1
+    int p_bias = -1;         // conv bias or -1
+    size_t w_off = 0, scale_off = 0, shift_off = 0;   // float offsets into the workspace
+};
+
+struct Act { size_t off = 0; int H = 0, W = 0, C = 0; };
+
+struct ConvPlan { int bm = 64, bn = 64, nsplit = 1, mtiles = 1, ntiles = 1; };
+
+static ConvPlan plan_conv(int HoWo, int B, int Cout, int ksteps, int groups, int force_bm = 0, int force_bn = 0,
+                          int force_split = 0) {
+    ConvPlan best;
+    double best_t = 1e300;
+    const int bms[2] = {64, 128}, bns[2] = {64, 128};
+    for (int bi = 0; bi < 2; ++bi)
+        for (int bj = 0; bj < 2; ++bj) {
+            int bm = bms[bi], bn = bns[bj];
+            if (force_bm && bm != force_bm) continue;
+            if (force_bn && bn != force_bn) continue;
+            if (!force_bn && bn == 128 && Cout <= 64) continue;
+            int mt = cdiv(HoWo, bm), nt = cdiv(Cout, bn);
+            for (int ns = 1; ns <= 32; ++ns) {
+                if (force_split && ns != force_split) continue;
+                int per = cdiv(ksteps, ns);
+                if ((ns - 1) * per >= ksteps) continue;
+                if (ns > 1 && (Cout % 4 != 0)) continue;
+                double nblk = (double)groups * B * mt * nt * ns;
+                double work = (double)(bm / 64) * (bn / 64) * per * 16.0 * 64.0 + 4000.0;
+                double t = ceil(nblk / 256.0) * work + (ns > 1 ? 10000.0 + 200.0 * ns : 0.0);
+                if (t < best_t) { best_t = t; best = ConvPlan{bm, bn, ns, mt, nt}; }
+            }
+        }
+    return best;
+}
+
+}  // namespace fpc
+
+using namespace fpc;
+
+struct fpc_net {
+    int layers[4];
+    int classes, B, H, W;
+    bool r34 = false;
+    std::vector<std::string> pnames;
+    std::vector<int64_t> pnumel;
+    std::vector<const float*> pptr;
+    std::vector<PackedConv> convs;
+    size_t packed_floats = 0;     // packed weights + folded BN region (persistent across forwards)
+    size_t total_floats = 0;      // + activations and scratch
+    float* ws = nullptr;
+    bool loaded = false;
+
+    // conv indices
+    int c_stem = -1;
+    struct Block { int conv1, conv2, ds; };
+    std::vector<Block> blocks[4];
+    struct Dec {
+        int lat[4];               // p5, p4, p3, p2 (1x1, bias)
+        int seg[7];               // s5.0 s5.1 s5.2 s4.0 s4.1 s3.0 s2.0
+        int p_gn[7];              // param index of GN weight (bias = +1)
+        int p_head_w, p_head_b;
+        int head_ch, head_chp;
+    } dec[4];
+
+    // activations (float offsets)
+    Act a_stem, a_pool;
+    std::vector<Act> a_blk_t[4], a_blk_y[4], a_blk_d[4];
+    Act a_p[4][4];                // [decoder][p5,p4,p3,p2]
+    Act a_seg[4][7];              // pre-GroupNorm conv outputs
+    Act a_up[4][3];               // s5.0 -> up, s5.1 -> up, s4.0 -> up
+    size_t gn_part_off[4][7], gn_aff_off[4][7];
+    int gn_P[7];
+    Act a_low[4];                 // low-res logits
+    size_t splitk_off = 0, splitk_floats = 0;
+
+    // per-conv launch plans (index = conv id of decoder 0 for grouped ones)
+    std::vector<ConvPlan> cplan;
+
+    size_t bump = 0;
+    size_t alloc(size_t n) { size_t o = bump; bump += (n + 63) / 64 * 64; return o; }
+    Act alloc_act(int h, int w, int c) { Act a; a.H = h; a.W = w; a.C = c; a.off = alloc((size_t)B * h * w * c); return a; }
+    int add_param(const std::string& n, int64_t numel) { pnames.push_back(n); pnumel.push_back(numel); return (int)pnames.size() - 1; }
+
+    int add_conv(const std::string& wname, int Cin, int Cout, int k, int stride, int pad, const char* bn_prefix,
+                 const char* bias_name) {
+        PackedConv c;
+        c.Cin = Cin; c.Cout = Cout; c.Kh = c.Kw = k; c.stride = stride; c.pad = pad;
+        c.K = Cin * k * k; c.Kpad = cdiv(c.K, kConvBK) * kConvBK; c.Npad = cdiv(Cout, kConvNAlign) * kConvNAlign;
+        c.p_w = add_param(wname, (int64_t)Cout * Cin * k * k);
+        if (bn_prefix) {
+            std::string p(bn_prefix);
+            c.p_bn = add_param(p + ".weight", Cout);
+            add_param(p + ".bias", Cout);
+            add_param(p + ".running_mean", Cout);
+            add_param(p + ".running_var", Cout);
+        }
+        if (bias_name) c.p_bias = add_param(bias_name, Cout);
+        c.w_off = alloc((size_t)c.Npad * c.Kpad);
+        if (bn_prefix) { c.scale_off = alloc(Cout); c.shift_off = alloc(Cout); }
+        convs.push_back(c);
+        return (int)convs.size() - 1;
+    }
+};
+
+static const char* kDecNames[4] = {"mask_decoder", "rotation_decoder", "translation_decoder", "scales_decoder"};
+static const char* kHeadNames[4] = {"segmentation_head", "rotation_head", "translation_head", "scales_head"};
+
+static int conv_out(int x, int k, int s, int p) { return (x + 2 * p - k) / s + 1; }
+
+extern "C" int fpc_net_create(const char* encoder, int classes, int B, int H, int W, fpc_net_t** out) {
+    if (!encoder || !out || classes < 2 || classes > 8 || B < 1 || H < 32 || W < 32 || H % 32 || W % 32) return FPC_EINVAL;
+    fpc_net* n = new fpc_net();
+    if (!strcmp(encoder, "resnet18")) { int l[4] = {2, 2, 2, 2}; memcpy(n->layers, l, sizeof(l)); }
+    else if (!strcmp(encoder, "resnet34")) { int l[4] = {3, 4, 6, 3}; memcpy(n->layers, l, sizeof(l)); n->r34 = true; }
+    else { delete n; return FPC_EINVAL; }
+    n->classes = classes; n->B = B; n->H = H; n->W = W;
+    char buf[256];
+
+    // ---- parameters + packed storage (persistent region first)
+    n->c_stem = n->add_conv("encoder.conv1.weight", 3, 64, 7, 2, 3, "encoder.bn1", nullptr);
+    const int planes[4] = {64, 128, 256, 512};
+    int inpl = 64;
+    for (int L = 0; L < 4; ++L)
+        for (int bi = 0; bi < n->layers[L]; ++bi) {
+            int stride = (bi == 0 && L > 0) ? 2 : 1;
+            fpc_net::Block blk;
+            snprintf(buf, sizeof(buf), "encoder.layer%d.%d", L + 1, bi);
+            std::string p(buf);
+            blk.conv1 = n->add_conv(p + ".conv1.weight", inpl, planes[L], 3, stride, 1, (p + ".bn1").c_str(), nullptr);
+            blk.conv2 = n->add_conv(p + ".conv2.weight", planes[L], planes[L], 3, 1, 1, (p + ".bn2").c_str(), nullptr);
+            blk.ds = -1;
+            if (stride != 1 || inpl != planes[L])
+                blk.ds = n->add_conv(p + ".downsample.0.weight", inpl, planes[L], 1, stride, 0, (p + ".downsample.1").c_str(), nullptr);
+            inpl = planes[L];
+            n->blocks[L].push_back(blk);
+        }
+    const int G = classes - 1;
+    const int head_ch[4] = {classes, 4 * G, 3 * G, 3 * G};
+    for (int d = 0; d < 4; ++d) {
+        std::string D(kDecNames[d]);
+        fpc_net::Dec& dc = n->dec[d];
+        dc.lat[0] = n->add_conv(D + ".p5.weight", 512, 256, 1, 1, 0, nullptr, (D + ".p5.bias").c_str());
+        const int skipc[3] = {256, 128, 64};
+        for (int i = 0; i < 3; ++i) {
+            snprintf(buf, sizeof(buf), "%s.p%d.skip_conv", kDecNames[d], 4 - i);
+            std::string p(buf);
+            dc.lat[1 + i] = n->add_conv(p + ".weight", skipc[i], 256, 1, 1, 0, nullptr, (p + ".bias").c_str());
+        }
+        const int nconv[4] = {3, 2, 1, 1};
+        int si = 0;
+        for (int sb = 0; sb < 4; ++sb)
+            for (int j = 0; j < nconv[sb]; ++j) {
+                snprintf(buf, sizeof(buf), "%s.seg_blocks.%d.block.%d.block", kDecNames[d], sb, j);
+                std::string p(buf);
+                dc.seg[si] = n->add_conv(p + ".0.weight", j == 0 ? 256 : 128, 128, 3, 1, 1, nullptr, nullptr);
+                dc.p_gn[si] = n->add_param(p + ".1.weight", 128);
+                n->add_param(p + ".1.bias", 128);
+                ++si;
+            }
+    }
+    for (int d = 0; d < 4; ++d) {
+        fpc_net::Dec& dc = n->dec[d];
+        dc.head_ch = head_ch[d];
+        dc.head_chp = (head_ch[d] + 3) / 4 * 4;
+        dc.p_head_w = n->add_param(std::string(kHeadNames[d]) + ".0.weight", (int64_t)head_ch[d] * 128);
+        dc.p_head_b = n->add_param(std::string(kHeadNames[d]) + ".0.bias", head_ch[d]);
+    }
+    n->packed_floats = n->bump;
+
+    // ---- activations
+    int h1 = conv_out(H, 7, 2, 3), w1 = conv_out(W, 7, 2, 3);
+    n->a_stem = n->alloc_act(h1, w1, 64);
+    int hp = conv_out(h1, 3, 2, 1), wp = conv_out(w1, 3, 2, 1);
+    n->a_pool = n->alloc_act(hp, wp, 64);
+    int fh[4], fw[4];
+    {
+        int h = hp, w = wp;
+        for (int L = 0; L < 4; ++L) {
+            if (L > 0) { h = conv_out(h, 3, 2, 1); w = conv_out(w, 3, 2, 1); }
+            fh[L] = h; fw[L] = w;
+            for (int bi = 0; bi < n->layers[L]; ++bi) {
+                n->a_blk_t[L].push_back(n->alloc_act(h, w, planes[L]));
+                n->a_blk_y[L].push_back(n->alloc_act(h, w, planes[L]));
+                n->a_blk_d[L].push_back(n->blocks[L][bi].ds >= 0 ? n->alloc_act(h, w, planes[L]) : Act());
+            }
+        }
+    }
+    // FPN needs exact x2 relations between levels
+    for (int L = 1; L < 4; ++L)
+        if (fh[L - 1] != 2 * fh[L] || fw[L - 1] != 2 * fw[L]) { delete n; return FPC_EINVAL; }
+    // seg conv geometry: index -> (resolution level): s5.0@L3, s5.1@L2, s5.2@L1, s4.0@L2, s4.1@L1, s3.0@L1, s2.0@L0
+    const int seg_level[7] = {3, 2, 1, 2, 1, 1, 0};
+    for (int d = 0; d < 4; ++d) {
+        for (int i = 0; i < 4; ++i) n->a_p[d][i] = n->alloc_act(fh[3 - i], fw[3 - i], 256);
+        for (int i = 0; i < 7; ++i) n->a_seg[d][i] = n->alloc_act(fh[seg_level[i]], fw[seg_level[i]], 128);
+        n->a_up[d][0] = n->alloc_act(fh[2], fw[2], 128);   // up2(s5.0)
+        n->a_up[d][1] = n->alloc_act(fh[1], fw[1], 128);   // up2(s5.1)
+        n->a_up[d][2] = n->alloc_act(fh[1], fw[1], 128);   // up2(s4.0)
+        n->a_low[d] = n->alloc_act(fh[0], fw[0], n->dec[d].head_chp);
+    }
+
+    // ---- conv plans (+ split-K scratch, GroupNorm partials)
+    n->cplan.resize(n->convs.size());
+    auto plan = [&](int ci, int HoWo, int groups) {
+        const PackedConv& c = n->convs[ci];
+        ConvPlan p = plan_conv(HoWo, B, c.Cout, c.Kpad / kConvBK, groups);
+        n->cplan[ci] = p;
+        if (p.nsplit > 1) {
+            size_t need = (size_t)groups * p.nsplit * B * p.mtiles * p.bm * c.Npad;
+            if (need > n->splitk_floats) n->splitk_floats = need;
+        }
+    };
+    plan(n->c_stem, h1 * w1, 1);
+    for (int L = 0; L < 4; ++L)
+        for (auto& blk : n->blocks[L]) {
+            plan(blk.conv1, fh[L] * fw[L], 1);
+            plan(blk.conv2, fh[L] * fw[L], 1);
+            if (blk.ds >= 0) plan(blk.ds, fh[L] * fw[L], 1);
+        }
+    for (int i = 0; i < 4; ++i) plan(n->dec[0].lat[i], fh[3 - i] * fw[3 - i], 4);
+    for (int i = 0; i < 7; ++i) {
+        plan(n->dec[0].seg[i], fh[seg_level[i]] * fw[seg_level[i]], 4);
+        const ConvPlan& p = n->cplan[n->dec[0].seg[i]];
+        n->gn_P[i] = p.mtiles * p.bm / 32;
+        for (int d = 0; d < 4; ++d) {
+            n->gn_part_off[d][i] = n->alloc((size_t)B * n->gn_P[i] * 128 * 2);
+            n->gn_aff_off[d][i] = n->alloc((size_t)B * 128 * 2);
+        }
+    }
+    n->splitk_off = n->alloc(n->splitk_floats);
+    n->total_floats = n->bump;
+    n->pptr.assign(n->pnames.size(), nullptr);
+    *out = n;
+    return FPC_OK;
+}
+
+extern "C" void fpc_net_destroy(fpc_net_t* n) { delete n; }
+extern "C" int fpc_net_param_count(const fpc_net_t* n) { return n ? (int)n->pnames.size() : 0; }
+extern "C" const char* fpc_net_param_name(const fpc_net_t* n, int i) {
+    return (n && i >= 0 && i < (int)n->pnames.size()) ? n->pnames[i].c_str() : nullptr;
+}
+extern "C" int64_t fpc_net_param_numel(const fpc_net_t* n, int i) {
+    return (n && i >= 0 && i < (int)n->pnumel.size()) ? n->pnumel[i] : -1;
+}
+extern "C" size_t fpc_net_workspace_bytes(const fpc_net_t* n) { return n ? n->total_floats * sizeof(float) : 0; }
+
+extern "C" int fpc_net_load_params(fpc_net_t* n, const float* const* params, int count, void* ws, size_t ws_bytes,
+                                   fpc_stream_t stream) {
+    if (!n || !params || count != (int)n->pnames.size() || !ws) return FPC_EINVAL;
+    if (((uintptr_t)ws & 255) != 0 || ws_bytes < n->total_floats * sizeof(float)) return FPC_EWORKSPACE;
+    for (int i = 0; i < count; ++i)
+        if (!params[i] || ((uintptr_t)params[i] & 15)) return FPC_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    n->ws = (float*)ws;
+    n->pptr.assign(params, params + count);
+    for (const PackedConv& c : n->convs) {
+        int rc = launch_pack_weight(n->pptr[c.p_w], n->ws + c.w_off, c.Cout, c.Cin, c.Kh, c.Kw, c.Npad, c.Kpad, s);
+        if (rc) return rc;
+        if (c.p_bn >= 0) {
+            rc = launch_fold_bn(n->pptr[c.p_bn], n->pptr[c.p_bn + 1], n->pptr[c.p_bn + 2], n->pptr[c.p_bn + 3], 1e-5f,
+                                c.Cout, n->ws + c.scale_off, n->ws + c.shift_off, s);
+            if (rc) return rc;
+        }
+    }
+    n->loaded = true;
+    return FPC_OK;
+}
+
+namespace {
+
+struct ConvIO {
+    const float* in; long long sb, sh, sw, sc; int Hi, Wi;
+    float* out; int Ho, Wo;
+    const float* res; const float* up; float* gn_part;
+};
+
+// fills the shared part of ConvArgs from conv `c` + plan `p`
+void fill_conv_args(const fpc_net* n, ConvArgs& a, const PackedConv& c, const ConvPlan& p, int Hi, int Wi, int Ho,
+                    int Wo, long long sb, long long sh, long long sw, long long sc, bool relu, bool generic) {
+    memset(&a, 0, sizeof(a));
+    a.B = n->B; a.Hi = Hi; a.Wi = Wi; a.Cin = c.Cin; a.Ho = Ho; a.Wo = Wo; a.Cout = c.Cout; a.Npad = c.Npad;
+    a.Kh = c.Kh; a.Kw = c.Kw; a.stride = c.stride; a.pad = c.pad; a.K = c.K; a.Kpad = c.Kpad;
+    a.in_sb = sb; a.in_sh = sh; a.in_sw = sw; a.in_sc = sc;
+    a.relu = relu ? 1 : 0; a.nsplit = p.nsplit; a.mtiles = p.mtiles; a.ntiles = p.ntiles; a.ksteps = c.Kpad / kConvBK;
+    a.bm = p.bm; a.bn = p.bn; a.generic = generic ? 1 : 0;
+    a.splitk_ws = n->ws + n->splitk_off;
+}
+
+int run_conv(const ConvArgs& a, int groups, hipStream_t s) {
+    int rc = launch_conv(a, groups, s);
+    if (rc) return rc;
+    if (a.nsplit > 1) rc = launch_conv_splitk_epilogue(a, groups, s);
+    return rc;
+}
+
+}  // namespace
+
+#define FPC_TRY(x) do { int rc__ = (x); if (rc__) return rc__; } while (0)
+
+extern "C" int fpc_net_forward(fpc_net_t* n, const float* x, float* logits_mask, float* logits_quat,
+                               float* logits_scales, float* logits_xy, float* logits_z, int64_t* cat_mask, float* cq,
+                               float* cs, float* cxy, float* cz, fpc_stream_t stream) {
+    if (!n || !n->loaded || !x || !cat_mask || !cq || !cs || !cxy || !cz) return FPC_EINVAL;
+    bool any = logits_mask || logits_quat || logits_scales || logits_xy || logits_z;
+    bool all = logits_mask && logits_quat && logits_scales && logits_xy && logits_z;
+    if (any && !all) return FPC_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    float* ws = n->ws;
+    const int B = n->B, H = n->H, W = n->W;
+    ConvArgs a;
+    auto nhwc = [&](const Act& t, long long& sb, long long& sh, long long& sw, long long& sc) {
+        sc = 1; sw = t.C; sh = (long long)t.W * t.C; sb = (long long)t.H * sh;
+    };
+
+    // stem: 7x7/2 on the NCHW image, BN + ReLU in the epilogue
+    {
+        const PackedConv& c = n->convs[n->c_stem];
+        fill_conv_args(n, a, c, n->cplan[n->c_stem], H, W, n->a_stem.H, n->a_stem.W, (long long)3 * H * W, W, 1,
+                       (long long)H * W, true, true);
+        a.p[0] = ConvPtrs{x, ws + c.w_off, ws + n->a_stem.off, ws + c.scale_off, ws + c.shift_off, nullptr, nullptr, nullptr};
+        FPC_TRY(run_conv(a, 1, s));
+    }
+    FPC_TRY(launch_maxpool3x3s2(ws + n->a_stem.off, ws + n->a_pool.off, B, n->a_stem.H, n->a_stem.W, 64, n->a_pool.H,
+                                n->a_pool.W, s));
+    // encoder stages
+    Act cur = n->a_pool;
+    Act feat[4];
+    for (int L = 0; L < 4; ++L) {
+        for (size_t bi = 0; bi < n->blocks[L].size(); ++bi) {
+            const fpc_net::Block& blk = n->blocks[L][bi];
+            const Act& T = n->a_blk_t[L][bi];
+            const Act& Y = n->a_blk_y[L][bi];
+            long long sb, sh, sw, sc;
+            nhwc(cur, sb, sh, sw, sc);
+            const PackedConv& c1 = n->convs[blk.conv1];
+            fill_conv_args(n, a, c1, n->cplan[blk.conv1], cur.H, cur.W, T.H, T.W, sb, sh, sw, sc, true, false);
+            a.p[0] = ConvPtrs{ws + cur.off, ws + c1.w_off, ws + T.off, ws + c1.scale_off, ws + c1.shift_off, nullptr, nullptr, nullptr};
+            FPC_TRY(run_conv(a, 1, s));
+            const float* res = ws + cur.off;
+            if (blk.ds >= 0) {
+                const PackedConv& cd = n->convs[blk.ds];
+                const Act& D = n->a_blk_d[L][bi];
+                fill_conv_args(n, a, cd, n->cplan[blk.ds], cur.H, cur.W, D.H, D.W, sb, sh, sw, sc, false, false);
+                a.p[0] = ConvPtrs{ws + cur.off, ws + cd.w_off, ws + D.off, ws + cd.scale_off, ws + cd.shift_off, nullptr, nullptr, nullptr};
+                FPC_TRY(run_conv(a, 1, s));
+                res = ws + D.off;
+            }
+            nhwc(T, sb, sh, sw, sc);
+            const PackedConv& c2 = n->convs[blk.conv2];
+            fill_conv_args(n, a, c2, n->cplan[blk.conv2], T.H, T.W, Y.H, Y.W, sb, sh, sw, sc, true, false);
+            a.p[0] = ConvPtrs{ws + T.off, ws + c2.w_off, ws + Y.off, ws + c2.scale_off, ws + c2.shift_off, res, nullptr, nullptr};
+            FPC_TRY(run_conv(a, 1, s));
+            cur = Y;
+        }
+        feat[L] = cur;
+    }
+
+    // ---- four decoders, grouped
+    // laterals: p5 = conv(c5); p4 = up2_nearest(p5) + conv(c4); p3; p2
+    for (int i = 0; i < 4; ++i) {
+        const Act& src = feat[3 - i];
+        long long sb, sh, sw, sc;
+        nhwc(src, sb, sh, sw, sc);
+        int ci0 = n->dec[0].lat[i];
+        fill_conv_args(n, a, n->convs[ci0], n->cplan[ci0], src.H, src.W, src.H, src.W, sb, sh, sw, sc, false, false);
+        for (int d = 0; d < 4; ++d) {
+            const PackedConv& c = n->convs[n->dec[d].lat[i]];
+            a.p[d] = ConvPtrs{ws + src.off, ws + c.w_off, ws + n->a_p[d][i].off, nullptr, n->pptr[c.p_bias], nullptr,
+                              i > 0 ? ws + n->a_p[d][i - 1].off : nullptr, nullptr};
+        }
+        FPC_TRY(run_conv(a, 4, s));
+    }
+    // segmentation blocks
+    auto seg_conv = [&](int si, int which) -> int {
+        // input of decoder d: which < 0 -> a_p[d][-which-1], else a_up[d][which]
+        int ci0 = n->dec[0].seg[si];
+        const Act& in0 = which < 0 ? n->a_p[0][-which - 1] : n->a_up[0][which];
+        long long sb, sh, sw, sc;
+        nhwc(in0, sb, sh, sw, sc);
+        const Act& o0 = n->a_seg[0][si];
+        fill_conv_args(n, a, n->convs[ci0], n->cplan[ci0], in0.H, in0.W, o0.H, o0.W, sb, sh, sw, sc, false, false);
+        for (int d = 0; d < 4; ++d) {
+            const PackedConv& c = n->convs[n->dec[d].seg[si]];
+            const Act& in = which < 0 ? n->a_p[d][-which - 1] : n->a_up[d][which];
+            a.p[d] = ConvPtrs{ws + in.off, ws + c.w_off, ws + n->a_seg[d][si].off, nullptr, nullptr, nullptr, nullptr,
+                              ws + n->gn_part_off[d][si]};
+        }
+        int rc = run_conv(a, 4, s);
+        if (rc) return rc;
+        GnFinArgs g;
+        memset(&g, 0, sizeof(g));
+        for (int d = 0; d < 4; ++d) {
+            g.gn_part[d] = ws + n->gn_part_off[d][si];
+            g.gamma[d] = n->pptr[n->dec[d].p_gn[si]];
+            g.beta[d] = n->pptr[n->dec[d].p_gn[si] + 1];
+            g.affine[d] = ws + n->gn_aff_off[d][si];
+        }
+        g.B = B; g.P = n->gn_P[si]; g.C = 128; g.groups = 32; g.count = (long long)o0.H * o0.W * 4; g.eps = 1e-5f;
+        return launch_gn_finalize(g, 4, s);
+    };
+    auto gn_up = [&](int si, int ui) -> int {
+        GnUpArgs u;
+        memset(&u, 0, sizeof(u));
+        for (int d = 0; d < 4; ++d) {
+            u.in[d] = ws + n->a_seg[d][si].off;
+            u.affine[d] = ws + n->gn_aff_off[d][si];
+            u.out[d] = ws + n->a_up[d][ui].off;
+        }
+        u.B = B; u.h = n->a_seg[0][si].H; u.w = n->a_seg[0][si].W; u.C = 128;
+        return launch_gn_relu_up2(u, 4, s);
+    };
+    FPC_TRY(seg_conv(0, -1));   // s5.0 on p5
+    FPC_TRY(seg_conv(3, -2));   // s4.0 on p4
+    FPC_TRY(seg_conv(5, -3));   // s3.0 on p3
+    FPC_TRY(seg_conv(6, -4));   // s2.0 on p2
+    FPC_TRY(gn_up(0, 0));
+    FPC_TRY(gn_up(3, 2));
+    FPC_TRY(seg_conv(1, 0));    // s5.1 on up(s5.0)
+    FPC_TRY(seg_conv(4, 2));    // s4.1 on up(s4.0)
+    FPC_TRY(gn_up(1, 1));
+    FPC_TRY(seg_conv(2, 1));    // s5.2 on up(s5.1)
+
+    // merge + head
+    {
+        MergeHeadArgs m;
+        memset(&m, 0, sizeof(m));
+        const int lo[3] = {2, 4, 5};     // s5.2, s4.1, s3.0 (sum order of the reference: p5-, p4-, p3-, p2-branch)
+        for (int d = 0; d < 4; ++d) {
+            for (int k = 0; k < 3; ++k) {
+                m.t_lo[d][k] = ws + n->a_seg[d][lo[k]].off;
+                m.a_lo[d][k] = ws + n->gn_aff_off[d][lo[k]];
+            }
+            m.t_hi[d] = ws + n->a_seg[d][6].off;
+            m.a_hi[d] = ws + n->gn_aff_off[d][6];
+            m.hw[d] = n->pptr[n->dec[d].p_head_w];
+            m.hb[d] = n->pptr[n->dec[d].p_head_b];
+            m.out[d] = ws + n->a_low[d].off;
+            m.ch[d] = n->dec[d].head_ch;
+            m.chp[d] = n->dec[d].head_chp;
+        }
+        m.B = B; m.h = n->a_seg[0][2].H; m.w = n->a_seg[0][2].W; m.C = 128;
+        FPC_TRY(launch_merge_head(m, 4, s));
+    }
+    {
+        Up4Args u;
+        memset(&u, 0, sizeof(u));
+        u.lm = ws + n->a_low[0].off; u.lq = ws + n->a_low[1].off; u.lt = ws + n->a_low[2].off; u.ls = ws + n->a_low[3].off;
+        u.pm = n->dec[0].head_chp; u.pq = n->dec[1].head_chp; u.pt = n->dec[2].head_chp; u.ps = n->dec[3].head_chp;
+        u.o_mask = logits_mask; u.o_quat = logits_quat; u.o_scales = logits_scales; u.o_xy = logits_xy; u.o_z = logits_z;
+        u.cat_mask = (long long*)cat_mask; u.cq = cq; u.cs = cs; u.cxy = cxy; u.cz = cz;
+        u.B = B; u.hl = n->a_low[0].H; u.wl = n->a_low[0].W; u.H = H; u.W = W; u.C = n->classes;
+        if (u.hl * 4 != H || u.wl * 4 != W) return FPC_EINVAL;
+        FPC_TRY(launch_up4_compress(u, s));
+    }
+    return FPC_OK;
+}
+
+// Debug / test access to the engine's intermediate activations (NHWC f32 inside the workspace).
+// name: "stem", "pool", "c2".."c5", "d<k>.p5".."d<k>.p2", "d<k>.seg<i>" (pre-GroupNorm), "d<k>.low".
+extern "C" int fpc_net_tensor(const fpc_net_t* n, const char* name, const float** ptr, int* H, int* W, int* C) {
+    if (!n || !n->ws || !name || !ptr || !H || !W || !C) return FPC_EINVAL;
+    Act t;
+    bool ok = false;
+    if (!strcmp(name, "stem")) { t = n->a_stem; ok = true; }
+    else if (!strcmp(name, "pool")) { t = n->a_pool; ok = true; }
+    else if (name[0] == 'c' && name[1] >= '2' && name[1] <= '5' && !name[2]) { t = n->a_blk_y[name[1] - '2'].back(); ok = true; }
+    else if (name[0] == 'd' && name[1] >= '0' && name[1] <= '3' && name[2] == '.') {
+        int d = name[1] - '0';
+        const char* r = name + 3;
+        if (r[0] == 'p' && r[1] >= '2' && r[1] <= '5' && !r[2]) { t = n->a_p[d]['5' - r[1]]; ok = true; }
+        else if (!strncmp(r, "seg", 3) && r[3] >= '0' && r[3] <= '6' && !r[4]) { t = n->a_seg[d][r[3] - '0']; ok = true; }
+        else if (!strcmp(r, "low")) { t = n->a_low[d]; ok = true; }
+    }
+    if (!ok) return FPC_EINVAL;
+    *ptr = n->ws + t.off; *H = t.H; *W = t.W; *C = t.C;
+    return FPC_OK;
+}
+
+// ---- stand-alone convolution (unit tests / micro-benchmarks of k_conv_igemm) -----------------
+extern "C" size_t fpc_conv2d_workspace_bytes(int B, int Ho, int Wo, int Cin, int Cout, int Kh, int Kw) {
+    int K = Cin * Kh * Kw, Kpad = cdiv(K, kConvBK) * kConvBK, Npad = cdiv(Cout, kConvNAlign) * kConvNAlign;
+    size_t packed = ((size_t)Npad * Kpad + 63) / 64 * 64;
+    size_t splitk = (size_t)32 * B * (cdiv(Ho * Wo, 128) * 128) * Npad;
+    return (packed + splitk) * sizeof(float);
+}
+
+extern "C" int fpc_conv2d_plan(int B, int Ho, int Wo, int Cin, int Cout, int Kh, int Kw, int bm, int bn, int nsplit,
+                               int* out4) {
+    if (!out4) return FPC_EINVAL;
+    int Kpad = cdiv(Cin * Kh * Kw, kConvBK) * kConvBK;
+    ConvPlan p = plan_conv(Ho * Wo, B, Cout, Kpad / kConvBK, 1, bm, bn, nsplit);
+    out4[0] = p.bm; out4[1] = p.bn; out4[2] = p.nsplit; out4[3] = p.mtiles * p.bm / 32;
+    return FPC_OK;
+}
+
+extern "C" int fpc_conv2d(const float* in, int64_t sb, int64_t sh, int64_t sw, int64_t sc, const float* w_oihw,
+                          const float* scale, const float* shift, const float* res, const float* up, float* out,
+                          float* gn_part, int B, int Hi, int Wi, int Cin, int Cout, int Kh, int Kw, int stride, int pad,
+                          int relu, int bm, int bn, int nsplit, void* ws, size_t ws_bytes, fpc_stream_t stream) {
+    if (!in || !w_oihw || !out || !ws || B < 1 || Kh != Kw) return FPC_EINVAL;
+    int Ho = conv_out(Hi, Kh, stride, pad), Wo = conv_out(Wi, Kw, stride, pad);
+    if (Ho < 1 || Wo < 1) return FPC_EINVAL;
+    if (ws_bytes < fpc_conv2d_workspace_bytes(B, Ho, Wo, Cin, Cout, Kh, Kw) || ((uintptr_t)ws & 255)) return FPC_EWORKSPACE;
+    PackedConv c;
+    c.Cin = Cin; c.Cout = Cout; c.Kh = Kh; c.Kw = Kw; c.stride = stride; c.pad = pad;
+    c.K = Cin * Kh * Kw; c.Kpad = cdiv(c.K, kConvBK) * kConvBK; c.Npad = cdiv(Cout, kConvNAlign) * kConvNAlign;
+    hipStream_t s = (hipStream_t)stream;
+    float* packed = (float*)ws;
+    FPC_TRY(launch_pack_weight(w_oihw, packed, Cout, Cin, Kh, Kw, c.Npad, c.Kpad, s));
+    ConvPlan p = plan_conv(Ho * Wo, B, Cout, c.Kpad / kConvBK, 1, bm, bn, nsplit);
+    bool generic = (Cin % kConvBK != 0) || sc != 1;
+    fpc_net tmp;
+    tmp.B = B;
+    tmp.ws = packed;
+    tmp.splitk_off = ((size_t)c.Npad * c.Kpad + 63) / 64 * 64;
+    ConvArgs a;
+    fill_conv_args(&tmp, a, c, p, Hi, Wi, Ho, Wo, sb, sh, sw, sc, relu != 0, generic);
+    a.p[0] = ConvPtrs{in, packed, out, scale, shift, res, up, gn_part};
+    return run_conv(a, 1, s);
+}

@@ -1,0 +1,687 @@
+// net_kernels.hip — device kernels of the backbone engine (encoder + FPN decoders + heads),
+// replacing the torch/cuDNN op chain of PoseRegressor.pure_model_forward
+// (F/lib/pose_regressor.py:709-743; encoder / FPNDecoder / SegmentationHead come from
+// segmentation_models_pytorch, call sites :608-666) for inference.
+//
+//   k_conv_igemm        implicit-GEMM convolution on the f32 matrix cores
+//                       (v_mfma_f32_32x32x2_f32: exact f32 FMA chains, no reduced precision).
+//                       M = output pixels of one image, N = output channels, K = (kh, kw, ci).
+//                       Activations are NHWC so a K-step of 32 channels is one 128-byte row per
+//                       output pixel; weights are pre-packed OHWI [Npad][Kpad].  256 threads =
+//                       2x2 wave64, each wave owns a (BM/2)x(BN/2) block of 32x32 MFMA tiles.
+//                       Global -> registers -> LDS (double buffered, rows padded to 36 floats:
+//                       conflict-free ds_read_b128 fragments), one barrier per K-step; the next
+//                       K-step's global loads are in flight under the current step's MFMAs.
+//                       Epilogue: folded BatchNorm / bias, residual, FPN nearest-x2 add, ReLU,
+//                       GroupNorm partial sums.  Split-K writes raw partials instead.
+//   k_conv_splitk_epilogue  fixed-order sum of the split-K partials + the same epilogue.
+//   k_maxpool3x3s2, k_gn_finalize, k_gn_relu_up2, k_merge_head, k_up4_compress: HBM-bound
+//                       streaming kernels, lanes along the contiguous (channel or x) axis.
+#include "net_kernels.hpp"
+
+namespace fpc {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));   // native vector: stays in registers (HIP's float4 struct copies can land in scratch)
+
+constexpr int kLdsRow = kConvBK + 4;   // 36 floats: 16 distinct 16-byte slots for 16 consecutive rows
+
+__device__ __forceinline__ int xcd_swizzle(int bid, int nwg) {
+    // consecutive logical blocks on one XCD (shared L2): bijective for any nwg (guide T1)
+    int q = nwg >> 3, r = nwg & 7, x = bid & 7, k = bid >> 3;
+    return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + k;
+}
+
+// ------------------------------------------------------------------------------------------
+// implicit-GEMM convolution
+
+// One K-step of operands, global -> registers.  Thread (sr, sq) owns rows sr + 32*i and the float4 at
+// column 4*sq of the 32-wide K-step.  (Macros, not functions: hipcc keeps by-reference register
+// arrays in scratch.)
+#define FPC_CONV_LOAD(KS)                                                                                     \
+    do {                                                                                                      \
+        const int ks_ = (KS);                                                                                 \
+        _Pragma("unroll") for (int i = 0; i < BR; ++i) rb[i] =                                                \
+            *reinterpret_cast<const f32x4*>(wrow[i] + ks_ * kConvBK);                                        \
+        if (!GENERIC) {                                                                                       \
+            int k0 = ks_ * kConvBK;                                                                           \
+            int tap = k0 / Cin, c0 = k0 - tap * Cin;                                                          \
+            int kh = tap / Kw, kw = tap - kh * Kw;                                                            \
+            long long koff = (long long)kh * in_sh + (long long)kw * in_sw + c0 + 4 * sq;                     \
+            _Pragma("unroll") for (int i = 0; i < AR; ++i) {                                                  \
+                int hi = a_hi0[i] + kh, wi = a_wi0[i] + kw;                                                   \
+                bool ok = hi >= 0 && hi < Hi && wi >= 0 && wi < Wi;                                           \
+                ra[i] = ok ? *reinterpret_cast<const f32x4*>(P.in + a_off[i] + koff)                         \
+                           : f32x4{0.f, 0.f, 0.f, 0.f};                                                 \
+            }                                                                                                 \
+        } else {                                                                                              \
+            /* any Cin / any input strides (the 7x7 stem reads the NCHW image directly) */                    \
+            _Pragma("unroll") for (int i = 0; i < AR; ++i) ra[i] = f32x4{0.f, 0.f, 0.f, 0.f};           \
+            _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                                   \
+                int k = ks_ * kConvBK + 4 * sq + e;                                                           \
+                bool kv = k < K;                                                                              \
+                int tap = k / Cin, ci = k - tap * Cin;                                                        \
+                int kh = tap / Kw, kw = tap - kh * Kw;                                                        \
+                long long koff = (long long)kh * in_sh + (long long)kw * in_sw + (long long)ci * in_sc;       \
+                _Pragma("unroll") for (int i = 0; i < AR; ++i) {                                              \
+                    int hi = a_hi0[i] + kh, wi = a_wi0[i] + kw;                                               \
+                    bool ok = kv && hi >= 0 && hi < Hi && wi >= 0 && wi < Wi;                                 \
+                    float v = ok ? P.in[a_off[i] + koff] : 0.f;                                               \
+                    if (e == 0) ra[i].x = v;                                                                  \
+                    if (e == 1) ra[i].y = v;                                                                  \
+                    if (e == 2) ra[i].z = v;                                                                  \
+                    if (e == 3) ra[i].w = v;                                                                  \
+                }                                                                                             \
+            }                                                                                                 \
+        }                                                                                                     \
+    } while (0)
+
+#define FPC_CONV_STORE(BUF)                                                                                   \
+    do {                                                                                                      \
+        float* As_ = lds + (BUF) * (BM + BN) * kLdsRow;                                                       \
+        float* Bs_ = As_ + BM * kLdsRow;                                                                      \
+        _Pragma("unroll") for (int i = 0; i < AR; ++i)                                                        \
+            *reinterpret_cast<f32x4*>(As_ + (sr + 32 * i) * kLdsRow + 4 * sq) = ra[i];                       \
+        _Pragma("unroll") for (int i = 0; i < BR; ++i)                                                        \
+            *reinterpret_cast<f32x4*>(Bs_ + (sr + 32 * i) * kLdsRow + 4 * sq) = rb[i];                       \
+    } while (0)
+
+template <int BM, int BN, bool GENERIC>
+__global__ __launch_bounds__(256, 2) void k_conv_igemm(const ConvArgs a) {
+    constexpr int TM = BM / 64, TN = BN / 64;     // 32x32 tiles per wave
+    constexpr int AR = BM / 32, BR = BN / 32;     // float4 rows staged per thread
+    __shared__ __attribute__((aligned(16))) float lds[2 * (BM + BN) * kLdsRow];
+
+    ConvPtrs P = a.p[0];
+    if (blockIdx.y == 1) P = a.p[1];
+    if (blockIdx.y == 2) P = a.p[2];
+    if (blockIdx.y == 3) P = a.p[3];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int li = lane & 31, lh = lane >> 5;
+    const int Cin = a.Cin, Kw = a.Kw, K = a.K, Hi = a.Hi, Wi = a.Wi, Wo = a.Wo, Cout = a.Cout, Npad = a.Npad;
+    const int Kpad = a.Kpad, stride = a.stride, pad = a.pad, mtiles = a.mtiles, ntiles = a.ntiles, nB = a.B;
+    const int nsplit = a.nsplit, ksteps = a.ksteps;
+    const long long in_sb = a.in_sb, in_sh = a.in_sh, in_sw = a.in_sw, in_sc = a.in_sc;
+
+    // block -> (m tile, image, n tile, k split); m fastest so neighbours share weights and halos
+    int bid = xcd_swizzle(blockIdx.x, gridDim.x);
+    const int mt = bid % mtiles; bid /= mtiles;
+    const int b = bid % nB; bid /= nB;
+    const int nt = bid % ntiles;
+    const int sp = bid / ntiles;
+    const int HoWo = a.Ho * Wo;
+    const int m0 = mt * BM, n0 = nt * BN;
+    int ks0 = 0, ks1 = ksteps;
+    if (nsplit > 1) {
+        int per = (ksteps + nsplit - 1) / nsplit;
+        ks0 = sp * per;
+        ks1 = min(ksteps, ks0 + per);
+    }
+
+    const int sr = t >> 3, sq = t & 7;
+    long long a_off[AR];     // element offset of (b, hi0, wi0, 0)
+    int a_hi0[AR], a_wi0[AR];
+#pragma unroll
+    for (int i = 0; i < AR; ++i) {
+        int p = m0 + sr + 32 * i;
+        bool ok = p < HoWo;
+        int ho = ok ? p / Wo : 0, wo = ok ? p - ho * Wo : 0;
+        a_hi0[i] = ok ? ho * stride - pad : -0x40000000;   // rows past the image: always out of bounds
+        a_wi0[i] = wo * stride - pad;
+        a_off[i] = (long long)b * in_sb + (long long)a_hi0[i] * in_sh + (long long)a_wi0[i] * in_sw;
+    }
+    const float* wrow[BR];
+#pragma unroll
+    for (int i = 0; i < BR; ++i) wrow[i] = P.w + (size_t)(n0 + sr + 32 * i) * Kpad + 4 * sq;
+
+    f32x4 ra[AR], rb[BR];
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    if (ks0 < ks1) {
+        FPC_CONV_LOAD(ks0);
+        FPC_CONV_STORE(0);
+    }
+    __syncthreads();
+    for (int ks = ks0; ks < ks1; ++ks) {
+        const int buf = (ks - ks0) & 1;
+        const bool more = ks + 1 < ks1;
+        if (more) FPC_CONV_LOAD(ks + 1);
+        const float* As = lds + buf * (BM + BN) * kLdsRow + (wm * (BM / 2) + li) * kLdsRow + 4 * lh;
+        const float* Bs = lds + buf * (BM + BN) * kLdsRow + BM * kLdsRow + (wn * (BN / 2) + li) * kLdsRow + 4 * lh;
+#pragma unroll
+        for (int kk = 0; kk < kConvBK / 8; ++kk) {
+            f32x4 fa[TM], fb[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) fa[i] = *reinterpret_cast<const f32x4*>(As + i * 32 * kLdsRow + kk * 8);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) fb[j] = *reinterpret_cast<const f32x4*>(Bs + j * 32 * kLdsRow + kk * 8);
+            // lanes 0-31 carry k = kk*8 + e, lanes 32-63 carry k = kk*8 + 4 + e: each MFMA sums two k
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].x, fb[j].x, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].y, fb[j].y, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].z, fb[j].z, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].w, fb[j].w, acc[i][j], 0, 0, 0);
+                }
+        }
+        if (more) FPC_CONV_STORE(buf ^ 1);
+        __syncthreads();
+    }
+
+    // C/D layout of the 32x32 tile: column = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+    if (nsplit > 1) {
+        float* ws = a.splitk_ws +
+                    ((((size_t)blockIdx.y * nsplit + sp) * nB + b) * ((size_t)mtiles * BM)) * Npad;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                int n = n0 + wn * (BN / 2) + j * 32 + li;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    int p = m0 + wm * (BM / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                    ws[(size_t)p * Npad + n] = acc[i][j][r];
+                }
+            }
+        return;
+    }
+    const int Wu = Wo >> 1, Hu = a.Ho >> 1;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            int n = n0 + wn * (BN / 2) + j * 32 + li;
+            bool nv = n < Cout;
+            float sc = (P.scale && nv) ? P.scale[n] : 1.f;
+            float sh = (P.shift && nv) ? P.shift[n] : 0.f;
+            int prow = m0 + wm * (BM / 2) + i * 32;
+            float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                int p = prow + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                if (p < HoWo && nv) {
+                    float v = acc[i][j][r];
+                    if (P.scale) v = v * sc;
+                    v = v + sh;
+                    size_t o = ((size_t)b * HoWo + p) * Cout + n;
+                    if (P.res) v += P.res[o];
+                    if (P.up) {
+                        int ho = p / Wo, wo = p - ho * Wo;
+                        v += P.up[(((size_t)b * Hu + (ho >> 1)) * Wu + (wo >> 1)) * Cout + n];
+                    }
+                    if (a.relu) v = fmaxf(v, 0.f);
+                    P.out[o] = v;
+                    s1 += v; s2 += v * v;
+                }
+            }
+            if (P.gn_part) {
+                s1 += __shfl_xor(s1, 32, 64);
+                s2 += __shfl_xor(s2, 32, 64);
+                if (lh == 0 && nv) {
+                    int P32 = mtiles * (BM / 32);
+                    float* g = P.gn_part + (((size_t)b * P32 + prow / 32) * Cout + n) * 2;
+                    g[0] = s1; g[1] = s2;
+                }
+            }
+        }
+}
+
+// grid (P32 = mtiles*bm/32, B, G); sums the split-K partials in split order and applies the epilogue.
+__global__ __launch_bounds__(256) void k_conv_splitk_epilogue(const ConvArgs a) {
+    __shared__ float s_sum[8][128][2];
+    ConvPtrs P = a.p[0];
+    if (blockIdx.z == 1) P = a.p[1];
+    if (blockIdx.z == 2) P = a.p[2];
+    if (blockIdx.z == 3) P = a.p[3];
+    const int t = threadIdx.x, rg = t >> 5, cq = t & 31;
+    const int b = blockIdx.y, tile = blockIdx.x;
+    const int HoWo = a.Ho * a.Wo, Mp = a.mtiles * a.bm;
+    const int Wu = a.Wo >> 1, Hu = a.Ho >> 1;
+    const int P32 = gridDim.x;
+    for (int nc = 0; nc < a.Cout; nc += 128) {
+        int n = nc + 4 * cq;
+        bool nv = n < a.Cout;     // Cout % 4 == 0 on this path
+        float cs1[4] = {0, 0, 0, 0}, cs2[4] = {0, 0, 0, 0};
+        float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (nv && P.scale) sc = *reinterpret_cast<const float4*>(P.scale + n);
+        if (nv && P.shift) sh = *reinterpret_cast<const float4*>(P.shift + n);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            int p = tile * 32 + rg + 8 * j;
+            if (!(nv && p < HoWo)) continue;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int sp = 0; sp < a.nsplit; ++sp) {
+                const float* ws = a.splitk_ws + ((((size_t)blockIdx.z * a.nsplit + sp) * a.B + b) * (size_t)Mp + p) * a.Npad + n;
+                float4 x = *reinterpret_cast<const float4*>(ws);
+                v.x += x.x; v.y += x.y; v.z += x.z; v.w += x.w;
+            }
+            if (P.scale) { v.x *= sc.x; v.y *= sc.y; v.z *= sc.z; v.w *= sc.w; }
+            v.x += sh.x; v.y += sh.y; v.z += sh.z; v.w += sh.w;
+            size_t o = ((size_t)b * HoWo + p) * a.Cout + n;
+            if (P.res) {
+                float4 x = *reinterpret_cast<const float4*>(P.res + o);
+                v.x += x.x; v.y += x.y; v.z += x.z; v.w += x.w;
+            }
+            if (P.up) {
+                int ho = p / a.Wo, wo = p - ho * a.Wo;
+                float4 x = *reinterpret_cast<const float4*>(P.up + (((size_t)b * Hu + (ho >> 1)) * Wu + (wo >> 1)) * a.Cout + n);
+                v.x += x.x; v.y += x.y; v.z += x.z; v.w += x.w;
+            }
+            if (a.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+            *reinterpret_cast<float4*>(P.out + o) = v;
+            cs1[0] += v.x; cs1[1] += v.y; cs1[2] += v.z; cs1[3] += v.w;
+            cs2[0] += v.x * v.x; cs2[1] += v.y * v.y; cs2[2] += v.z * v.z; cs2[3] += v.w * v.w;
+        }
+        if (P.gn_part) {
+            __syncthreads();
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { s_sum[rg][4 * cq + e][0] = cs1[e]; s_sum[rg][4 * cq + e][1] = cs2[e]; }
+            __syncthreads();
+            if (t < 128 && nc + t < a.Cout) {
+                float u = 0.f, w = 0.f;
+#pragma unroll
+                for (int g = 0; g < 8; ++g) { u += s_sum[g][t][0]; w += s_sum[g][t][1]; }
+                float* gp = P.gn_part + (((size_t)b * P32 + tile) * a.Cout + nc + t) * 2;
+                gp[0] = u; gp[1] = w;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// max pooling 3x3 stride 2 pad 1, NHWC, one float4 of channels per thread
+
+__global__ __launch_bounds__(256) void k_maxpool3x3s2(const float* __restrict__ in, float* __restrict__ out, int B,
+                                                      int Hi, int Wi, int C, int Ho, int Wo) {
+    int C4 = C >> 2;
+    long long total = (long long)B * Ho * Wo * C4;
+    for (long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (long long)gridDim.x * blockDim.x) {
+        int c4 = (int)(g % C4);
+        long long r = g / C4;
+        int wo = (int)(r % Wo); r /= Wo;
+        int ho = (int)(r % Ho);
+        int b = (int)(r / Ho);
+        float4 m = make_float4(-__builtin_huge_valf(), -__builtin_huge_valf(), -__builtin_huge_valf(), -__builtin_huge_valf());
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy) {
+            int hi = ho * 2 - 1 + dy;
+            if (hi < 0 || hi >= Hi) continue;
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx) {
+                int wi = wo * 2 - 1 + dx;
+                if (wi < 0 || wi >= Wi) continue;
+                float4 v = *reinterpret_cast<const float4*>(in + (((size_t)b * Hi + hi) * Wi + wi) * C + 4 * c4);
+                m.x = fmaxf(m.x, v.x); m.y = fmaxf(m.y, v.y); m.z = fmaxf(m.z, v.z); m.w = fmaxf(m.w, v.w);
+            }
+        }
+        *reinterpret_cast<float4*>(out + (size_t)g * 4) = m;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// GroupNorm statistics: partial sums -> per (image, channel) affine  y = x*a + b
+// grid (groups, B, G), 64 threads; fp64 combine in fixed order.
+
+__global__ __launch_bounds__(64) void k_gn_finalize(const GnFinArgs a) {
+    const int g = blockIdx.x, b = blockIdx.y, z = blockIdx.z;
+    const int cpg = a.C / a.groups;
+    const float* part = a.gn_part[z] + (size_t)b * a.P * a.C * 2;
+    double s1 = 0.0, s2 = 0.0;
+    for (int i = threadIdx.x; i < a.P * cpg; i += 64) {
+        int tile = i / cpg, c = g * cpg + (i - tile * cpg);
+        const float* q = part + ((size_t)tile * a.C + c) * 2;
+        s1 += (double)q[0]; s2 += (double)q[1];
+    }
+    s1 = wave_reduce_add(s1);
+    s2 = wave_reduce_add(s2);
+    s1 = __shfl(s1, 0, 64); s2 = __shfl(s2, 0, 64);
+    double mean = s1 / (double)a.count;
+    double var = s2 / (double)a.count - mean * mean;
+    if (var < 0.0) var = 0.0;
+    float rstd = (float)(1.0 / sqrt(var + (double)a.eps));
+    float fmean = (float)mean;
+    if ((int)threadIdx.x < cpg) {
+        int c = g * cpg + threadIdx.x;
+        float ga = a.gamma[z][c], be = a.beta[z][c];
+        float sa = rstd * ga;
+        float* o = a.affine[z] + ((size_t)b * a.C + c) * 2;
+        o[0] = sa;
+        o[1] = be - fmean * sa;
+    }
+}
+
+// bilinear source coordinate, align_corners=True, torch's arithmetic (UpSample.cuh):
+// src = dst * (in-1)/(out-1) in f32; i0 = (int)src; l1 = src - i0; i1 = i0 + (i0 < in-1)
+struct Lerp { int i0, i1; float l0, l1; };
+__device__ __forceinline__ Lerp lerp_coord(int dst, int in, int out) {
+    float scale = out > 1 ? (float)(in - 1) / (float)(out - 1) : 0.f;
+    float src = scale * (float)dst;
+    Lerp L;
+    L.i0 = (int)src;
+    L.i1 = L.i0 + (L.i0 < in - 1 ? 1 : 0);
+    L.l1 = src - (float)L.i0;
+    L.l0 = 1.f - L.l1;
+    return L;
+}
+
+__device__ __forceinline__ float4 gn_relu4(const float* p, float4 sa, float4 sb) {
+    float4 v = *reinterpret_cast<const float4*>(p);
+    v.x = fmaxf(v.x * sa.x + sb.x, 0.f); v.y = fmaxf(v.y * sa.y + sb.y, 0.f);
+    v.z = fmaxf(v.z * sa.z + sb.z, 0.f); v.w = fmaxf(v.w * sa.w + sb.w, 0.f);
+    return v;
+}
+
+__device__ __forceinline__ float4 bilerp4(float4 v00, float4 v01, float4 v10, float4 v11, Lerp ly, Lerp lx) {
+    float4 r;
+    r.x = ly.l0 * (lx.l0 * v00.x + lx.l1 * v01.x) + ly.l1 * (lx.l0 * v10.x + lx.l1 * v11.x);
+    r.y = ly.l0 * (lx.l0 * v00.y + lx.l1 * v01.y) + ly.l1 * (lx.l0 * v10.y + lx.l1 * v11.y);
+    r.z = ly.l0 * (lx.l0 * v00.z + lx.l1 * v01.z) + ly.l1 * (lx.l0 * v10.z + lx.l1 * v11.z);
+    r.w = ly.l0 * (lx.l0 * v00.w + lx.l1 * v01.w) + ly.l1 * (lx.l0 * v10.w + lx.l1 * v11.w);
+    return r;
+}
+
+// affine [B][C][2] interleaved (a, b): two float4 loads give (a0,b0,a1,b1),(a2,b2,a3,b3)
+__device__ __forceinline__ void load_affine4(const float* aff, float4& sa, float4& sb) {
+    float4 u = *reinterpret_cast<const float4*>(aff), v = *reinterpret_cast<const float4*>(aff + 4);
+    sa = make_float4(u.x, u.z, v.x, v.z);
+    sb = make_float4(u.y, u.w, v.y, v.w);
+}
+
+// GN + ReLU + x2 bilinear upsample (Conv3x3GNReLU with upsample=True), grid-stride, grid.y = group
+__global__ __launch_bounds__(256) void k_gn_relu_up2(const GnUpArgs a) {
+    const int z = blockIdx.y;
+    const float* in = a.in[z];
+    const float* aff = a.affine[z];
+    float* out = a.out[z];
+    const int C4 = a.C >> 2, H2 = 2 * a.h, W2 = 2 * a.w;
+    long long total = (long long)a.B * H2 * W2 * C4;
+    for (long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (long long)gridDim.x * blockDim.x) {
+        int c4 = (int)(g % C4);
+        long long r = g / C4;
+        int x = (int)(r % W2); r /= W2;
+        int y = (int)(r % H2);
+        int b = (int)(r / H2);
+        Lerp ly = lerp_coord(y, a.h, H2), lx = lerp_coord(x, a.w, W2);
+        float4 sa, sb;
+        load_affine4(aff + ((size_t)b * a.C + 4 * c4) * 2, sa, sb);
+        const float* base = in + (size_t)b * a.h * a.w * a.C + 4 * c4;
+        float4 v00 = gn_relu4(base + ((size_t)ly.i0 * a.w + lx.i0) * a.C, sa, sb);
+        float4 v01 = gn_relu4(base + ((size_t)ly.i0 * a.w + lx.i1) * a.C, sa, sb);
+        float4 v10 = gn_relu4(base + ((size_t)ly.i1 * a.w + lx.i0) * a.C, sa, sb);
+        float4 v11 = gn_relu4(base + ((size_t)ly.i1 * a.w + lx.i1) * a.C, sa, sb);
+        *reinterpret_cast<float4*>(out + (size_t)g * 4) = bilerp4(v00, v01, v10, v11, ly, lx);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// FPN merge ("add" of the four segmentation blocks' outputs, smp MergeBlock) fused with the last
+// GN+ReLU(+x2 upsample) of each branch and with the 1x1 segmentation head:
+//   merged = up2(relu(gn(t5))) + up2(relu(gn(t4))) + up2(relu(gn(t3))) + relu(gn(t2))   (sum order of sum([...]))
+//   logits_lowres[pixel][ch] = bias[ch] + sum_c merged[pixel][c] * W[ch][c]
+// One workgroup = 64 pixels of one image; merged tile and head weights live in LDS.
+// Dropout2d is the identity in eval mode.  grid (ceil(H2*W2/64), B, G).
+constexpr int kMhPx = 64;
+constexpr int kMhMaxC = 128;
+constexpr int kMhMaxCh = 32;
+
+__global__ __launch_bounds__(256) void k_merge_head(const MergeHeadArgs a) {
+    __shared__ __attribute__((aligned(16))) float s_m[kMhPx][kMhMaxC + 4];
+    __shared__ __attribute__((aligned(16))) float s_w[kMhMaxCh][kMhMaxC + 4];
+    const int z = blockIdx.z, b = blockIdx.y;
+    const int H2 = 2 * a.h, W2 = 2 * a.w, C = a.C, C4 = C >> 2;
+    const int ch = a.ch[z], chp = a.chp[z];
+    for (int i = threadIdx.x; i < ch * C; i += 256) s_w[i / C][i % C] = a.hw[z][i];
+    const int p0 = blockIdx.x * kMhPx;
+    for (int e = threadIdx.x; e < kMhPx * C4; e += 256) {
+        int c4 = e % C4, pl = e / C4;
+        int p = p0 + pl;
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (p < H2 * W2) {
+            int y = p / W2, x = p - y * W2;
+            Lerp ly = lerp_coord(y, a.h, H2), lx = lerp_coord(x, a.w, W2);
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                float4 sa, sb;
+                load_affine4(a.a_lo[z][k] + ((size_t)b * C + 4 * c4) * 2, sa, sb);
+                const float* base = a.t_lo[z][k] + (size_t)b * a.h * a.w * C + 4 * c4;
+                float4 v00 = gn_relu4(base + ((size_t)ly.i0 * a.w + lx.i0) * C, sa, sb);
+                float4 v01 = gn_relu4(base + ((size_t)ly.i0 * a.w + lx.i1) * C, sa, sb);
+                float4 v10 = gn_relu4(base + ((size_t)ly.i1 * a.w + lx.i0) * C, sa, sb);
+                float4 v11 = gn_relu4(base + ((size_t)ly.i1 * a.w + lx.i1) * C, sa, sb);
+                float4 u = bilerp4(v00, v01, v10, v11, ly, lx);
+                acc.x += u.x; acc.y += u.y; acc.z += u.z; acc.w += u.w;
+            }
+            float4 sa, sb;
+            load_affine4(a.a_hi[z] + ((size_t)b * C + 4 * c4) * 2, sa, sb);
+            float4 u = gn_relu4(a.t_hi[z] + ((size_t)b * H2 * W2 + p) * C + 4 * c4, sa, sb);
+            acc.x += u.x; acc.y += u.y; acc.z += u.z; acc.w += u.w;
+        }
+        *reinterpret_cast<float4*>(&s_m[pl][4 * c4]) = acc;
+    }
+    __syncthreads();
+    // head: lanes along the pixel axis read LDS rows at stride C+4 (conflict-free), weights broadcast
+    for (int e = threadIdx.x; e < kMhPx * chp; e += 256) {
+        int pl = e % kMhPx, k = e / kMhPx;
+        int p = p0 + pl;
+        if (p >= H2 * W2) continue;
+        float v = 0.f;
+        if (k < ch) {
+            v = a.hb[z][k];
+            for (int c = 0; c < C; c += 4) {
+                float4 m = *reinterpret_cast<const float4*>(&s_m[pl][c]);
+                float4 w = *reinterpret_cast<const float4*>(&s_w[k][c]);
+                v += m.x * w.x; v += m.y * w.y; v += m.z * w.z; v += m.w * w.w;
+            }
+        }
+        a.out[z][((size_t)b * H2 * W2 + p) * chp + k] = v;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// x4 bilinear upsample (UpsamplingBilinear2d, align_corners=True) of the four heads' low-res
+// logits to full resolution, the xyz -> xy / z channel split (pose_regressor.py:729-732) and
+// class compression (pose_regressor.py:445-457, gpu_tensor_funcs.py:37-99) in one pass.
+// One thread per output pixel, lanes along x: every full-res plane store is a coalesced
+// 256-byte wave row; the low-res taps (5 MB in total) are served by L1/L2.
+
+template <int MAXC>
+__global__ __launch_bounds__(256) void k_up4_compress(const Up4Args a) {
+    const int b = blockIdx.z, y = blockIdx.y;
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    if (x >= a.W) return;
+    const int HW = a.H * a.W, C = a.C, G = C - 1;
+    const size_t p = (size_t)y * a.W + x;
+    Lerp ly = lerp_coord(y, a.hl, a.H), lx = lerp_coord(x, a.wl, a.W);
+    const size_t t00 = ((size_t)b * a.hl + ly.i0) * a.wl + lx.i0, t01 = ((size_t)b * a.hl + ly.i0) * a.wl + lx.i1;
+    const size_t t10 = ((size_t)b * a.hl + ly.i1) * a.wl + lx.i0, t11 = ((size_t)b * a.hl + ly.i1) * a.wl + lx.i1;
+    auto tap = [&](const float* L, int stride, int c) {
+        return ly.l0 * (lx.l0 * L[t00 * stride + c] + lx.l1 * L[t01 * stride + c]) +
+               ly.l1 * (lx.l0 * L[t10 * stride + c] + lx.l1 * L[t11 * stride + c]);
+    };
+    // mask logits + arg-max of the log-softmax (first maximal index on ties), as class_compress.hip
+    float v[MAXC];
+    float mx = -__builtin_huge_valf();
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c)
+        if (c < C) {
+            v[c] = tap(a.lm, a.pm, c);
+            mx = fmaxf(mx, v[c]);
+            if (a.o_mask) a.o_mask[((size_t)b * C + c) * HW + p] = v[c];
+        }
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c)
+        if (c < C) s += expf(v[c] - mx);
+    float lse = logf(s);
+    float best = (v[0] - mx) - lse;
+    int cls = 0;
+#pragma unroll
+    for (int c = 1; c < MAXC; ++c)
+        if (c < C) {
+            float val = (v[c] - mx) - lse;
+            if (val > best) { best = val; cls = c; }
+        }
+    a.cat_mask[(size_t)b * HW + p] = cls;
+    const int g = cls - 1;
+    float q[4] = {0, 0, 0, 0}, sc[3] = {0, 0, 0}, vxy[2] = {0, 0}, zz = 0.f;
+    for (int k = 0; k < G; ++k) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float u = tap(a.lq, a.pq, 4 * k + e);
+            if (a.o_quat) a.o_quat[((size_t)b * 4 * G + 4 * k + e) * HW + p] = u;
+            if (k == g) q[e] = u;
+        }
+#pragma unroll
+        for (int e = 0; e < 3; ++e) {
+            float u = tap(a.ls, a.ps, 3 * k + e);
+            if (a.o_scales) a.o_scales[((size_t)b * 3 * G + 3 * k + e) * HW + p] = u;
+            if (k == g) sc[e] = u;
+        }
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            float u = tap(a.lt, a.pt, 3 * k + e);
+            if (a.o_xy) a.o_xy[((size_t)b * 2 * G + 2 * k + e) * HW + p] = u;
+            if (k == g) vxy[e] = u;
+        }
+        float u = tap(a.lt, a.pt, 3 * k + 2);
+        if (a.o_z) a.o_z[((size_t)b * G + k) * HW + p] = u;
+        if (k == g) zz = u;
+    }
+    float nq = sqrtf(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+    if (nq == 0.0f) nq = 1.0f;
+    float nv = sqrtf(vxy[0] * vxy[0] + vxy[1] * vxy[1]);
+    if (nv == 0.0f) nv = 1.0f;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) a.cq[((size_t)b * 4 + e) * HW + p] = q[e] / nq;
+#pragma unroll
+    for (int e = 0; e < 3; ++e) a.cs[((size_t)b * 3 + e) * HW + p] = sc[e];
+#pragma unroll
+    for (int e = 0; e < 2; ++e) a.cxy[((size_t)b * 2 + e) * HW + p] = vxy[e] / nv;
+    a.cz[(size_t)b * HW + p] = zz;
+}
+
+// ------------------------------------------------------------------------------------------
+// parameter repacking (once per plan)
+
+// OIHW [Cout][Cin][Kh][Kw] -> OHWI rows [Npad][Kpad], k = (kh*Kw + kw)*Cin + ci, zero padded
+__global__ __launch_bounds__(256) void k_pack_weight(const float* __restrict__ w, float* __restrict__ out, int Cout,
+                                                     int Cin, int Kh, int Kw, int Npad, int Kpad) {
+    long long total = (long long)Npad * Kpad;
+    int K = Cin * Kh * Kw;
+    for (long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (long long)gridDim.x * blockDim.x) {
+        int k = (int)(g % Kpad), n = (int)(g / Kpad);
+        float v = 0.f;
+        if (n < Cout && k < K) {
+            int tap = k / Cin, ci = k - tap * Cin;
+            int kh = tap / Kw, kw = tap - kh * Kw;
+            v = w[(((size_t)n * Cin + ci) * Kh + kh) * Kw + kw];
+        }
+        out[g] = v;
+    }
+}
+
+// eval-mode BatchNorm as y = x*scale + shift (torch: (x - mean) / sqrt(var + eps) * gamma + beta)
+__global__ void k_fold_bn(const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ mean,
+                          const float* __restrict__ var, float eps, int C, float* __restrict__ scale,
+                          float* __restrict__ shift) {
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    float inv = 1.0f / sqrtf(var[c] + eps);
+    float s = gamma[c] * inv;
+    scale[c] = s;
+    shift[c] = beta[c] - mean[c] * s;
+}
+
+// ------------------------------------------------------------------------------------------
+// launch wrappers
+
+template <int BM, int BN>
+static void launch_conv_t(const ConvArgs& a, int groups, hipStream_t s) {
+    dim3 grid(a.mtiles * a.B * a.ntiles * a.nsplit, groups);
+    if (a.generic)
+        hipLaunchKernelGGL((k_conv_igemm<BM, BN, true>), grid, dim3(256), 0, s, a);
+    else
+        hipLaunchKernelGGL((k_conv_igemm<BM, BN, false>), grid, dim3(256), 0, s, a);
+}
+
+int launch_conv(const ConvArgs& a, int groups, hipStream_t s) {
+    if (groups < 1 || groups > kMaxGroup || a.Npad % a.bn != 0 || a.Kpad % kConvBK != 0) return FPC_EINVAL;
+    if (!a.generic && (a.Cin % kConvBK != 0 || a.in_sc != 1)) return FPC_EINVAL;
+    if (a.bm == 128 && a.bn == 128) launch_conv_t<128, 128>(a, groups, s);
+    else if (a.bm == 128 && a.bn == 64) launch_conv_t<128, 64>(a, groups, s);
+    else if (a.bm == 64 && a.bn == 128) launch_conv_t<64, 128>(a, groups, s);
+    else if (a.bm == 64 && a.bn == 64) launch_conv_t<64, 64>(a, groups, s);
+    else return FPC_EINVAL;
+    return check_launch();
+}
+
+int launch_conv_splitk_epilogue(const ConvArgs& a, int groups, hipStream_t s) {
+    if (a.Cout % 4 != 0) return FPC_EINVAL;
+    hipLaunchKernelGGL(k_conv_splitk_epilogue, dim3(a.mtiles * a.bm / 32, a.B, groups), dim3(256), 0, s, a);
+    return check_launch();
+}
+
+static int stream_grid(long long work_items) {
+    long long g = (work_items + 255) / 256;
+    return (int)(g < 1 ? 1 : (g > 4096 ? 4096 : g));
+}
+
+int launch_maxpool3x3s2(const float* in, float* out, int B, int Hi, int Wi, int C, int Ho, int Wo, hipStream_t s) {
+    if (C % 4 != 0) return FPC_EINVAL;
+    hipLaunchKernelGGL(k_maxpool3x3s2, dim3(stream_grid((long long)B * Ho * Wo * (C / 4))), dim3(256), 0, s, in, out, B,
+                       Hi, Wi, C, Ho, Wo);
+    return check_launch();
+}
+
+int launch_gn_finalize(const GnFinArgs& a, int groups, hipStream_t s) {
+    if (a.C % a.groups != 0 || a.C / a.groups > 64) return FPC_EINVAL;
+    hipLaunchKernelGGL(k_gn_finalize, dim3(a.groups, a.B, groups), dim3(64), 0, s, a);
+    return check_launch();
+}
+
+int launch_gn_relu_up2(const GnUpArgs& a, int groups, hipStream_t s) {
+    if (a.C % 4 != 0) return FPC_EINVAL;
+    hipLaunchKernelGGL(k_gn_relu_up2, dim3(stream_grid((long long)a.B * 4 * a.h * a.w * (a.C / 4)), groups), dim3(256), 0,
+                       s, a);
+    return check_launch();
+}
+
+int launch_merge_head(const MergeHeadArgs& a, int groups, hipStream_t s) {
+    if (a.C > kMhMaxC || a.C % 4 != 0) return FPC_EINVAL;
+    for (int z = 0; z < groups; ++z)
+        if (a.ch[z] > kMhMaxCh || a.chp[z] > kMhMaxCh || a.chp[z] < a.ch[z]) return FPC_EINVAL;
+    hipLaunchKernelGGL(k_merge_head, dim3(cdiv(4 * a.h * a.w, kMhPx), a.B, groups), dim3(256), 0, s, a);
+    return check_launch();
+}
+
+int launch_up4_compress(const Up4Args& a, hipStream_t s) {
+    if (a.C < 2 || a.C > 32 || a.H > 65535 || a.B > 65535) return FPC_EINVAL;
+    dim3 grid(cdiv(a.W, 256), a.H, a.B);
+    if (a.C <= 8) hipLaunchKernelGGL(k_up4_compress<8>, grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL(k_up4_compress<32>, grid, dim3(256), 0, s, a);
+    return check_launch();
+}
+
+int launch_pack_weight(const float* w, float* packed, int Cout, int Cin, int Kh, int Kw, int Npad, int Kpad,
+                       hipStream_t s) {
+    hipLaunchKernelGGL(k_pack_weight, dim3(stream_grid((long long)Npad * Kpad)), dim3(256), 0, s, w, packed, Cout, Cin,
+                       Kh, Kw, Npad, Kpad);
+    return check_launch();
+}
+
+int launch_fold_bn(const float* gamma, const float* beta, const float* mean, const float* var, float eps, int C,
+                   float* scale, float* shift, hipStream_t s) {
+    hipLaunchKernelGGL(k_fold_bn, dim3(cdiv(C, 256)), dim3(256), 0, s, gamma, beta, mean, var, eps, C, scale, shift);
+    return check_launch();
+}
+
+}  // namespace fpc

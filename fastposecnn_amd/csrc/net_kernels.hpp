@@ -1,0 +1,81 @@
+// net_kernels.hpp — argument structs and launch wrappers of the backbone kernels
+// (net_kernels.hip), used by the engine (net.hip).  gfx950 only.
+#pragma once
+#include "common.hpp"
+
+namespace fpc {
+
+constexpr int kMaxGroup = 4;      // the four FPN decoders run as one grouped launch
+constexpr int kConvBK = 32;       // K-step of the implicit GEMM (floats)
+constexpr int kConvNAlign = 128;  // packed weight rows are padded to a multiple of this
+
+struct ConvPtrs {
+    const float* in;      // input activation
+    const float* w;       // packed weights [Npad][Kpad] (OHWI, zero padded)
+    float* out;           // NHWC [B,Ho,Wo,Cout]
+    const float* scale;   // per-channel multiplier (folded BatchNorm) or null
+    const float* shift;   // per-channel addend (folded BatchNorm / conv bias) or null
+    const float* res;     // residual, same shape as out, or null
+    const float* up;      // [B,Ho/2,Wo/2,Cout]: nearest-x2 upsampled and added (FPN top-down) or null
+    float* gn_part;       // [B][P][Cout][2] per-32-row-tile column sums / sums of squares, or null
+};
+
+struct ConvArgs {
+    ConvPtrs p[kMaxGroup];
+    float* splitk_ws;     // [G][nsplit][B][mtiles*BM][Npad] raw partial sums (nsplit > 1)
+    int B, Hi, Wi, Cin, Ho, Wo, Cout, Npad, Kh, Kw, stride, pad, K, Kpad;
+    long long in_sb, in_sh, in_sw, in_sc;   // element strides of the input
+    int relu, nsplit, mtiles, ntiles, ksteps, bm, bn, generic;
+};
+
+struct GnFinArgs {
+    const float* gn_part[kMaxGroup];   // [B][P][C][2]
+    const float* gamma[kMaxGroup];
+    const float* beta[kMaxGroup];
+    float* affine[kMaxGroup];          // [B][C][2]: y = x*a + b
+    int B, P, C, groups;
+    long long count;                   // elements per (image, group) = Ho*Wo*C/groups
+    float eps;
+};
+
+struct GnUpArgs {
+    const float* in[kMaxGroup];        // [B,h,w,C]
+    const float* affine[kMaxGroup];    // [B][C][2]
+    float* out[kMaxGroup];             // [B,2h,2w,C]
+    int B, h, w, C;
+};
+
+struct MergeHeadArgs {
+    const float* t_lo[kMaxGroup][3];   // three [B,h,w,C] pre-GroupNorm maps, upsampled x2 after GN+ReLU
+    const float* a_lo[kMaxGroup][3];   // their affines [B][C][2]
+    const float* t_hi[kMaxGroup];      // [B,2h,2w,C] pre-GroupNorm map at the merge resolution
+    const float* a_hi[kMaxGroup];
+    const float* hw[kMaxGroup];        // head weight [Ch][C]
+    const float* hb[kMaxGroup];        // head bias [Ch]
+    float* out[kMaxGroup];             // low-res logits NHWC [B,2h,2w,chp]
+    int ch[kMaxGroup];                 // real head channels
+    int chp[kMaxGroup];                // padded (multiple of 4) channel stride of out
+    int B, h, w, C;
+};
+
+struct Up4Args {
+    const float* lm; const float* lq; const float* lt; const float* ls;   // low-res NHWC logits (mask, quat, xyz, scales)
+    int pm, pq, pt, ps;                                                   // their channel strides
+    float* o_mask; float* o_quat; float* o_scales; float* o_xy; float* o_z;   // full-res NCHW logits (nullable as a set)
+    long long* cat_mask; float* cq; float* cs; float* cxy; float* cz;          // categorical outputs
+    int B, hl, wl, H, W, C;                                               // C classes incl. background
+};
+
+int launch_conv(const ConvArgs& a, int groups, hipStream_t s);
+int launch_conv_splitk_epilogue(const ConvArgs& a, int groups, hipStream_t s);
+int launch_maxpool3x3s2(const float* in, float* out, int B, int Hi, int Wi, int C, int Ho, int Wo, hipStream_t s);
+int launch_gn_finalize(const GnFinArgs& a, int groups, hipStream_t s);
+int launch_gn_relu_up2(const GnUpArgs& a, int groups, hipStream_t s);
+int launch_merge_head(const MergeHeadArgs& a, int groups, hipStream_t s);
+int launch_up4_compress(const Up4Args& a, hipStream_t s);
+int launch_pack_weight(const float* w_oihw, float* packed, int Cout, int Cin, int Kh, int Kw, int Npad, int Kpad,
+                       hipStream_t s);
+int launch_fold_bn(const float* gamma, const float* beta, const float* mean, const float* var, float eps, int C,
+                   float* scale, float* shift, hipStream_t s);
+
+}  // namespace fpc

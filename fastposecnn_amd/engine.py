@@ -1,0 +1,88 @@
+"""Host side of the backbone engine (`fpc_net_*` in include/fpc.h, csrc/net.hip).
+
+A `NetEngine` binds one PoseRegressor's parameters to a native plan for a fixed (B, H, W): the C
+side repacks the weights once (OHWI, padded; BatchNorm folded), then every `forward` is a single C
+call that enqueues the whole frame's kernels on torch's current stream.  torch only owns the
+memory: parameters, the workspace and the output tensors.
+"""
+import ctypes
+
+import torch
+
+from fastposecnn_amd import _native as nat
+
+
+class NetEngine:
+
+    def __init__(self, model, B, H, W, device):
+        L = nat.lib()
+        self._lib = L
+        self.B, self.H, self.W, self.device = B, H, W, device
+        self.classes = model.classes
+        h = ctypes.c_void_p()
+        enc = model.encoder.name.encode()
+        nat.check(L.fpc_net_create(enc, self.classes, B, H, W, ctypes.byref(h)), "fpc_net_create")
+        self._h = h
+        tensors = dict(model.named_parameters())
+        tensors.update(dict(model.named_buffers()))
+        n = L.fpc_net_param_count(h)
+        self._params = []           # keeps the tensors alive: the plan reads some of them in place
+        for i in range(n):
+            name = L.fpc_net_param_name(h, i).decode()
+            if name not in tensors:
+                raise RuntimeError(f"fastposecnn_amd: the model has no parameter {name!r} (smp naming expected)")
+            t = tensors[name].detach()
+            if t.device != device or t.dtype != torch.float32 or not t.is_contiguous():
+                raise RuntimeError(f"fastposecnn_amd: parameter {name!r} must be a contiguous f32 tensor on {device}")
+            if t.numel() != L.fpc_net_param_numel(h, i):
+                raise RuntimeError(f"fastposecnn_amd: parameter {name!r} has {t.numel()} elements, expected "
+                                   f"{L.fpc_net_param_numel(h, i)}")
+            self._params.append(t)
+        ptrs = (ctypes.c_void_p * n)(*[t.data_ptr() for t in self._params])
+        nbytes = L.fpc_net_workspace_bytes(h)
+        with torch.cuda.device(device):
+            self._ws = torch.empty(nbytes, dtype=torch.uint8, device=device)
+            assert self._ws.data_ptr() % 256 == 0
+            nat.check(L.fpc_net_load_params(h, ptrs, n, self._ws.data_ptr(), nbytes, nat.stream()), "fpc_net_load_params")
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h:
+            self._lib.fpc_net_destroy(h)
+            self._h = None
+
+    def forward(self, x, want_logits=True):
+        """x f32 [B,3,H,W] -> (logits dict | None, categorical dict incl. 'mask')."""
+        B, H, W, C, dev = self.B, self.H, self.W, self.classes, self.device
+        G = C - 1
+        if tuple(x.shape) != (B, 3, H, W) or x.device != dev:
+            raise RuntimeError("NetEngine.forward: input shape / device does not match the plan")
+        if x.dtype != torch.float32 or not x.is_contiguous():
+            x = x.float().contiguous()
+        f32 = dict(dtype=torch.float32, device=dev)
+        logits = None
+        lp = [None] * 5
+        if want_logits:
+            logits = {'mask': torch.empty((B, C, H, W), **f32), 'quaternion': torch.empty((B, 4 * G, H, W), **f32),
+                      'scales': torch.empty((B, 3 * G, H, W), **f32), 'xy': torch.empty((B, 2 * G, H, W), **f32),
+                      'z': torch.empty((B, G, H, W), **f32)}
+            lp = [logits[k].data_ptr() for k in ('mask', 'quaternion', 'scales', 'xy', 'z')]
+        cat = {'mask': torch.empty((B, H, W), dtype=torch.int64, device=dev),
+               'quaternion': torch.empty((B, 4, H, W), **f32), 'scales': torch.empty((B, 3, H, W), **f32),
+               'xy': torch.empty((B, 2, H, W), **f32), 'z': torch.empty((B, H, W), **f32)}
+        with torch.cuda.device(dev):
+            nat.check(self._lib.fpc_net_forward(self._h, x.data_ptr(), *lp, cat['mask'].data_ptr(),
+                                                cat['quaternion'].data_ptr(), cat['scales'].data_ptr(),
+                                                cat['xy'].data_ptr(), cat['z'].data_ptr(), nat.stream()),
+                      "fpc_net_forward")
+        return logits, cat
+
+    def tensor(self, name):
+        """Intermediate activation as an NHWC view into the workspace (tests)."""
+        p = ctypes.c_void_p()
+        H, W, C = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+        nat.check(self._lib.fpc_net_tensor(self._h, name.encode(), ctypes.byref(p), ctypes.byref(H), ctypes.byref(W),
+                                           ctypes.byref(C)), "fpc_net_tensor")
+        off = p.value - self._ws.data_ptr()
+        n = self.B * H.value * W.value * C.value
+        return self._ws[off:off + 4 * n].view(torch.float32).view(self.B, H.value, W.value, C.value)

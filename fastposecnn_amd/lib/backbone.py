@@ -57,6 +57,7 @@ class ResNetEncoder(nn.Module):
         if name not in _RESNET_LAYERS:
             raise KeyError(f"encoder {name!r} not available (have {sorted(_RESNET_LAYERS)})")
         layers = _RESNET_LAYERS[name]
+        self.name = name
         self._depth = depth
         self.out_channels = (in_channels, 64, 64, 128, 256, 512)
         self.inplanes = 64

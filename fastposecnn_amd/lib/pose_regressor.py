@@ -37,6 +37,11 @@ class Model(object):
 
     @CLASS_COMPRESS_TIMER
     def class_compression(self, logits):
+        # the engine's last kernel already produced the categorical data of ITS logits
+        fused = getattr(self, '_fused', None)
+        if fused is not None and fused[0] is logits:
+            self._fused = None
+            return fused[1]
         # arg-max of log-softmax + class compression + normalisation in one kernel
         return gtf.class_compression_fused(self.classes, logits)
 
@@ -122,6 +127,8 @@ class PoseRegressor(Model, torch.nn.Module):
         upsampling: int = 4,
     ):
         torch.nn.Module.__init__(self)
+        self._engines = {}
+        self._fused = None
         self.HPARAM = HPARAM
         self.classes = classes  # includes background
         self.intrinsics = torch.from_numpy(np.asarray(HPARAM.NUMPY_INTRINSICS)).float()
@@ -174,8 +181,45 @@ class PoseRegressor(Model, torch.nn.Module):
         self._xy_index = [i for i in range(n_xyz) if i % 3 != 2]
         self._z_index = [i for i in range(n_xyz) if i % 3 == 2]
 
+    # ---- native engine (inference) -------------------------------------------------------
+    def _engine_for(self, x):
+        """The native plan for this input, or None when the torch modules must run: training /
+        autograd (the engine has no backward), CPU tensors (config 1 plumbing), odd sizes."""
+        if (self.training or torch.is_grad_enabled() or not x.is_cuda or x.dim() != 4 or x.shape[1] != 3
+                or x.shape[2] % 32 or x.shape[3] % 32 or not getattr(self.HPARAM, 'USE_NATIVE_ENGINE', True)):
+            return None
+        key = (x.shape[0], x.shape[2], x.shape[3], x.device)
+        eng = self._engines.get(key)
+        if eng is None:
+            from fastposecnn_amd.engine import NetEngine
+            eng = NetEngine(self, key[0], key[1], key[2], x.device)
+            self._engines[key] = eng
+        return eng
+
+    def _drop_engines(self):
+        # packed weights are a snapshot of the parameters: anything that may change them drops the plans
+        self._engines = {}
+        self._fused = None
+
+    def train(self, mode: bool = True):
+        self._drop_engines()
+        return super().train(mode)
+
+    def _apply(self, fn, *args, **kwargs):
+        self._drop_engines()
+        return super()._apply(fn, *args, **kwargs)
+
+    def load_state_dict(self, *args, **kwargs):
+        self._drop_engines()
+        return super().load_state_dict(*args, **kwargs)
+
     @MODEL_TIMER
     def pure_model_forward(self, x: torch.Tensor):
+        eng = self._engine_for(x)
+        if eng is not None:
+            logits, cat = eng.forward(x)
+            self._fused = (logits, cat)
+            return logits
         features = self.encoder(x)
         mask_logits = self.segmentation_head(self.mask_decoder(*features))
         quat_logits = self.rotation_head(self.rotation_decoder(*features))

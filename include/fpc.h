@@ -19,6 +19,7 @@
  *   fpc_cc_label                 lib/aggregation_layer.py:160-183 (cupyx / scipy ndimage.label)
  *   fpc_aggregate                lib/aggregation_layer.py:61-158
  *   fpc_pose_rt                  lib/gpu_tensor_funcs.py:204-253, 306-326
+ *   fpc_net_*                    lib/pose_regressor.py:709-743 (+ segmentation_models_pytorch encoder/decoder/head)
  * The Python-side bindings a maintainer would add are shown in INTEGRATION.md.
  */
 #ifndef FPC_H_
@@ -122,6 +123,57 @@ int fpc_aggregate(const int32_t* labels, const int64_t* cat_mask,
  * -> R [n,9], T [n,3], RT [n,16]. */
 int fpc_pose_rt(const float* q, const float* xy, const float* z, const float* kinv, int n,
                 float* R, float* T, float* RT, fpc_stream_t stream);
+
+/* ---- backbone engine ----------------------------------------------------------
+ * PoseRegressor.pure_model_forward + Model.class_compression for inference
+ * (lib/pose_regressor.py:709-743, 445-457; encoder / FPN decoder / head graph of
+ * segmentation_models_pytorch as built at :608-666): ResNet-18/34 encoder, four FPN decoders,
+ * four 1x1 heads, x4 bilinear upsample, xyz -> xy/z split, class compression.  f32 throughout
+ * (f32 matrix-core FMAs).  BatchNorm uses running statistics and Dropout2d is the identity
+ * (eval mode).
+ *
+ * fpc_net_create     host-side plan for a fixed (encoder, classes, B, H, W); H, W multiples of 32.
+ * fpc_net_param_*    the parameter tensors the plan needs, by state-dict name (smp naming,
+ *                    e.g. "encoder.layer1.0.conv1.weight", "mask_decoder.p4.skip_conv.bias",
+ *                    "rotation_decoder.seg_blocks.0.block.1.block.1.weight", "scales_head.0.weight"),
+ *                    each a contiguous f32 tensor in torch's own layout (OIHW weights).
+ * fpc_net_load_params  repacks the weights into the workspace (OHWI, padded) and folds BatchNorm.
+ *                    `params[i]` (device, 16-byte aligned) must stay valid and unchanged for as
+ *                    long as the plan is used: GroupNorm / bias / head parameters are read in place.
+ *                    ws: device, 256-byte aligned, >= fpc_net_workspace_bytes(); owned by the caller,
+ *                    must outlive the plan's use; holds packed weights AND activations.
+ * fpc_net_forward    x f32 [B,3,H,W] (NCHW) -> full-resolution logits (NCHW planes; pass all five
+ *                    or all NULL to skip materialising them) and the categorical outputs:
+ *                    logits_mask [B,C,H,W], logits_quat [B,4(C-1),H,W], logits_scales [B,3(C-1),H,W],
+ *                    logits_xy [B,2(C-1),H,W], logits_z [B,(C-1),H,W];
+ *                    cat_mask i64 [B,H,W], cq [B,4,H,W], cs [B,3,H,W], cxy [B,2,H,W], cz [B,H,W]. */
+typedef struct fpc_net fpc_net_t;
+int fpc_net_create(const char* encoder, int classes, int B, int H, int W, fpc_net_t** out);
+void fpc_net_destroy(fpc_net_t* net);
+int fpc_net_param_count(const fpc_net_t* net);
+const char* fpc_net_param_name(const fpc_net_t* net, int i);
+int64_t fpc_net_param_numel(const fpc_net_t* net, int i);
+size_t fpc_net_workspace_bytes(const fpc_net_t* net);
+int fpc_net_load_params(fpc_net_t* net, const float* const* params, int count, void* ws, size_t ws_bytes,
+                        fpc_stream_t stream);
+int fpc_net_forward(fpc_net_t* net, const float* x, float* logits_mask, float* logits_quat,
+                    float* logits_scales, float* logits_xy, float* logits_z, int64_t* cat_mask,
+                    float* cq, float* cs, float* cxy, float* cz, fpc_stream_t stream);
+/* Intermediate activations (NHWC f32 inside the workspace) for tests: "stem", "pool", "c2".."c5",
+ * "d<k>.p5".."d<k>.p2", "d<k>.seg<i>" (pre-GroupNorm conv outputs), "d<k>.low" (low-res logits). */
+int fpc_net_tensor(const fpc_net_t* net, const char* name, const float** ptr, int* H, int* W, int* C);
+
+/* Stand-alone convolution on the engine's implicit-GEMM kernel (tests / micro-benchmarks).
+ * in: any element strides (sb, sh, sw, sc); w_oihw torch layout; out NHWC [B,Ho,Wo,Cout];
+ * optional per-channel scale / shift, residual (as out), nearest-x2 `up` [B,Ho/2,Wo/2,Cout], ReLU,
+ * GroupNorm partials gn_part [B][P32][Cout][2]; bm/bn/nsplit = 0 -> chosen by the planner. */
+size_t fpc_conv2d_workspace_bytes(int B, int Ho, int Wo, int Cin, int Cout, int Kh, int Kw);
+int fpc_conv2d_plan(int B, int Ho, int Wo, int Cin, int Cout, int Kh, int Kw, int bm, int bn, int nsplit,
+                    int* out4 /* bm, bn, nsplit, P32 */);
+int fpc_conv2d(const float* in, int64_t sb, int64_t sh, int64_t sw, int64_t sc, const float* w_oihw,
+               const float* scale, const float* shift, const float* res, const float* up, float* out,
+               float* gn_part, int B, int Hi, int Wi, int Cin, int Cout, int Kh, int Kw, int stride, int pad,
+               int relu, int bm, int bn, int nsplit, void* ws, size_t ws_bytes, fpc_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,234 @@
+"""GPU parity of the backbone engine (fpc_net_*, fpc_conv2d) — floating point, so the bar is the
+north-star tolerance (1e-4 relative to the tensor's scale, fp32) against
+  * torch in float64 on the CPU (small shapes: the tight check), and
+  * the torch-ROCm modules (the path the engine replaces) at full 640x480.
+The conv stack's oracle is torch itself: segmentation_models_pytorch is not vendored in the
+reference, so every op is checked against torch.nn.functional.
+"""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    return torch.device("cuda:0")
+
+
+@pytest.fixture(scope="module")
+def lib(dev):
+    import fastposecnn_amd.lib as L
+    from fastposecnn_amd import _native
+    _native.lib()
+    return L
+
+
+def _conv2d(dev, x_nchw, w, stride, pad, scale=None, shift=None, res=None, up=None, relu=False, gn=False, bm=0, bn=0,
+            nsplit=0, nchw_input=False):
+    """Runs fpc_conv2d; x is given NCHW (CPU), fed as NHWC unless nchw_input. Returns (out NCHW cpu, gn_part)."""
+    from fastposecnn_amd import _native as nat
+    L = nat.lib()
+    B, Cin, Hi, Wi = x_nchw.shape
+    Cout, _, Kh, Kw = w.shape
+    Ho = (Hi + 2 * pad - Kh) // stride + 1
+    Wo = (Wi + 2 * pad - Kw) // stride + 1
+    if nchw_input:
+        xin = x_nchw.contiguous().to(dev)
+        sb, sc, sh, sw = xin.stride()
+    else:
+        xin = x_nchw.permute(0, 2, 3, 1).contiguous().to(dev)
+        sb, sh, sw, sc = xin.stride()
+    wd = w.contiguous().to(dev)
+    out = torch.full((B, Ho, Wo, Cout), float("nan"), device=dev)
+    plan = (ctypes.c_int * 4)()
+    nat.check(L.fpc_conv2d_plan(B, Ho, Wo, Cin, Cout, Kh, Kw, bm, bn, nsplit, plan), "plan")
+    P32 = plan[3]
+    gpart = torch.zeros((B, P32, Cout, 2), device=dev) if gn else None
+    ws = torch.empty(L.fpc_conv2d_workspace_bytes(B, Ho, Wo, Cin, Cout, Kh, Kw), dtype=torch.uint8, device=dev)
+    t = lambda a: None if a is None else a.contiguous().to(dev)
+    scale_d, shift_d = t(scale), t(shift)
+    res_d = None if res is None else res.permute(0, 2, 3, 1).contiguous().to(dev)
+    up_d = None if up is None else up.permute(0, 2, 3, 1).contiguous().to(dev)
+    nat.check(L.fpc_conv2d(xin.data_ptr(), sb, sh, sw, sc, wd.data_ptr(), nat.ptr(scale_d), nat.ptr(shift_d),
+                           nat.ptr(res_d), nat.ptr(up_d), out.data_ptr(), nat.ptr(gpart), B, Hi, Wi, Cin, Cout, Kh, Kw,
+                           stride, pad, int(relu), bm, bn, nsplit, ws.data_ptr(), ws.numel(), nat.stream()), "conv2d")
+    torch.cuda.synchronize()
+    return out.permute(0, 3, 1, 2).cpu(), (None if gpart is None else gpart.cpu()), tuple(plan)
+
+
+def _ref_conv(x, w, stride, pad, scale=None, shift=None, res=None, up=None, relu=False):
+    y = F.conv2d(x.double(), w.double(), stride=stride, padding=pad)
+    if scale is not None:
+        y = y * scale.double().view(1, -1, 1, 1)
+    if shift is not None:
+        y = y + shift.double().view(1, -1, 1, 1)
+    if res is not None:
+        y = y + res.double()
+    if up is not None:
+        y = y + F.interpolate(up.double(), scale_factor=2, mode="nearest")
+    if relu:
+        y = y.relu()
+    return y
+
+
+CONV_CASES = [
+    # B, Cin, Hi, Wi, Cout, k, stride, pad, (bm, bn, nsplit), extras
+    (1, 64, 30, 40, 64, 3, 1, 1, (0, 0, 0), "bn_relu"),
+    (2, 64, 15, 20, 128, 3, 2, 1, (64, 64, 1), "bn_relu_res"),
+    (1, 128, 16, 24, 128, 3, 1, 1, (128, 128, 1), "gn"),
+    (1, 128, 16, 24, 128, 3, 1, 1, (128, 64, 1), "gn"),
+    (1, 128, 16, 24, 128, 3, 1, 1, (64, 128, 1), "gn"),
+    (2, 256, 15, 20, 128, 3, 1, 1, (64, 64, 4), "gn"),          # split-K + GroupNorm partials, ragged M (300)
+    (1, 512, 15, 20, 512, 3, 1, 1, (0, 0, 0), "bn_relu_res"),   # planner picks split-K
+    (2, 64, 24, 32, 256, 1, 1, 0, (0, 0, 0), "bias_up"),        # FPN lateral: 1x1 + bias + nearest-x2 add
+    (1, 64, 24, 32, 128, 1, 2, 0, (0, 0, 0), "bn"),             # downsample 1x1 stride 2
+    (2, 3, 64, 96, 64, 7, 2, 3, (0, 0, 0), "stem"),             # 7x7/2 on the NCHW image (generic loader)
+    (1, 128, 12, 16, 7, 1, 1, 0, (64, 64, 1), "bias"),          # Cout not a multiple of anything
+    (1, 32, 9, 11, 24, 3, 1, 1, (64, 64, 1), "bias_relu"),
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES, ids=lambda c: f"{c[1]}x{c[2]}x{c[3]}-{c[4]}-k{c[5]}s{c[6]}-{c[8]}-{c[9]}")
+def test_conv2d_vs_float64(lib, dev, case):
+    B, Cin, Hi, Wi, Cout, k, stride, pad, (bm, bn, ns), extra = case
+    g = torch.Generator().manual_seed(CONV_CASES.index(case))
+    x = torch.randn((B, Cin, Hi, Wi), generator=g)
+    w = torch.randn((Cout, Cin, k, k), generator=g) / (Cin * k * k) ** 0.5
+    Ho, Wo = (Hi + 2 * pad - k) // stride + 1, (Wi + 2 * pad - k) // stride + 1
+    kw = {}
+    if "bn" in extra:
+        kw["scale"] = torch.rand(Cout, generator=g) + 0.5
+        kw["shift"] = torch.randn(Cout, generator=g)
+    if "bias" in extra:
+        kw["shift"] = torch.randn(Cout, generator=g)
+    if "res" in extra:
+        kw["res"] = torch.randn((B, Cout, Ho, Wo), generator=g)
+    if "up" in extra:
+        kw["up"] = torch.randn((B, Cout, Ho // 2, Wo // 2), generator=g)
+    if "relu" in extra or extra == "stem":
+        kw["relu"] = True
+    if extra == "stem":
+        kw["scale"] = torch.rand(Cout, generator=g) + 0.5
+        kw["shift"] = torch.randn(Cout, generator=g)
+    out, gpart, plan = _conv2d(dev, x, w, stride, pad, gn=("gn" in extra), bm=bm, bn=bn, nsplit=ns,
+                               nchw_input=(extra == "stem"), **kw)
+    ref = _ref_conv(x, w, stride, pad, **kw)
+    assert not torch.isnan(out).any(), "unwritten outputs"
+    err = (out.double() - ref).abs().max().item()
+    assert err <= 2e-5 * max(1.0, ref.abs().max().item()), (err, plan)
+    if gpart is not None:
+        s = gpart.double().sum(1)                                   # [B, Cout, 2] over the row tiles
+        np.testing.assert_allclose(s[..., 0].numpy(), ref.sum((2, 3)).numpy(), rtol=1e-4, atol=1e-3)
+        np.testing.assert_allclose(s[..., 1].numpy(), (ref * ref).sum((2, 3)).numpy(), rtol=1e-4, atol=1e-3)
+
+
+def _model(lib, dev, encoder, seed=0):
+    from fastposecnn_amd import config
+    hp = config.INFERENCE()
+    hp.RUNTIME_TIMING = False
+    hp.ENCODER = encoder
+    hp.PERFORM_AGGREGATION = False
+    torch.manual_seed(seed)
+    m = lib.pose_regressor.MODELS['PoseRegressor'].load_from_ckpt(None, hp)
+    # non-trivial BatchNorm statistics / affine parameters so that folding is exercised
+    g = torch.Generator().manual_seed(seed + 1)
+    for mod in m.modules():
+        if isinstance(mod, torch.nn.BatchNorm2d):
+            mod.running_mean.copy_(torch.randn(mod.num_features, generator=g) * 0.1)
+            mod.running_var.copy_(torch.rand(mod.num_features, generator=g) + 0.5)
+            mod.weight.data.copy_(torch.rand(mod.num_features, generator=g) + 0.5)
+            mod.bias.data.copy_(torch.randn(mod.num_features, generator=g) * 0.1)
+        if isinstance(mod, torch.nn.GroupNorm):
+            mod.weight.data.copy_(torch.rand(mod.num_channels, generator=g) + 0.5)
+            mod.bias.data.copy_(torch.randn(mod.num_channels, generator=g) * 0.1)
+    return m.eval(), hp
+
+
+def _torch_path(m, x):
+    """The torch-module path of the same model (what the engine replaces)."""
+    m.HPARAM.USE_NATIVE_ENGINE = False
+    try:
+        with torch.no_grad():
+            return m.pure_model_forward(x)
+    finally:
+        m.HPARAM.USE_NATIVE_ENGINE = True
+
+
+@pytest.mark.parametrize("encoder,B,H,W", [("resnet18", 2, 64, 96), ("resnet34", 1, 96, 64)])
+def test_net_vs_float64_cpu(lib, dev, encoder, B, H, W):
+    from fastposecnn_amd import synth
+    m, hp = _model(lib, dev, encoder)
+    x = torch.stack([synth.make_image(i, H, W) for i in range(B)])
+    import copy
+    ref_m = copy.deepcopy(m).double()
+    ref_m.HPARAM = copy.copy(hp); ref_m.HPARAM.USE_NATIVE_ENGINE = False
+    with torch.no_grad():
+        ref = ref_m.pure_model_forward(x.double())
+    m = m.to(dev)
+    with torch.no_grad():
+        out = m(x.to(dev))
+    assert m._engines, "the native engine did not run"
+    eng = next(iter(m._engines.values()))
+    # encoder features localise a failure
+    with torch.no_grad():
+        feats = ref_m.encoder(x.double())
+    for name, f in zip(("c2", "c3", "c4", "c5"), feats[2:]):
+        got = eng.tensor(name).permute(0, 3, 1, 2).cpu().double()
+        err = (got - f).abs().max().item()
+        assert err <= 1e-4 * max(1.0, f.abs().max().item()), (name, err)
+    for k in ("mask", "quaternion", "scales", "xy", "z"):
+        got = out["logits"][k].cpu().double()
+        assert got.shape == ref[k].shape, k
+        err = (got - ref[k]).abs().max().item()
+        assert err <= 1e-4 * max(1.0, ref[k].abs().max().item()), (k, err)
+
+
+def test_net_fullsize_vs_torch_modules(lib, dev):
+    """640x480, ResNet18: engine logits vs the torch-ROCm module path; the fused class compression
+    is bit-identical to the stand-alone kernel on the engine's own logits."""
+    import gpu_tensor_funcs as gtf
+    from fastposecnn_amd import synth
+    m, hp = _model(lib, dev, "resnet18")
+    m = m.to(dev)
+    x = synth.make_image(0)[None].to(dev)
+    with torch.no_grad():
+        out = m(x)
+    assert m._engines
+    ref = _torch_path(m, x)
+    for k in ("mask", "quaternion", "scales", "xy", "z"):
+        scale = max(1.0, ref[k].abs().max().item())
+        err = (out["logits"][k] - ref[k]).abs().max().item()
+        assert err <= 2e-4 * scale, (k, err, scale)       # MIOpen's Winograd convs carry their own f32 error
+    cat = gtf.class_compression_fused(7, out["logits"])
+    assert torch.equal(cat["mask"], out["categorical"]["mask"])
+    for k in ("quaternion", "scales", "xy", "z"):
+        assert torch.equal(cat[k], out["categorical"][k]), k
+    # schema of the reference's forward
+    assert set(out) == {"logits", "categorical", "aggregated"} and out["aggregated"] is None
+    assert out["categorical"]["mask"].dtype == torch.int64 and tuple(out["categorical"]["z"].shape) == (1, 480, 640)
+
+
+def test_engine_invalidation(lib, dev):
+    """Packed weights are a snapshot: train()/eval(), load_state_dict and .to() must drop the plan."""
+    from fastposecnn_amd import synth
+    m, hp = _model(lib, dev, "resnet18")
+    m = m.to(dev)
+    x = synth.make_image(1, 64, 64)[None].to(dev)
+    with torch.no_grad():
+        a = m(x)["logits"]["mask"].clone()
+        assert m._engines
+        with torch.no_grad():
+            m.segmentation_head[0].bias.add_(1.0)
+        m.eval()                                              # any train()/eval() call drops the plans
+        assert not m._engines
+        b = m(x)["logits"]["mask"]
+    assert torch.allclose(b, a + 1.0, atol=1e-5)
+    m.train()
+    out = m(x)                                                # training mode: torch modules, autograd works
+    assert not m._engines and out["logits"]["mask"].requires_grad

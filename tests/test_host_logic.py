@@ -1,0 +1,169 @@
+"""CPU-side checks (no GPU, no compute calls into the HIP library):
+  * libfpc_hip.so loads and exports every symbol include/fpc.h declares;
+  * the engine's parameter table matches the drop-in model's state dict (smp naming);
+  * the convolution planner returns valid tilings;
+  * host logic: eps-threshold equivalence used by the kernels, pose-record packing,
+    image sharding, and the world-size-2 all-gather of pose records over gloo.
+"""
+import ctypes
+import os
+import re
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def hiplib():
+    from fastposecnn_amd import build, _native
+    build.build()
+    return _native.lib()
+
+
+def test_abi_exports_every_declared_symbol(hiplib):
+    from fastposecnn_amd import _native
+    hdr = open(os.path.join(REPO, "include", "fpc.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(fpc_[a-z0-9_]+)\s*\(", hdr))
+    assert len(declared) >= 25
+    raw = ctypes.CDLL(_native.LIB_PATH)
+    for name in sorted(declared):
+        assert hasattr(raw, name), f"{name} is declared in include/fpc.h but not exported"
+    assert declared == set(_native.EXPORTED), declared ^ set(_native.EXPORTED)
+    assert hiplib.fpc_abi_version() == 1
+    assert hiplib.fpc_error_string(-2).decode().startswith("workspace")
+
+
+def test_missing_library_fails_loudly(monkeypatch):
+    from fastposecnn_amd import _native
+    monkeypatch.setattr(_native, "_lib", None)
+    monkeypatch.setattr(_native, "LIB_PATH", "/nonexistent/libfpc_hip.so")
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        _native.lib()
+
+
+def test_cpu_tensors_are_refused():
+    import fastposecnn_amd.lib  # noqa: F401
+    import aggregation_layer as al
+    import ransac_voting_gpu_layer.ransac_voting_gpu as rvg
+    with pytest.raises(RuntimeError):
+        rvg.ransac_voting_layer_v3(torch.zeros((1, 8, 8)), torch.zeros((1, 8, 8, 1, 2)), 16)
+    with pytest.raises(RuntimeError):
+        al.AggregationLayer(None, 7).forward({"mask": torch.zeros((1, 8, 8), dtype=torch.int64)})
+
+
+def test_eps_threshold_equivalence():
+    """(double)x < 1e-6  <=>  x <= float32(1e-6) for every float x (common.hpp: below_eps)."""
+    f = np.float32(1e-6)
+    assert float(f) < 1e-6 < float(np.nextafter(f, np.float32(1)))
+    for x in (np.nextafter(f, np.float32(0)), f, np.nextafter(f, np.float32(1)), np.float32(0), np.float32(1e-7)):
+        assert (float(x) < 1e-6) == bool(x <= f)
+
+
+@pytest.mark.parametrize("encoder", ["resnet18", "resnet34"])
+def test_engine_param_table_matches_state_dict(hiplib, encoder):
+    import fastposecnn_amd.lib as L
+    from fastposecnn_amd import config
+    hp = config.INFERENCE()
+    hp.ENCODER = encoder
+    m = L.pose_regressor.MODELS['PoseRegressor'].load_from_ckpt(None, hp)
+    sd = dict(m.named_parameters())
+    sd.update(dict(m.named_buffers()))
+    h = ctypes.c_void_p()
+    assert hiplib.fpc_net_create(encoder.encode(), 7, 2, 480, 640, ctypes.byref(h)) == 0
+    try:
+        n = hiplib.fpc_net_param_count(h)
+        names = [hiplib.fpc_net_param_name(h, i).decode() for i in range(n)]
+        assert len(set(names)) == n
+        for i, name in enumerate(names):
+            assert name in sd, name
+            assert sd[name].numel() == hiplib.fpc_net_param_numel(h, i), name
+        unused = [k for k in sd if k not in set(names) and not k.endswith("num_batches_tracked")]
+        assert unused == []
+        assert hiplib.fpc_net_workspace_bytes(h) > 0
+        # forward before load_params is refused, not a crash
+        assert hiplib.fpc_net_forward(h, *([None] * 11), None) == -1
+    finally:
+        hiplib.fpc_net_destroy(h)
+    assert hiplib.fpc_net_create(b"resnet50", 7, 1, 480, 640, ctypes.byref(h)) == -1
+    assert hiplib.fpc_net_create(b"resnet18", 7, 1, 481, 640, ctypes.byref(h)) == -1
+
+
+def test_conv_planner_is_valid(hiplib):
+    out = (ctypes.c_int * 4)()
+    for B, Ho, Wo, Cin, Cout, k in [(1, 120, 160, 256, 128, 3), (1, 15, 20, 512, 512, 3), (32, 15, 20, 512, 512, 3),
+                                    (1, 240, 320, 3, 64, 7), (1, 120, 160, 128, 7, 1), (2, 30, 40, 256, 256, 1)]:
+        assert hiplib.fpc_conv2d_plan(B, Ho, Wo, Cin, Cout, k, k, 0, 0, 0, out) == 0
+        bm, bn, ns, p32 = out
+        ksteps = -(-Cin * k * k // 32)
+        assert bm in (64, 128) and bn in (64, 128) and 1 <= ns <= 32
+        per = -(-ksteps // ns)
+        assert (ns - 1) * per < ksteps                      # no empty split
+        assert p32 == -(-Ho * Wo // bm) * bm // 32
+        if Cout % 4:
+            assert ns == 1
+
+
+def test_pose_record_roundtrip_and_sharding():
+    from fastposecnn_amd import parallel
+    assert [list(parallel.shard_indices(10, r, 4)) for r in range(4)] == [[0, 1, 2], [3, 4, 5], [6, 7], [8, 9]]
+    g = torch.Generator().manual_seed(0)
+    n = 5
+    agg = {"sample_ids": torch.arange(n), "class_ids": torch.randint(1, 7, (n,), generator=g),
+           "quaternion": torch.randn(n, 4, generator=g), "scales": torch.randn(n, 3, generator=g),
+           "xy": torch.randn(n, 2, generator=g), "z": torch.randn(n, 1, generator=g),
+           "R": torch.randn(n, 3, 3, generator=g), "T": torch.randn(n, 3, generator=g), "RT": torch.randn(n, 4, 4, generator=g)}
+    buf = parallel.pack_pose_records(agg, sample_offset=32, capacity=8)
+    assert tuple(buf.shape) == (9, parallel.RECORD_WIDTH)
+    out = parallel.unpack_pose_records(buf[None])
+    assert torch.equal(out["sample_ids"], agg["sample_ids"] + 32) and torch.equal(out["class_ids"], agg["class_ids"])
+    for k in ("quaternion", "scales", "xy", "z", "R", "T", "RT"):
+        assert torch.equal(out[k].reshape(agg[k].shape), agg[k]), k
+    with pytest.raises(RuntimeError):
+        parallel.pack_pose_records(agg, 0, capacity=4)
+
+
+def _gloo_worker(rank, world, port, q):
+    import torch.distributed as dist
+    sys.path.insert(0, REPO)
+    from fastposecnn_amd import parallel
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    n = 2 + rank                                             # ragged instance counts
+    g = torch.Generator().manual_seed(100 + rank)
+    imgs = parallel.shard_indices(6, rank, world)
+    agg = {"sample_ids": torch.randint(0, len(imgs), (n,), generator=g), "class_ids": torch.full((n,), rank + 1),
+           "quaternion": torch.randn(n, 4, generator=g), "scales": torch.randn(n, 3, generator=g),
+           "xy": torch.randn(n, 2, generator=g), "z": torch.randn(n, 1, generator=g),
+           "R": torch.randn(n, 3, 3, generator=g), "T": torch.randn(n, 3, generator=g), "RT": torch.randn(n, 4, 4, generator=g)}
+    gathered = parallel.all_gather_pose_records(agg, imgs[0], capacity=4)
+    out = parallel.unpack_pose_records(gathered)
+    q.put((rank, out["class_ids"].tolist(), out["sample_ids"].tolist(), float(out["RT"].sum()),
+           (agg["sample_ids"] + imgs[0]).tolist(), float(agg["RT"].sum())))
+    dist.destroy_process_group()
+
+
+def test_all_gather_pose_records_gloo_world2():
+    import torch.multiprocessing as mp
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_gloo_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    # both ranks see the same concatenation, in rank order, with globally offset sample ids
+    assert res[0][1] == res[1][1] == [1, 1, 2, 2, 2]
+    assert res[0][2] == res[1][2] == res[0][4] + res[1][4]
+    assert abs(res[0][3] - (res[0][5] + res[1][5])) < 1e-4 and abs(res[0][3] - res[1][3]) < 1e-6
