@@ -23,7 +23,7 @@
 namespace fpc {
 
 struct PackedConv {
-    int Cin = 0, Cout = 0, Kh = 1, Kw = 1, stride = 1, pad = 0;
+    int Cin = 0, Cinp = 0, Cout = 0, Kh = 1, Kw = 1, stride = 1, pad = 0;   // Cinp: channels of the input LAYOUT
     int K = 0, Kpad = 0, Npad = 0;
     int p_w = -1;            // parameter index of the OIHW weight
     int p_bn = -1;           // first of (weight, bias, running_mean, running_var) or -1
@@ -61,6 +61,29 @@ static ConvPlan plan_conv(int HoWo, int B, int Cout, int ksteps, int groups, int
     return best;
 }
 
+// Tilings the autotuner may try for one convolution site (the heuristic plan is always among them).
+static std::vector<ConvPlan> conv_candidates(int HoWo, int B, int Cout, int ksteps, int groups) {
+    std::vector<ConvPlan> out;
+    const int splits[] = {1, 2, 3, 4, 6, 8, 12, 16, 24};
+    for (int bm = 64; bm <= 128; bm += 64)
+        for (int bn = 64; bn <= 128; bn += 64) {
+            if (bn == 128 && Cout <= 64) continue;
+            int mt = cdiv(HoWo, bm), nt = cdiv(Cout, bn);
+            long long base = (long long)groups * B * mt * nt;
+            for (int ns : splits) {
+                int per = cdiv(ksteps, ns);
+                if (ns > 1 && (per < 2 || (ns - 1) * per >= ksteps || Cout % 4 != 0)) continue;
+                if (ns > 1 && base * ns > 4096) continue;          // already plenty of workgroups
+                out.push_back(ConvPlan{bm, bn, ns, mt, nt});
+            }
+        }
+    return out;
+}
+
+static size_t splitk_floats_for(const ConvPlan& p, int groups, int B, int Npad) {
+    return p.nsplit > 1 ? (size_t)groups * p.nsplit * B * p.mtiles * p.bm * Npad : 0;
+}
+
 }  // namespace fpc
 
 using namespace fpc;
@@ -77,6 +100,8 @@ struct fpc_net {
     size_t total_floats = 0;      // + activations and scratch
     float* ws = nullptr;
     bool loaded = false;
+    bool tuning = false;          // next forward times every candidate tiling per conv site and keeps the best
+    bool tuned = false;
 
     // conv indices
     int c_stem = -1;
@@ -91,7 +116,7 @@ struct fpc_net {
     } dec[4];
 
     // activations (float offsets)
-    Act a_stem, a_pool;
+    Act a_img4, a_stem, a_pool;
     std::vector<Act> a_blk_t[4], a_blk_y[4], a_blk_d[4];
     Act a_p[4][4];                // [decoder][p5,p4,p3,p2]
     Act a_seg[4][7];              // pre-GroupNorm conv outputs
@@ -110,10 +135,10 @@ struct fpc_net {
     int add_param(const std::string& n, int64_t numel) { pnames.push_back(n); pnumel.push_back(numel); return (int)pnames.size() - 1; }
 
     int add_conv(const std::string& wname, int Cin, int Cout, int k, int stride, int pad, const char* bn_prefix,
-                 const char* bias_name) {
+                 const char* bias_name, int Cinp = 0) {
         PackedConv c;
-        c.Cin = Cin; c.Cout = Cout; c.Kh = c.Kw = k; c.stride = stride; c.pad = pad;
-        c.K = Cin * k * k; c.Kpad = cdiv(c.K, kConvBK) * kConvBK; c.Npad = cdiv(Cout, kConvNAlign) * kConvNAlign;
+        c.Cin = Cin; c.Cinp = Cinp ? Cinp : Cin; c.Cout = Cout; c.Kh = c.Kw = k; c.stride = stride; c.pad = pad;
+        c.K = c.Cinp * k * k; c.Kpad = cdiv(c.K, kConvBK) * kConvBK; c.Npad = cdiv(Cout, kConvNAlign) * kConvNAlign;
         c.p_w = add_param(wname, (int64_t)Cout * Cin * k * k);
         if (bn_prefix) {
             std::string p(bn_prefix);
@@ -145,7 +170,7 @@ extern "C" int fpc_net_create(const char* encoder, int classes, int B, int H, in
     char buf[256];
 
     // ---- parameters + packed storage (persistent region first)
-    n->c_stem = n->add_conv("encoder.conv1.weight", 3, 64, 7, 2, 3, "encoder.bn1", nullptr);
+    n->c_stem = n->add_conv("encoder.conv1.weight", 3, 64, 7, 2, 3, "encoder.bn1", nullptr, 4);
     const int planes[4] = {64, 128, 256, 512};
     int inpl = 64;
     for (int L = 0; L < 4; ++L)
@@ -197,6 +222,7 @@ extern "C" int fpc_net_create(const char* encoder, int classes, int B, int H, in
 
     // ---- activations
     int h1 = conv_out(H, 7, 2, 3), w1 = conv_out(W, 7, 2, 3);
+    n->a_img4 = n->alloc_act(H, W, 4);
     n->a_stem = n->alloc_act(h1, w1, 64);
     int hp = conv_out(h1, 3, 2, 1), wp = conv_out(w1, 3, 2, 1);
     n->a_pool = n->alloc_act(hp, wp, 64);
@@ -227,16 +253,17 @@ extern "C" int fpc_net_create(const char* encoder, int classes, int B, int H, in
         n->a_low[d] = n->alloc_act(fh[0], fw[0], n->dec[d].head_chp);
     }
 
-    // ---- conv plans (+ split-K scratch, GroupNorm partials)
+    // ---- conv plans (+ split-K scratch for the worst candidate, GroupNorm partials for the largest P32)
     n->cplan.resize(n->convs.size());
     auto plan = [&](int ci, int HoWo, int groups) {
         const PackedConv& c = n->convs[ci];
-        ConvPlan p = plan_conv(HoWo, B, c.Cout, c.Kpad / kConvBK, groups);
-        n->cplan[ci] = p;
-        if (p.nsplit > 1) {
-            size_t need = (size_t)groups * p.nsplit * B * p.mtiles * p.bm * c.Npad;
-            if (need > n->splitk_floats) n->splitk_floats = need;
+        n->cplan[ci] = plan_conv(HoWo, B, c.Cout, c.Kpad / kConvBK, groups);
+        size_t need = splitk_floats_for(n->cplan[ci], groups, B, c.Npad);
+        for (const ConvPlan& q : conv_candidates(HoWo, B, c.Cout, c.Kpad / kConvBK, groups)) {
+            size_t f = splitk_floats_for(q, groups, B, c.Npad);
+            if (f * sizeof(float) <= ((size_t)256 << 20) && f > need) need = f;
         }
+        if (need > n->splitk_floats) n->splitk_floats = need;
     };
     plan(n->c_stem, h1 * w1, 1);
     for (int L = 0; L < 4; ++L)
@@ -247,9 +274,9 @@ extern "C" int fpc_net_create(const char* encoder, int classes, int B, int H, in
         }
     for (int i = 0; i < 4; ++i) plan(n->dec[0].lat[i], fh[3 - i] * fw[3 - i], 4);
     for (int i = 0; i < 7; ++i) {
-        plan(n->dec[0].seg[i], fh[seg_level[i]] * fw[seg_level[i]], 4);
-        const ConvPlan& p = n->cplan[n->dec[0].seg[i]];
-        n->gn_P[i] = p.mtiles * p.bm / 32;
+        int HoWo = fh[seg_level[i]] * fw[seg_level[i]];
+        plan(n->dec[0].seg[i], HoWo, 4);
+        n->gn_P[i] = cdiv(HoWo, 128) * 4;      // upper bound of mtiles*bm/32 over the tilings
         for (int d = 0; d < 4; ++d) {
             n->gn_part_off[d][i] = n->alloc((size_t)B * n->gn_P[i] * 128 * 2);
             n->gn_aff_off[d][i] = n->alloc((size_t)B * 128 * 2);
@@ -282,7 +309,7 @@ extern "C" int fpc_net_load_params(fpc_net_t* n, const float* const* params, int
     n->ws = (float*)ws;
     n->pptr.assign(params, params + count);
     for (const PackedConv& c : n->convs) {
-        int rc = launch_pack_weight(n->pptr[c.p_w], n->ws + c.w_off, c.Cout, c.Cin, c.Kh, c.Kw, c.Npad, c.Kpad, s);
+        int rc = launch_pack_weight(n->pptr[c.p_w], n->ws + c.w_off, c.Cout, c.Cin, c.Cinp, c.Kh, c.Kw, c.Npad, c.Kpad, s);
         if (rc) return rc;
         if (c.p_bn >= 0) {
             rc = launch_fold_bn(n->pptr[c.p_bn], n->pptr[c.p_bn + 1], n->pptr[c.p_bn + 2], n->pptr[c.p_bn + 3], 1e-5f,
@@ -304,21 +331,55 @@ struct ConvIO {
 
 // fills the shared part of ConvArgs from conv `c` + plan `p`
 void fill_conv_args(const fpc_net* n, ConvArgs& a, const PackedConv& c, const ConvPlan& p, int Hi, int Wi, int Ho,
-                    int Wo, long long sb, long long sh, long long sw, long long sc, bool relu, bool generic) {
+                    int Wo, long long sb, long long sh, long long sw, long long sc, bool relu, int mode) {
     memset(&a, 0, sizeof(a));
     a.B = n->B; a.Hi = Hi; a.Wi = Wi; a.Cin = c.Cin; a.Ho = Ho; a.Wo = Wo; a.Cout = c.Cout; a.Npad = c.Npad;
     a.Kh = c.Kh; a.Kw = c.Kw; a.stride = c.stride; a.pad = c.pad; a.K = c.K; a.Kpad = c.Kpad;
     a.in_sb = sb; a.in_sh = sh; a.in_sw = sw; a.in_sc = sc;
     a.relu = relu ? 1 : 0; a.nsplit = p.nsplit; a.mtiles = p.mtiles; a.ntiles = p.ntiles; a.ksteps = c.Kpad / kConvBK;
-    a.bm = p.bm; a.bn = p.bn; a.generic = generic ? 1 : 0;
+    a.bm = p.bm; a.bn = p.bn; a.generic = mode;
     a.splitk_ws = n->ws + n->splitk_off;
 }
 
-int run_conv(const ConvArgs& a, int groups, hipStream_t s) {
+int launch_conv_plan(ConvArgs& a, const ConvPlan& p, int groups, hipStream_t s) {
+    a.bm = p.bm; a.bn = p.bn; a.nsplit = p.nsplit; a.mtiles = p.mtiles; a.ntiles = p.ntiles;
     int rc = launch_conv(a, groups, s);
     if (rc) return rc;
     if (a.nsplit > 1) rc = launch_conv_splitk_epilogue(a, groups, s);
     return rc;
+}
+
+// Runs conv site `ci` with its current plan; in tuning mode first times every candidate tiling
+// (HIP events on the stream, synchronising — only ever inside fpc_net_autotune) and keeps the fastest.
+int run_conv(fpc_net* n, ConvArgs& a, int groups, int ci, hipStream_t s) {
+    if (n && n->tuning) {
+        hipEvent_t e0, e1;
+        if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return FPC_ELAUNCH;
+        float best_ms = 1e30f;
+        ConvPlan best = n->cplan[ci];
+        size_t cap = n->splitk_floats;
+        for (const ConvPlan& q : conv_candidates(a.Ho * a.Wo, a.B, a.Cout, a.ksteps, groups)) {
+            if (splitk_floats_for(q, groups, a.B, a.Npad) > cap) continue;
+            int rc = launch_conv_plan(a, q, groups, s);     // warm-up (also validates the launch)
+            if (rc) { hipEventDestroy(e0); hipEventDestroy(e1); return rc; }
+            float ms = 1e30f;
+            for (int rep = 0; rep < 2; ++rep) {
+                hipEventRecord(e0, s);
+                launch_conv_plan(a, q, groups, s);
+                hipEventRecord(e1, s);
+                hipEventSynchronize(e1);
+                float t = 0.f;
+                hipEventElapsedTime(&t, e0, e1);
+                if (t < ms) ms = t;
+            }
+            if (ms < best_ms) { best_ms = ms; best = q; }
+        }
+        hipEventDestroy(e0);
+        hipEventDestroy(e1);
+        n->cplan[ci] = best;
+    }
+    const ConvPlan& p = n ? n->cplan[ci] : ConvPlan{a.bm, a.bn, a.nsplit, a.mtiles, a.ntiles};
+    return launch_conv_plan(a, p, groups, s);
 }
 
 }  // namespace
@@ -340,13 +401,15 @@ extern "C" int fpc_net_forward(fpc_net_t* n, const float* x, float* logits_mask,
         sc = 1; sw = t.C; sh = (long long)t.W * t.C; sb = (long long)t.H * sh;
     };
 
-    // stem: 7x7/2 on the NCHW image, BN + ReLU in the epilogue
+    // stem: image -> NHWC4 (16-byte pixels), 7x7/2 with BN + ReLU in the epilogue
+    FPC_TRY(launch_nchw3_to_nhwc4(x, ws + n->a_img4.off, B, H * W, s));
     {
         const PackedConv& c = n->convs[n->c_stem];
-        fill_conv_args(n, a, c, n->cplan[n->c_stem], H, W, n->a_stem.H, n->a_stem.W, (long long)3 * H * W, W, 1,
-                       (long long)H * W, true, true);
-        a.p[0] = ConvPtrs{x, ws + c.w_off, ws + n->a_stem.off, ws + c.scale_off, ws + c.shift_off, nullptr, nullptr, nullptr};
-        FPC_TRY(run_conv(a, 1, s));
+        fill_conv_args(n, a, c, n->cplan[n->c_stem], H, W, n->a_stem.H, n->a_stem.W, (long long)4 * H * W, (long long)4 * W, 4,
+                       1, true, 2);
+        a.Cin = c.Cinp;
+        a.p[0] = ConvPtrs{ws + n->a_img4.off, ws + c.w_off, ws + n->a_stem.off, ws + c.scale_off, ws + c.shift_off, nullptr, nullptr, nullptr};
+        FPC_TRY(run_conv(n, a, 1, n->c_stem, s));
     }
     FPC_TRY(launch_maxpool3x3s2(ws + n->a_stem.off, ws + n->a_pool.off, B, n->a_stem.H, n->a_stem.W, 64, n->a_pool.H,
                                 n->a_pool.W, s));
@@ -361,23 +424,23 @@ extern "C" int fpc_net_forward(fpc_net_t* n, const float* x, float* logits_mask,
             long long sb, sh, sw, sc;
             nhwc(cur, sb, sh, sw, sc);
             const PackedConv& c1 = n->convs[blk.conv1];
-            fill_conv_args(n, a, c1, n->cplan[blk.conv1], cur.H, cur.W, T.H, T.W, sb, sh, sw, sc, true, false);
+            fill_conv_args(n, a, c1, n->cplan[blk.conv1], cur.H, cur.W, T.H, T.W, sb, sh, sw, sc, true, 0);
             a.p[0] = ConvPtrs{ws + cur.off, ws + c1.w_off, ws + T.off, ws + c1.scale_off, ws + c1.shift_off, nullptr, nullptr, nullptr};
-            FPC_TRY(run_conv(a, 1, s));
+            FPC_TRY(run_conv(n, a, 1, blk.conv1, s));
             const float* res = ws + cur.off;
             if (blk.ds >= 0) {
                 const PackedConv& cd = n->convs[blk.ds];
                 const Act& D = n->a_blk_d[L][bi];
-                fill_conv_args(n, a, cd, n->cplan[blk.ds], cur.H, cur.W, D.H, D.W, sb, sh, sw, sc, false, false);
+                fill_conv_args(n, a, cd, n->cplan[blk.ds], cur.H, cur.W, D.H, D.W, sb, sh, sw, sc, false, 0);
                 a.p[0] = ConvPtrs{ws + cur.off, ws + cd.w_off, ws + D.off, ws + cd.scale_off, ws + cd.shift_off, nullptr, nullptr, nullptr};
-                FPC_TRY(run_conv(a, 1, s));
+                FPC_TRY(run_conv(n, a, 1, blk.ds, s));
                 res = ws + D.off;
             }
             nhwc(T, sb, sh, sw, sc);
             const PackedConv& c2 = n->convs[blk.conv2];
-            fill_conv_args(n, a, c2, n->cplan[blk.conv2], T.H, T.W, Y.H, Y.W, sb, sh, sw, sc, true, false);
+            fill_conv_args(n, a, c2, n->cplan[blk.conv2], T.H, T.W, Y.H, Y.W, sb, sh, sw, sc, true, 0);
             a.p[0] = ConvPtrs{ws + T.off, ws + c2.w_off, ws + Y.off, ws + c2.scale_off, ws + c2.shift_off, res, nullptr, nullptr};
-            FPC_TRY(run_conv(a, 1, s));
+            FPC_TRY(run_conv(n, a, 1, blk.conv2, s));
             cur = Y;
         }
         feat[L] = cur;
@@ -390,13 +453,13 @@ extern "C" int fpc_net_forward(fpc_net_t* n, const float* x, float* logits_mask,
         long long sb, sh, sw, sc;
         nhwc(src, sb, sh, sw, sc);
         int ci0 = n->dec[0].lat[i];
-        fill_conv_args(n, a, n->convs[ci0], n->cplan[ci0], src.H, src.W, src.H, src.W, sb, sh, sw, sc, false, false);
+        fill_conv_args(n, a, n->convs[ci0], n->cplan[ci0], src.H, src.W, src.H, src.W, sb, sh, sw, sc, false, 0);
         for (int d = 0; d < 4; ++d) {
             const PackedConv& c = n->convs[n->dec[d].lat[i]];
             a.p[d] = ConvPtrs{ws + src.off, ws + c.w_off, ws + n->a_p[d][i].off, nullptr, n->pptr[c.p_bias], nullptr,
                               i > 0 ? ws + n->a_p[d][i - 1].off : nullptr, nullptr};
         }
-        FPC_TRY(run_conv(a, 4, s));
+        FPC_TRY(run_conv(n, a, 4, ci0, s));
     }
     // segmentation blocks
     auto seg_conv = [&](int si, int which) -> int {
@@ -406,14 +469,14 @@ extern "C" int fpc_net_forward(fpc_net_t* n, const float* x, float* logits_mask,
         long long sb, sh, sw, sc;
         nhwc(in0, sb, sh, sw, sc);
         const Act& o0 = n->a_seg[0][si];
-        fill_conv_args(n, a, n->convs[ci0], n->cplan[ci0], in0.H, in0.W, o0.H, o0.W, sb, sh, sw, sc, false, false);
+        fill_conv_args(n, a, n->convs[ci0], n->cplan[ci0], in0.H, in0.W, o0.H, o0.W, sb, sh, sw, sc, false, 0);
         for (int d = 0; d < 4; ++d) {
             const PackedConv& c = n->convs[n->dec[d].seg[si]];
             const Act& in = which < 0 ? n->a_p[d][-which - 1] : n->a_up[d][which];
             a.p[d] = ConvPtrs{ws + in.off, ws + c.w_off, ws + n->a_seg[d][si].off, nullptr, nullptr, nullptr, nullptr,
                               ws + n->gn_part_off[d][si]};
         }
-        int rc = run_conv(a, 4, s);
+        int rc = run_conv(n, a, 4, ci0, s);
         if (rc) return rc;
         GnFinArgs g;
         memset(&g, 0, sizeof(g));
@@ -423,7 +486,7 @@ extern "C" int fpc_net_forward(fpc_net_t* n, const float* x, float* logits_mask,
             g.beta[d] = n->pptr[n->dec[d].p_gn[si] + 1];
             g.affine[d] = ws + n->gn_aff_off[d][si];
         }
-        g.B = B; g.P = n->gn_P[si]; g.C = 128; g.groups = 32; g.count = (long long)o0.H * o0.W * 4; g.eps = 1e-5f;
+        g.B = B; g.P = n->cplan[ci0].mtiles * n->cplan[ci0].bm / 32; g.C = 128; g.groups = 32; g.count = (long long)o0.H * o0.W * 4; g.eps = 1e-5f;
         return launch_gn_finalize(g, 4, s);
     };
     auto gn_up = [&](int si, int ui) -> int {
@@ -480,6 +543,24 @@ extern "C" int fpc_net_forward(fpc_net_t* n, const float* x, float* logits_mask,
         if (u.hl * 4 != H || u.wl * 4 != W) return FPC_EINVAL;
         FPC_TRY(launch_up4_compress(u, s));
     }
+    if (n->tuning) { n->tuning = false; n->tuned = true; }
+    return FPC_OK;
+}
+
+// The NEXT fpc_net_forward times every candidate tiling of every convolution site on the device
+// (it synchronises the stream; not capturable) and keeps the fastest; later forwards reuse the plans.
+extern "C" int fpc_net_autotune_next(fpc_net_t* n) {
+    if (!n || !n->loaded) return FPC_EINVAL;
+    n->tuning = true;
+    return FPC_OK;
+}
+
+// Chosen tiling of convolution site `i` (0 <= i < fpc_net_conv_count): out5 = bm, bn, nsplit, Cout, K.
+extern "C" int fpc_net_conv_count(const fpc_net_t* n) { return n ? (int)n->convs.size() : 0; }
+extern "C" int fpc_net_conv_plan(const fpc_net_t* n, int i, int* out5) {
+    if (!n || !out5 || i < 0 || i >= (int)n->convs.size()) return FPC_EINVAL;
+    out5[0] = n->cplan[i].bm; out5[1] = n->cplan[i].bn; out5[2] = n->cplan[i].nsplit;
+    out5[3] = n->convs[i].Cout; out5[4] = n->convs[i].K;
     return FPC_OK;
 }
 
@@ -530,19 +611,20 @@ extern "C" int fpc_conv2d(const float* in, int64_t sb, int64_t sh, int64_t sw, i
     if (Ho < 1 || Wo < 1) return FPC_EINVAL;
     if (ws_bytes < fpc_conv2d_workspace_bytes(B, Ho, Wo, Cin, Cout, Kh, Kw) || ((uintptr_t)ws & 255)) return FPC_EWORKSPACE;
     PackedConv c;
-    c.Cin = Cin; c.Cout = Cout; c.Kh = Kh; c.Kw = Kw; c.stride = stride; c.pad = pad;
+    c.Cin = c.Cinp = Cin; c.Cout = Cout; c.Kh = Kh; c.Kw = Kw; c.stride = stride; c.pad = pad;
     c.K = Cin * Kh * Kw; c.Kpad = cdiv(c.K, kConvBK) * kConvBK; c.Npad = cdiv(Cout, kConvNAlign) * kConvNAlign;
     hipStream_t s = (hipStream_t)stream;
     float* packed = (float*)ws;
-    FPC_TRY(launch_pack_weight(w_oihw, packed, Cout, Cin, Kh, Kw, c.Npad, c.Kpad, s));
+    FPC_TRY(launch_pack_weight(w_oihw, packed, Cout, Cin, Cin, Kh, Kw, c.Npad, c.Kpad, s));
     ConvPlan p = plan_conv(Ho * Wo, B, Cout, c.Kpad / kConvBK, 1, bm, bn, nsplit);
-    bool generic = (Cin % kConvBK != 0) || sc != 1;
+    int mode = (sc == 1 && Cin % kConvBK == 0) ? 0
+               : (sc == 1 && Cin % 4 == 0 && sw % 4 == 0 && sh % 4 == 0 && sb % 4 == 0 && ((uintptr_t)in & 15) == 0) ? 2 : 1;
     fpc_net tmp;
     tmp.B = B;
     tmp.ws = packed;
     tmp.splitk_off = ((size_t)c.Npad * c.Kpad + 63) / 64 * 64;
     ConvArgs a;
-    fill_conv_args(&tmp, a, c, p, Hi, Wi, Ho, Wo, sb, sh, sw, sc, relu != 0, generic);
+    fill_conv_args(&tmp, a, c, p, Hi, Wi, Ho, Wo, sb, sh, sw, sc, relu != 0, mode);
     a.p[0] = ConvPtrs{in, packed, out, scale, shift, res, up, gn_part};
-    return run_conv(a, 1, s);
+    return run_conv(nullptr, a, 1, 0, s);
 }

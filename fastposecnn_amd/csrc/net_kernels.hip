@@ -38,12 +38,12 @@ __device__ __forceinline__ int xcd_swizzle(int bid, int nwg) {
 // One K-step of operands, global -> registers.  Thread (sr, sq) owns rows sr + 32*i and the float4 at
 // column 4*sq of the 32-wide K-step.  (Macros, not functions: hipcc keeps by-reference register
 // arrays in scratch.)
-#define FPC_CONV_LOAD(KS)                                                                                     \
+#define FPC_CONV_LOAD(KS, ra, rb)                                                                                     \
     do {                                                                                                      \
         const int ks_ = (KS);                                                                                 \
         _Pragma("unroll") for (int i = 0; i < BR; ++i) rb[i] =                                                \
             *reinterpret_cast<const f32x4*>(wrow[i] + ks_ * kConvBK);                                        \
-        if (!GENERIC) {                                                                                       \
+        if (MODE == 0) {                                                                                      \
             int k0 = ks_ * kConvBK;                                                                           \
             int tap = k0 / Cin, c0 = k0 - tap * Cin;                                                          \
             int kh = tap / Kw, kw = tap - kh * Kw;                                                            \
@@ -54,8 +54,22 @@ __device__ __forceinline__ int xcd_swizzle(int bid, int nwg) {
                 ra[i] = ok ? *reinterpret_cast<const f32x4*>(P.in + a_off[i] + koff)                         \
                            : f32x4{0.f, 0.f, 0.f, 0.f};                                                 \
             }                                                                                                 \
+        } else if (MODE == 2) {                                                                               \
+            /* Cin % 4 == 0, channel-last: this lane's float4 is 4 channels of ONE tap (the 7x7 stem on */   \
+            /* the NHWC4 image: 8 taps per K-step)                                                       */   \
+            int kq = ks_ * kConvBK + 4 * sq;                                                                  \
+            bool kv = kq < K;                                                                                 \
+            int tap = kq / Cin, c0 = kq - tap * Cin;                                                          \
+            int kh = tap / Kw, kw = tap - kh * Kw;                                                            \
+            long long koff = (long long)kh * in_sh + (long long)kw * in_sw + c0;                              \
+            _Pragma("unroll") for (int i = 0; i < AR; ++i) {                                                  \
+                int hi = a_hi0[i] + kh, wi = a_wi0[i] + kw;                                                   \
+                bool ok = kv && hi >= 0 && hi < Hi && wi >= 0 && wi < Wi;                                     \
+                ra[i] = ok ? *reinterpret_cast<const f32x4*>(P.in + a_off[i] + koff)                          \
+                           : f32x4{0.f, 0.f, 0.f, 0.f};                                                       \
+            }                                                                                                 \
         } else {                                                                                              \
-            /* any Cin / any input strides (the 7x7 stem reads the NCHW image directly) */                    \
+            /* any Cin / any input strides */                                                                 \
             _Pragma("unroll") for (int i = 0; i < AR; ++i) ra[i] = f32x4{0.f, 0.f, 0.f, 0.f};           \
             _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                                   \
                 int k = ks_ * kConvBK + 4 * sq + e;                                                           \
@@ -76,7 +90,7 @@ __device__ __forceinline__ int xcd_swizzle(int bid, int nwg) {
         }                                                                                                     \
     } while (0)
 
-#define FPC_CONV_STORE(BUF)                                                                                   \
+#define FPC_CONV_STORE(BUF, ra, rb)                                                                           \
     do {                                                                                                      \
         float* As_ = lds + (BUF) * (BM + BN) * kLdsRow;                                                       \
         float* Bs_ = As_ + BM * kLdsRow;                                                                      \
@@ -86,7 +100,7 @@ __device__ __forceinline__ int xcd_swizzle(int bid, int nwg) {
             *reinterpret_cast<f32x4*>(Bs_ + (sr + 32 * i) * kLdsRow + 4 * sq) = rb[i];                       \
     } while (0)
 
-template <int BM, int BN, bool GENERIC>
+template <int BM, int BN, int MODE>
 __global__ __launch_bounds__(256, 2) void k_conv_igemm(const ConvArgs a) {
     constexpr int TM = BM / 64, TN = BN / 64;     // 32x32 tiles per wave
     constexpr int AR = BM / 32, BR = BN / 32;     // float4 rows staged per thread
@@ -135,7 +149,10 @@ __global__ __launch_bounds__(256, 2) void k_conv_igemm(const ConvArgs a) {
 #pragma unroll
     for (int i = 0; i < BR; ++i) wrow[i] = P.w + (size_t)(n0 + sr + 32 * i) * Kpad + 4 * sq;
 
-    f32x4 ra[AR], rb[BR];
+    // two register sets: the loads of K-step k+2 are issued while step k is computed and step k+1
+    // waits in registers, so every global load has two compute phases to land (HBM / L2 latency
+    // under load exceeds one phase of 16..64 MFMAs)
+    f32x4 ra0[AR], rb0[BR], ra1[AR], rb1[BR];
     f32x16 acc[TM][TN];
 #pragma unroll
     for (int i = 0; i < TM; ++i)
@@ -144,36 +161,42 @@ __global__ __launch_bounds__(256, 2) void k_conv_igemm(const ConvArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+#define FPC_CONV_COMPUTE(BUF)                                                                                  \
+    do {                                                                                                      \
+        const float* As = lds + (BUF) * (BM + BN) * kLdsRow + (wm * (BM / 2) + li) * kLdsRow + 4 * lh;        \
+        const float* Bs = lds + (BUF) * (BM + BN) * kLdsRow + BM * kLdsRow + (wn * (BN / 2) + li) * kLdsRow + \
+                          4 * lh;                                                                             \
+        _Pragma("unroll") for (int kk = 0; kk < kConvBK / 8; ++kk) {                                          \
+            f32x4 fa[TM], fb[TN];                                                                             \
+            _Pragma("unroll") for (int i = 0; i < TM; ++i) fa[i] =                                            \
+                *reinterpret_cast<const f32x4*>(As + i * 32 * kLdsRow + kk * 8);                              \
+            _Pragma("unroll") for (int j = 0; j < TN; ++j) fb[j] =                                            \
+                *reinterpret_cast<const f32x4*>(Bs + j * 32 * kLdsRow + kk * 8);                              \
+            /* lanes 0-31 carry k = kk*8 + e, lanes 32-63 carry k = kk*8 + 4 + e: each MFMA sums two k */     \
+            _Pragma("unroll") for (int e = 0; e < 4; ++e)                                                     \
+                _Pragma("unroll") for (int i = 0; i < TM; ++i)                                                \
+                    _Pragma("unroll") for (int j = 0; j < TN; ++j)                                            \
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][e], fb[j][e], acc[i][j], 0, 0, 0); \
+        }                                                                                                     \
+    } while (0)
+
     if (ks0 < ks1) {
-        FPC_CONV_LOAD(ks0);
-        FPC_CONV_STORE(0);
+        FPC_CONV_LOAD(ks0, ra0, rb0);
+        FPC_CONV_STORE(0, ra0, rb0);
     }
+    if (ks0 + 1 < ks1) FPC_CONV_LOAD(ks0 + 1, ra0, rb0);
     __syncthreads();
-    for (int ks = ks0; ks < ks1; ++ks) {
-        const int buf = (ks - ks0) & 1;
-        const bool more = ks + 1 < ks1;
-        if (more) FPC_CONV_LOAD(ks + 1);
-        const float* As = lds + buf * (BM + BN) * kLdsRow + (wm * (BM / 2) + li) * kLdsRow + 4 * lh;
-        const float* Bs = lds + buf * (BM + BN) * kLdsRow + BM * kLdsRow + (wn * (BN / 2) + li) * kLdsRow + 4 * lh;
-#pragma unroll
-        for (int kk = 0; kk < kConvBK / 8; ++kk) {
-            f32x4 fa[TM], fb[TN];
-#pragma unroll
-            for (int i = 0; i < TM; ++i) fa[i] = *reinterpret_cast<const f32x4*>(As + i * 32 * kLdsRow + kk * 8);
-#pragma unroll
-            for (int j = 0; j < TN; ++j) fb[j] = *reinterpret_cast<const f32x4*>(Bs + j * 32 * kLdsRow + kk * 8);
-            // lanes 0-31 carry k = kk*8 + e, lanes 32-63 carry k = kk*8 + 4 + e: each MFMA sums two k
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < TN; ++j) {
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].x, fb[j].x, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].y, fb[j].y, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].z, fb[j].z, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].w, fb[j].w, acc[i][j], 0, 0, 0);
-                }
-        }
-        if (more) FPC_CONV_STORE(buf ^ 1);
+    for (int ks = ks0; ks < ks1; ks += 2) {
+        // even phase: LDS buffer 0 holds step ks, set 0 holds ks+1
+        if (ks + 2 < ks1) FPC_CONV_LOAD(ks + 2, ra1, rb1);
+        FPC_CONV_COMPUTE(0);
+        if (ks + 1 < ks1) FPC_CONV_STORE(1, ra0, rb0);
+        __syncthreads();
+        if (ks + 1 >= ks1) break;
+        // odd phase: LDS buffer 1 holds step ks+1, set 1 holds ks+2
+        if (ks + 3 < ks1) FPC_CONV_LOAD(ks + 3, ra0, rb0);
+        FPC_CONV_COMPUTE(1);
+        if (ks + 2 < ks1) FPC_CONV_STORE(0, ra1, rb1);
         __syncthreads();
     }
 
@@ -235,7 +258,9 @@ __global__ __launch_bounds__(256, 2) void k_conv_igemm(const ConvArgs a) {
         }
 }
 
-// grid (P32 = mtiles*bm/32, B, G); sums the split-K partials in split order and applies the epilogue.
+// Sums the split-K partials in split order and applies the epilogue.
+// grid (P32 * nchunk, B, G): one workgroup = 32 rows x 128 channels; thread = 4 rows x 4 channels, so a
+// split costs every thread four independent 16-byte loads (unrolled over splits for more in flight).
 __global__ __launch_bounds__(256) void k_conv_splitk_epilogue(const ConvArgs a) {
     __shared__ float s_sum[8][128][2];
     ConvPtrs P = a.p[0];
@@ -243,56 +268,61 @@ __global__ __launch_bounds__(256) void k_conv_splitk_epilogue(const ConvArgs a) 
     if (blockIdx.z == 2) P = a.p[2];
     if (blockIdx.z == 3) P = a.p[3];
     const int t = threadIdx.x, rg = t >> 5, cq = t & 31;
-    const int b = blockIdx.y, tile = blockIdx.x;
-    const int HoWo = a.Ho * a.Wo, Mp = a.mtiles * a.bm;
+    const int nchunk = (a.Cout + 127) >> 7;
+    const int b = blockIdx.y, tile = blockIdx.x / nchunk, nc = (blockIdx.x - tile * nchunk) * 128;
+    const int HoWo = a.Ho * a.Wo, Mp = a.mtiles * a.bm, nsplit = a.nsplit, Npad = a.Npad, Cout = a.Cout;
     const int Wu = a.Wo >> 1, Hu = a.Ho >> 1;
-    const int P32 = gridDim.x;
-    for (int nc = 0; nc < a.Cout; nc += 128) {
-        int n = nc + 4 * cq;
-        bool nv = n < a.Cout;     // Cout % 4 == 0 on this path
-        float cs1[4] = {0, 0, 0, 0}, cs2[4] = {0, 0, 0, 0};
-        float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (nv && P.scale) sc = *reinterpret_cast<const float4*>(P.scale + n);
-        if (nv && P.shift) sh = *reinterpret_cast<const float4*>(P.shift + n);
+    const int P32 = a.mtiles * a.bm / 32;
+    const int n = nc + 4 * cq;
+    const bool nv = n < Cout;     // Cout % 4 == 0 on this path
+    f32x4 v[4];
+    bool rv[4];
+    const float* src[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            int p = tile * 32 + rg + 8 * j;
-            if (!(nv && p < HoWo)) continue;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            for (int sp = 0; sp < a.nsplit; ++sp) {
-                const float* ws = a.splitk_ws + ((((size_t)blockIdx.z * a.nsplit + sp) * a.B + b) * (size_t)Mp + p) * a.Npad + n;
-                float4 x = *reinterpret_cast<const float4*>(ws);
-                v.x += x.x; v.y += x.y; v.z += x.z; v.w += x.w;
-            }
-            if (P.scale) { v.x *= sc.x; v.y *= sc.y; v.z *= sc.z; v.w *= sc.w; }
-            v.x += sh.x; v.y += sh.y; v.z += sh.z; v.w += sh.w;
-            size_t o = ((size_t)b * HoWo + p) * a.Cout + n;
-            if (P.res) {
-                float4 x = *reinterpret_cast<const float4*>(P.res + o);
-                v.x += x.x; v.y += x.y; v.z += x.z; v.w += x.w;
-            }
-            if (P.up) {
-                int ho = p / a.Wo, wo = p - ho * a.Wo;
-                float4 x = *reinterpret_cast<const float4*>(P.up + (((size_t)b * Hu + (ho >> 1)) * Wu + (wo >> 1)) * a.Cout + n);
-                v.x += x.x; v.y += x.y; v.z += x.z; v.w += x.w;
-            }
-            if (a.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-            *reinterpret_cast<float4*>(P.out + o) = v;
-            cs1[0] += v.x; cs1[1] += v.y; cs1[2] += v.z; cs1[3] += v.w;
-            cs2[0] += v.x * v.x; cs2[1] += v.y * v.y; cs2[2] += v.z * v.z; cs2[3] += v.w * v.w;
+    for (int j = 0; j < 4; ++j) {
+        int p = tile * 32 + rg + 8 * j;
+        rv[j] = nv && p < HoWo;
+        v[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        src[j] = a.splitk_ws + (((size_t)blockIdx.z * nsplit * a.B + b) * (size_t)Mp + (rv[j] ? p : 0)) * Npad + (nv ? n : 0);
+    }
+    const size_t sstride = (size_t)a.B * Mp * Npad;
+#pragma unroll 4
+    for (int sp = 0; sp < nsplit; ++sp) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] += *reinterpret_cast<const f32x4*>(src[j] + sp * sstride);
+    }
+    f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
+    if (nv && P.scale) sc = *reinterpret_cast<const f32x4*>(P.scale + n);
+    if (nv && P.shift) sh = *reinterpret_cast<const f32x4*>(P.shift + n);
+    f32x4 cs1 = {0.f, 0.f, 0.f, 0.f}, cs2 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        if (!rv[j]) continue;
+        int p = tile * 32 + rg + 8 * j;
+        f32x4 x = v[j];
+        if (P.scale) x = x * sc;
+        x = x + sh;
+        size_t o = ((size_t)b * HoWo + p) * Cout + n;
+        if (P.res) x += *reinterpret_cast<const f32x4*>(P.res + o);
+        if (P.up) {
+            int ho = p / a.Wo, wo = p - ho * a.Wo;
+            x += *reinterpret_cast<const f32x4*>(P.up + (((size_t)b * Hu + (ho >> 1)) * Wu + (wo >> 1)) * Cout + n);
         }
-        if (P.gn_part) {
-            __syncthreads();
+        if (a.relu) { x[0] = fmaxf(x[0], 0.f); x[1] = fmaxf(x[1], 0.f); x[2] = fmaxf(x[2], 0.f); x[3] = fmaxf(x[3], 0.f); }
+        *reinterpret_cast<f32x4*>(P.out + o) = x;
+        cs1 += x;
+        cs2 += x * x;
+    }
+    if (P.gn_part) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) { s_sum[rg][4 * cq + e][0] = cs1[e]; s_sum[rg][4 * cq + e][1] = cs2[e]; }
-            __syncthreads();
-            if (t < 128 && nc + t < a.Cout) {
-                float u = 0.f, w = 0.f;
+        for (int e = 0; e < 4; ++e) { s_sum[rg][4 * cq + e][0] = cs1[e]; s_sum[rg][4 * cq + e][1] = cs2[e]; }
+        __syncthreads();
+        if (t < 128 && nc + t < Cout) {
+            float u = 0.f, w = 0.f;
 #pragma unroll
-                for (int g = 0; g < 8; ++g) { u += s_sum[g][t][0]; w += s_sum[g][t][1]; }
-                float* gp = P.gn_part + (((size_t)b * P32 + tile) * a.Cout + nc + t) * 2;
-                gp[0] = u; gp[1] = w;
-            }
+            for (int g = 0; g < 8; ++g) { u += s_sum[g][t][0]; w += s_sum[g][t][1]; }
+            float* gp = P.gn_part + (((size_t)b * P32 + tile) * Cout + nc + t) * 2;
+            gp[0] = u; gp[1] = w;
         }
     }
 }
@@ -572,20 +602,32 @@ __global__ __launch_bounds__(256) void k_up4_compress(const Up4Args a) {
 // ------------------------------------------------------------------------------------------
 // parameter repacking (once per plan)
 
-// OIHW [Cout][Cin][Kh][Kw] -> OHWI rows [Npad][Kpad], k = (kh*Kw + kw)*Cin + ci, zero padded
+// OIHW [Cout][Cin][Kh][Kw] -> OHWI rows [Npad][Kpad], k = (kh*Kw + kw)*Cinp + ci (Cinp >= Cin: channel
+// padding of the input layout, e.g. 4 for the RGB stem), zero padded
 __global__ __launch_bounds__(256) void k_pack_weight(const float* __restrict__ w, float* __restrict__ out, int Cout,
-                                                     int Cin, int Kh, int Kw, int Npad, int Kpad) {
+                                                     int Cin, int Cinp, int Kh, int Kw, int Npad, int Kpad) {
     long long total = (long long)Npad * Kpad;
-    int K = Cin * Kh * Kw;
+    int K = Cinp * Kh * Kw;
     for (long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (long long)gridDim.x * blockDim.x) {
         int k = (int)(g % Kpad), n = (int)(g / Kpad);
         float v = 0.f;
         if (n < Cout && k < K) {
-            int tap = k / Cin, ci = k - tap * Cin;
+            int tap = k / Cinp, ci = k - tap * Cinp;
             int kh = tap / Kw, kw = tap - kh * Kw;
-            v = w[(((size_t)n * Cin + ci) * Kh + kh) * Kw + kw];
+            if (ci < Cin) v = w[(((size_t)n * Cin + ci) * Kh + kh) * Kw + kw];
         }
         out[g] = v;
+    }
+}
+
+// image NCHW [B,3,H,W] -> NHWC4 [B,H,W,4] (4th channel 0): 16-byte pixels for the stem's loader
+__global__ __launch_bounds__(256) void k_nchw3_to_nhwc4(const float* __restrict__ x, float* __restrict__ out, int B,
+                                                        int HW) {
+    long long total = (long long)B * HW;
+    for (long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (long long)gridDim.x * blockDim.x) {
+        long long b = g / HW, p = g - b * HW;
+        const float* s = x + b * 3 * HW + p;
+        *reinterpret_cast<f32x4*>(out + g * 4) = f32x4{s[0], s[HW], s[2 * (long long)HW], 0.f};
     }
 }
 
@@ -607,15 +649,21 @@ __global__ void k_fold_bn(const float* __restrict__ gamma, const float* __restri
 template <int BM, int BN>
 static void launch_conv_t(const ConvArgs& a, int groups, hipStream_t s) {
     dim3 grid(a.mtiles * a.B * a.ntiles * a.nsplit, groups);
-    if (a.generic)
-        hipLaunchKernelGGL((k_conv_igemm<BM, BN, true>), grid, dim3(256), 0, s, a);
+    if (a.generic == 0)
+        hipLaunchKernelGGL((k_conv_igemm<BM, BN, 0>), grid, dim3(256), 0, s, a);
+    else if (a.generic == 2)
+        hipLaunchKernelGGL((k_conv_igemm<BM, BN, 2>), grid, dim3(256), 0, s, a);
     else
-        hipLaunchKernelGGL((k_conv_igemm<BM, BN, false>), grid, dim3(256), 0, s, a);
+        hipLaunchKernelGGL((k_conv_igemm<BM, BN, 1>), grid, dim3(256), 0, s, a);
 }
 
+// a.generic: 0 = Cin % 32 == 0 channel-last (fast path), 2 = Cin % 4 == 0 channel-last (per-lane tap decode),
+//            1 = anything (scalar gathers)
 int launch_conv(const ConvArgs& a, int groups, hipStream_t s) {
     if (groups < 1 || groups > kMaxGroup || a.Npad % a.bn != 0 || a.Kpad % kConvBK != 0) return FPC_EINVAL;
-    if (!a.generic && (a.Cin % kConvBK != 0 || a.in_sc != 1)) return FPC_EINVAL;
+    if (a.generic == 0 && (a.Cin % kConvBK != 0 || a.in_sc != 1)) return FPC_EINVAL;
+    if (a.generic == 2 && (a.Cin % 4 != 0 || a.in_sc != 1 || a.in_sw % 4 != 0 || a.in_sh % 4 != 0 || a.in_sb % 4 != 0))
+        return FPC_EINVAL;
     if (a.bm == 128 && a.bn == 128) launch_conv_t<128, 128>(a, groups, s);
     else if (a.bm == 128 && a.bn == 64) launch_conv_t<128, 64>(a, groups, s);
     else if (a.bm == 64 && a.bn == 128) launch_conv_t<64, 128>(a, groups, s);
@@ -626,7 +674,8 @@ int launch_conv(const ConvArgs& a, int groups, hipStream_t s) {
 
 int launch_conv_splitk_epilogue(const ConvArgs& a, int groups, hipStream_t s) {
     if (a.Cout % 4 != 0) return FPC_EINVAL;
-    hipLaunchKernelGGL(k_conv_splitk_epilogue, dim3(a.mtiles * a.bm / 32, a.B, groups), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(k_conv_splitk_epilogue, dim3((a.mtiles * a.bm / 32) * cdiv(a.Cout, 128), a.B, groups), dim3(256), 0, s,
+                       a);
     return check_launch();
 }
 
@@ -671,10 +720,15 @@ int launch_up4_compress(const Up4Args& a, hipStream_t s) {
     return check_launch();
 }
 
-int launch_pack_weight(const float* w, float* packed, int Cout, int Cin, int Kh, int Kw, int Npad, int Kpad,
+int launch_pack_weight(const float* w, float* packed, int Cout, int Cin, int Cinp, int Kh, int Kw, int Npad, int Kpad,
                        hipStream_t s) {
     hipLaunchKernelGGL(k_pack_weight, dim3(stream_grid((long long)Npad * Kpad)), dim3(256), 0, s, w, packed, Cout, Cin,
-                       Kh, Kw, Npad, Kpad);
+                       Cinp, Kh, Kw, Npad, Kpad);
+    return check_launch();
+}
+
+int launch_nchw3_to_nhwc4(const float* x, float* out, int B, int HW, hipStream_t s) {
+    hipLaunchKernelGGL(k_nchw3_to_nhwc4, dim3(stream_grid((long long)B * HW)), dim3(256), 0, s, x, out, B, HW);
     return check_launch();
 }
 

@@ -73,8 +73,9 @@ int launch_gn_finalize(const GnFinArgs& a, int groups, hipStream_t s);
 int launch_gn_relu_up2(const GnUpArgs& a, int groups, hipStream_t s);
 int launch_merge_head(const MergeHeadArgs& a, int groups, hipStream_t s);
 int launch_up4_compress(const Up4Args& a, hipStream_t s);
-int launch_pack_weight(const float* w_oihw, float* packed, int Cout, int Cin, int Kh, int Kw, int Npad, int Kpad,
-                       hipStream_t s);
+int launch_pack_weight(const float* w_oihw, float* packed, int Cout, int Cin, int Cinp, int Kh, int Kw, int Npad,
+                       int Kpad, hipStream_t s);
+int launch_nchw3_to_nhwc4(const float* x, float* out, int B, int HW, hipStream_t s);
 int launch_fold_bn(const float* gamma, const float* beta, const float* mean, const float* var, float eps, int C,
                    float* scale, float* shift, hipStream_t s);
 

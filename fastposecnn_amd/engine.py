@@ -14,7 +14,7 @@ from fastposecnn_amd import _native as nat
 
 class NetEngine:
 
-    def __init__(self, model, B, H, W, device):
+    def __init__(self, model, B, H, W, device, autotune=True):
         L = nat.lib()
         self._lib = L
         self.B, self.H, self.W, self.device = B, H, W, device
@@ -44,6 +44,18 @@ class NetEngine:
             self._ws = torch.empty(nbytes, dtype=torch.uint8, device=device)
             assert self._ws.data_ptr() % 256 == 0
             nat.check(L.fpc_net_load_params(h, ptrs, n, self._ws.data_ptr(), nbytes, nat.stream()), "fpc_net_load_params")
+        if autotune:
+            # one (discarded) forward that times every candidate tiling per convolution on this device
+            nat.check(L.fpc_net_autotune_next(h), "fpc_net_autotune_next")
+            self.forward(torch.zeros((B, 3, H, W), dtype=torch.float32, device=device), want_logits=False)
+
+    def conv_plans(self):
+        out = []
+        buf = (ctypes.c_int * 5)()
+        for i in range(self._lib.fpc_net_conv_count(self._h)):
+            self._lib.fpc_net_conv_plan(self._h, i, buf)
+            out.append(tuple(buf))
+        return out
 
     def __del__(self):
         h = getattr(self, "_h", None)

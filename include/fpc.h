@@ -159,6 +159,13 @@ int fpc_net_load_params(fpc_net_t* net, const float* const* params, int count, v
 int fpc_net_forward(fpc_net_t* net, const float* x, float* logits_mask, float* logits_quat,
                     float* logits_scales, float* logits_xy, float* logits_z, int64_t* cat_mask,
                     float* cq, float* cs, float* cxy, float* cz, fpc_stream_t stream);
+/* Autotuning: after fpc_net_autotune_next the NEXT fpc_net_forward times every candidate tiling
+ * (block tile, split-K factor) of every convolution on the device, keeps the fastest, and is itself
+ * a valid forward; it synchronises the stream, so it must not be captured into a graph.
+ * fpc_net_conv_plan reports the tiling in use for convolution i: out5 = bm, bn, nsplit, Cout, K. */
+int fpc_net_autotune_next(fpc_net_t* net);
+int fpc_net_conv_count(const fpc_net_t* net);
+int fpc_net_conv_plan(const fpc_net_t* net, int i, int* out5);
 /* Intermediate activations (NHWC f32 inside the workspace) for tests: "stem", "pool", "c2".."c5",
  * "d<k>.p5".."d<k>.p2", "d<k>.seg<i>" (pre-GroupNorm conv outputs), "d<k>.low" (low-res logits). */
 int fpc_net_tensor(const fpc_net_t* net, const char* name, const float** ptr, int* H, int* W, int* C);
