@@ -113,20 +113,26 @@ def main():
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
     vote_ms = []
 
-    def step(timed):
+    def step():
+        """One frame: backbone + class compression on the image, then aggregation -> hough voting -> RT on
+        the vote-bench frame through Model.agg_hough_and_generate_RT (capacity-sized buffers, instance
+        count kept on the device, ONE host read at the end of the frame)."""
         with torch.no_grad():
             if not args.vote_only:
                 logits = model_gpu.pure_model_forward(x)
                 model_gpu.class_compression(logits)
-            agg = model_gpu.aggregate(cat)
-            if timed:
-                ev[0].record()
-            agg = model_gpu.hough_voting(agg)
-            if timed:
-                ev[1].record()
-            agg = model_gpu.perform_RT_calculation(agg)
+            agg = model_gpu.agg_hough_and_generate_RT(cat)
             if world > 1:
                 parallel.all_gather_pose_records(agg, rank, cap)
+        return agg
+
+    def vote_probe():
+        """HIP events around the hough-voting enqueue alone (its inputs produced just before)."""
+        with torch.no_grad():
+            agg = model_gpu.aggregate(cat)
+            ev[0].record()
+            agg = model_gpu.hough_voting(agg)
+            ev[1].record()
         return agg
 
     def barrier():
@@ -135,11 +141,11 @@ def main():
         torch.cuda.synchronize()
 
     for _ in range(args.warmup):
-        step(False)
+        step()
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        step(False)
+        step()
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
@@ -149,7 +155,7 @@ def main():
 
     # vote roofline: separate, untimed-for-throughput loop with HIP events around the vote call
     for _ in range(max(5, min(args.steps, 30))):
-        step(True)
+        vote_probe()
         ev[1].synchronize()
         vote_ms.append(ev[0].elapsed_time(ev[1]))
     vote_ms.sort()

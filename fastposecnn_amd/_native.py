@@ -28,13 +28,13 @@ _SIGNATURES = {
     "fpc_generate_hypothesis": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     "fpc_voting_for_hypothesis": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _f, _vp]),
     "fpc_ransac_workspace_bytes": (_sz, [_i, _i, _i, _i]),
-    "fpc_ransac_voting_v3": (_i, [_vp, _vp, _i64, _i64, _i64, _i64, _i, _i, _i, _i, _vp, _vp, _u64, _f, _i, _i,
+    "fpc_ransac_voting_v3": (_i, [_vp, _vp, _i64, _i64, _i64, _i64, _i, _vp, _i, _i, _i, _vp, _vp, _u64, _f, _i, _i,
                                   _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "fpc_class_compress": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     "fpc_cc_workspace_bytes": (_sz, [_i, _i, _i]),
     "fpc_cc_label": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _i, _vp, _sz, _vp]),
     "fpc_aggregate_workspace_bytes": (_sz, [_i]),
-    "fpc_aggregate": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz,
+    "fpc_aggregate": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz,
                            _vp]),
     "fpc_pose_rt": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp]),
     "fpc_net_create": (_i, [ctypes.c_char_p, _i, _i, _i, _i, ctypes.POINTER(_vp)]),
@@ -72,7 +72,7 @@ def lib():
             fn = getattr(L, name)
             fn.restype = res
             fn.argtypes = args
-        if L.fpc_abi_version() != 1:
+        if L.fpc_abi_version() != 2:
             raise RuntimeError("fastposecnn_amd: libfpc_hip.so ABI version mismatch")
         _lib = L
     return _lib

@@ -13,9 +13,9 @@ namespace fpc {
 struct AggWs {
     double* sums;        // [N, 8]   zero-filled per call
     int32_t* cnt;        // [N]      zero-filled
-    uint32_t* cls_min;   // [N]      0xFFFFFFFF-filled
+    uint32_t* cls_min;   // [N]      zero-filled; holds 0xFFFFFFFF - (smallest class id seen)
     int32_t* sample;     // [N]
-    size_t zero_bytes, ff_off, ff_bytes, total;
+    size_t zero_bytes, total;
 };
 
 static AggWs agg_carve(void* base, int N) {
@@ -24,121 +24,101 @@ static AggWs agg_carve(void* base, int N) {
     size_t off = 0;
     w.sums = (double*)(p + off); off = align_up(off + sizeof(double) * 8 * (size_t)N, 256);
     w.cnt = (int32_t*)(p + off); off = align_up(off + sizeof(int32_t) * (size_t)N, 256);
-    w.zero_bytes = off;
-    w.ff_off = off;
     w.cls_min = (uint32_t*)(p + off); off = align_up(off + sizeof(uint32_t) * (size_t)N, 256);
-    w.ff_bytes = off - w.ff_off;
+    w.zero_bytes = off;
     w.sample = (int32_t*)(p + off); off = align_up(off + sizeof(int32_t) * (size_t)N, 256);
     w.total = off;
     return w;
 }
 
-constexpr int kAggIters = 16;                 // 256 threads x 16 = 4096 pixels per workgroup
-constexpr int kAggPx = 256 * kAggIters;
-constexpr int kAggRecs = 4 * kAggIters;       // one record per (iteration, wave)
+constexpr int kAggRows = 8;                   // image rows per wave: a workgroup covers a 64 x 32 pixel tile
 
 __device__ __forceinline__ void agg_flush(int i, const double* v, int n, uint32_t c, int b, double* sums,
                                           int32_t* cnt, uint32_t* cls_min, int32_t* sample) {
 #pragma unroll
     for (int a = 0; a < 8; ++a) unsafeAtomicAdd(&sums[(size_t)i * 8 + a], v[a]);
     atomicAdd(&cnt[i], n);
-    atomicMin(&cls_min[i], c);
+    atomicMax(&cls_min[i], 0xFFFFFFFFu - c);   // stored inverted so that one zero-fill initialises everything
     sample[i] = b;
 }
 
-// grid (ceil(HW/4096), B).  A wave whose 64 pixels carry one label (the common case) reduces
-// them with shuffles into one LDS record; the workgroup then merges its <= 64 records per label
-// in a fixed order and issues ONE set of global atomics per (workgroup, label).  Waves that
-// straddle several labels fall back to per-lane atomics.
+// One wave = a 64-pixel-wide, kAggRows-tall strip (coalesced 256-byte rows).  Instances are blobs, so
+// going DOWN a strip the wave usually stays inside one label: lanes keep private fp64 sums while the
+// wave-uniform label is unchanged and the wave reduces (shuffles) + issues ONE set of global atomics
+// only when that label changes or the strip ends.  Rows where two instances meet inside the 64 pixels
+// fall back to per-lane atomics for the minority label.   grid (ceil(W/64), ceil(H/(4*kAggRows)), B)
 __global__ __launch_bounds__(256) void k_agg_accum(const int32_t* __restrict__ labels,
                                                    const int64_t* __restrict__ cm, const float* __restrict__ quat,
                                                    const float* __restrict__ scales, const float* __restrict__ z,
-                                                   int HW, int N, double* __restrict__ sums,
-                                                   int32_t* __restrict__ cnt, uint32_t* __restrict__ cls_min,
-                                                   int32_t* __restrict__ sample) {
-    __shared__ int s_label[kAggRecs];
-    __shared__ int s_n[kAggRecs];
-    __shared__ uint32_t s_cls[kAggRecs];
-    __shared__ double s_v[kAggRecs][8];
-    int b = blockIdx.y;
-    int lane = threadIdx.x & (kWave - 1), w = threadIdx.x / kWave;
-    int p0 = blockIdx.x * kAggPx;
-#pragma unroll 1
-    for (int it = 0; it < kAggIters; ++it) {
-        int p = p0 + it * 256 + threadIdx.x;
+                                                   int H, int W, int N, const int32_t* __restrict__ n_dev,
+                                                   double* __restrict__ sums, int32_t* __restrict__ cnt,
+                                                   uint32_t* __restrict__ cls_min, int32_t* __restrict__ sample) {
+    if (n_dev) N = min(N, *n_dev);
+    const int b = blockIdx.z, HW = H * W;
+    const int lane = threadIdx.x & (kWave - 1), w = threadIdx.x / kWave;
+    const int x = blockIdx.x * kWave + lane;
+    const int y0 = (blockIdx.y * 4 + w) * kAggRows;
+    int cur = 0, n = 0;
+    uint32_t c = 0xFFFFFFFFu;
+    double v[8];
+#pragma unroll
+    for (int a = 0; a < 8; ++a) v[a] = 0.0;
+    auto wave_flush = [&]() {
+        double t[8];
+#pragma unroll
+        for (int a = 0; a < 8; ++a) t[a] = wave_reduce_add(v[a]);
+        int nn = wave_reduce_add(n);
+        uint32_t cc = c;
+#pragma unroll
+        for (int o = kWave / 2; o > 0; o >>= 1) cc = min(cc, (uint32_t)__shfl_down((int)cc, o, kWave));
+        if (lane == 0 && nn > 0) agg_flush(cur - 1, t, nn, cc, b, sums, cnt, cls_min, sample);
+        n = 0; c = 0xFFFFFFFFu;
+#pragma unroll
+        for (int a = 0; a < 8; ++a) v[a] = 0.0;
+    };
+    for (int r = 0; r < kAggRows; ++r) {
+        int y = y0 + r;
+        if (y >= H) break;                                   // wave-uniform
+        int p = y * W + x;
         int l = 0;
-        if (p < HW) l = labels[(size_t)b * HW + p];
+        if (x < W) l = labels[(size_t)b * HW + p];
         if (l > N) l = 0;
         bool act = l > 0;
         unsigned long long m = __ballot(act);
-        int rec = it * 4 + w;
-        if (m == 0) {
-            if (lane == 0) s_label[rec] = 0;
-            continue;
-        }
-        double v[8];
-        uint32_t c = 0xFFFFFFFFu;
-        if (act) {
-            size_t o = (size_t)b * HW + p;
-            long long cc = cm[o];
-            if (cc != 0) c = (uint32_t)cc;
-#pragma unroll
-            for (int a = 0; a < 4; ++a) v[a] = (double)quat[((size_t)b * 4 + a) * HW + p];
-#pragma unroll
-            for (int a = 0; a < 3; ++a) v[4 + a] = (double)scales[((size_t)b * 3 + a) * HW + p];
-            v[7] = (double)z[o];
-        } else {
-#pragma unroll
-            for (int a = 0; a < 8; ++a) v[a] = 0.0;
-        }
+        if (m == 0) continue;
         int first = __builtin_amdgcn_readlane(l, __ffsll((long long)m) - 1);
-        bool uniform = __ballot(act && l != first) == 0;
-        if (uniform) {
+        if (first != cur) {                                  // wave-uniform decision
+            if (cur > 0) wave_flush();
+            cur = first;
+        }
+        if (!act) continue;
+        size_t o = (size_t)b * HW + p;
+        long long cc = cm[o];
+        uint32_t pc = cc != 0 ? (uint32_t)cc : 0xFFFFFFFFu;
+        double q[8];
 #pragma unroll
-            for (int a = 0; a < 8; ++a) v[a] = wave_reduce_add(v[a]);
+        for (int a = 0; a < 4; ++a) q[a] = (double)quat[((size_t)b * 4 + a) * HW + p];
 #pragma unroll
-            for (int o = kWave / 2; o > 0; o >>= 1) c = min(c, (uint32_t)__shfl_down((int)c, o, kWave));
-            if (lane == 0) {
-                s_label[rec] = first;
-                s_n[rec] = __popcll(m);
-                s_cls[rec] = c;
+        for (int a = 0; a < 3; ++a) q[4 + a] = (double)scales[((size_t)b * 3 + a) * HW + p];
+        q[7] = (double)z[o];
+        if (l == cur) {
 #pragma unroll
-                for (int a = 0; a < 8; ++a) s_v[rec][a] = v[a];
-            }
+            for (int a = 0; a < 8; ++a) v[a] += q[a];
+            ++n;
+            c = min(c, pc);
         } else {
-            if (lane == 0) s_label[rec] = 0;
-            if (act) agg_flush(l - 1, v, 1, c, b, sums, cnt, cls_min, sample);
+            agg_flush(l - 1, q, 1, pc, b, sums, cnt, cls_min, sample);   // a second instance inside these 64 pixels
         }
     }
-    __syncthreads();
-    int r = threadIdx.x;
-    if (r < kAggRecs) {
-        int l = s_label[r];
-        bool lead = l > 0;
-        for (int k = 0; k < r && lead; ++k) lead = s_label[k] != l;
-        if (lead) {
-            double v[8];
-#pragma unroll
-            for (int a = 0; a < 8; ++a) v[a] = s_v[r][a];
-            int n = s_n[r];
-            uint32_t c = s_cls[r];
-            for (int k = r + 1; k < kAggRecs; ++k) {
-                if (s_label[k] != l) continue;
-#pragma unroll
-                for (int a = 0; a < 8; ++a) v[a] += s_v[k][a];
-                n += s_n[k];
-                c = min(c, s_cls[k]);
-            }
-            agg_flush(l - 1, v, n, c, b, sums, cnt, cls_min, sample);
-        }
-    }
+    if (cur > 0) wave_flush();
 }
 
-__global__ void k_agg_finalize(int N, const double* __restrict__ sums, const int32_t* __restrict__ cnt,
+__global__ void k_agg_finalize(int N, const int32_t* __restrict__ n_dev, const double* __restrict__ sums, const int32_t* __restrict__ cnt,
                                const uint32_t* __restrict__ cls_min, const int32_t* __restrict__ sample,
                                int64_t* __restrict__ class_ids, int64_t* __restrict__ sample_ids,
                                float* __restrict__ oq, float* __restrict__ os, float* __restrict__ oz) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n_dev) N = min(N, *n_dev);
     if (i >= N) return;
     double c = (double)cnt[i];
     float q[4];
@@ -151,7 +131,7 @@ __global__ void k_agg_finalize(int N, const double* __restrict__ sums, const int
 #pragma unroll
     for (int a = 0; a < 3; ++a) os[(size_t)i * 3 + a] = (float)(sums[(size_t)i * 8 + 4 + a] / c);
     oz[i] = expf((float)(sums[(size_t)i * 8 + 7] / c));
-    uint32_t cm = cls_min[i];
+    uint32_t cm = 0xFFFFFFFFu - cls_min[i];
     class_ids[i] = cm == 0xFFFFFFFFu ? 0 : (int64_t)cm;
     sample_ids[i] = cnt[i] > 0 ? (int64_t)sample[i] : -1;
 }
@@ -159,8 +139,10 @@ __global__ void k_agg_finalize(int N, const double* __restrict__ sums, const int
 // grid (ceil(HW/1024), N)
 __global__ __launch_bounds__(256) void k_agg_planes(const int32_t* __restrict__ labels, const float* __restrict__ xy,
                                                     const int32_t* __restrict__ sample, int HW,
+                                                    const int32_t* __restrict__ n_dev,
                                                     float* __restrict__ inst_masks, float* __restrict__ oxy) {
     int i = blockIdx.y;
+    if (n_dev && i >= *n_dev) return;     // capacity rows past the device-side instance count
     int b = sample[i];
     int p0 = blockIdx.x * 1024 + threadIdx.x * 4;
     if (p0 >= HW) return;
@@ -206,7 +188,8 @@ extern "C" size_t fpc_aggregate_workspace_bytes(int N) {
 }
 
 extern "C" int fpc_aggregate(const int32_t* labels, const int64_t* cat_mask, const float* quat, const float* scales,
-                             const float* xy, const float* z, int B, int H, int W, int N, int64_t* class_ids,
+                             const float* xy, const float* z, int B, int H, int W, int N, const int32_t* n_dev,
+                             int64_t* class_ids,
                              int64_t* sample_ids, float* inst_masks, float* oq, float* os, float* oz, float* oxy,
                              void* ws, size_t ws_bytes, fpc_stream_t stream) {
     if (B < 0 || H < 1 || W < 1 || N < 0) return FPC_EINVAL;
@@ -224,14 +207,14 @@ extern "C" int fpc_aggregate(const int32_t* labels, const int64_t* cat_mask, con
     hipStream_t s = (hipStream_t)stream;
     int HW = H * W;
     hipError_t e = hipMemsetAsync(ws, 0, w.zero_bytes, s);
-    if (e == hipSuccess) e = hipMemsetAsync((char*)ws + w.ff_off, 0xFF, w.ff_bytes, s);
     if (e != hipSuccess) { set_hip_error(e); return FPC_ELAUNCH; }
     int gx = cdiv(HW, 1024);
-    hipLaunchKernelGGL(k_agg_accum, dim3(cdiv(HW, kAggPx), B), dim3(256), 0, s, labels, cat_mask, quat, scales, z, HW, N, w.sums,
+    hipLaunchKernelGGL(k_agg_accum, dim3(cdiv(W, kWave), cdiv(H, 4 * kAggRows), B), dim3(256), 0, s, labels, cat_mask, quat, scales, z,
+                       H, W, N, n_dev, w.sums,
                        w.cnt, w.cls_min, w.sample);
-    hipLaunchKernelGGL(k_agg_finalize, dim3(cdiv(N, 64)), dim3(64), 0, s, N, w.sums, w.cnt, w.cls_min, w.sample,
+    hipLaunchKernelGGL(k_agg_finalize, dim3(cdiv(N, 64)), dim3(64), 0, s, N, n_dev, w.sums, w.cnt, w.cls_min, w.sample,
                        class_ids, sample_ids, oq, os, oz);
     if (inst_masks || oxy)
-        hipLaunchKernelGGL(k_agg_planes, dim3(gx, N), dim3(256), 0, s, labels, xy, w.sample, HW, inst_masks, oxy);
+        hipLaunchKernelGGL(k_agg_planes, dim3(gx, N), dim3(256), 0, s, labels, xy, w.sample, HW, n_dev, inst_masks, oxy);
     return check_launch();
 }

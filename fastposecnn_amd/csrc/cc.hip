@@ -100,21 +100,36 @@ __global__ __launch_bounds__(256) void k_cc_merge(int W, int HW, long long total
     }
 }
 
+// Root of every pixel + root census.  Only pixels whose parent lies OUTSIDE their 64-pixel wave segment
+// (run starts that were united with another row / segment) walk the union-find tree; a pixel whose
+// parent is a lower lane of its own wave — every non-start pixel of a run, k_cc_init — takes that
+// lane's root by shuffle.  This removes ~60x of the finds and all of their atomic contention.
 __global__ __launch_bounds__(256) void k_cc_flatten(long long total, int32_t* __restrict__ L,
                                                     int32_t* __restrict__ R, int32_t* __restrict__ blk_cnt) {
     __shared__ int scratch[4];
     long long g0 = (long long)blockIdx.x * kCcBlock;
+    int lane = threadIdx.x & (kWave - 1);
     int roots = 0;
 #pragma unroll
     for (int it = 0; it < 4; ++it) {
         long long g = g0 + it * 256 + threadIdx.x;
-        if (g >= total) continue;
+        bool in = g < total;
+        int p = in ? L[g] : -1;
+        bool fg = p >= 0;
+        long long seg0 = g - lane;
+        bool inseg = fg && p >= seg0 && p < g;
         int r = -1;
-        if (L[g] >= 0) {
-            r = cc_find_halve(L, (int)g);
-            roots += (r == (int)g);
+        if (fg && !inseg) r = cc_find_halve(L, (int)g);
+        for (int k = 0; k < 8; ++k) {      // in-segment chains are one link deep unless runs of one row were united
+            int pr = __shfl(r, inseg ? (int)(p - seg0) : lane, kWave);
+            if (inseg && r < 0 && pr >= 0) r = pr;
+            if (!__any(inseg && r < 0)) break;
         }
-        R[g] = r;
+        if (fg && r < 0) r = cc_find(L, (int)g);
+        if (in) {
+            roots += (r == (int)g);
+            R[g] = r;
+        }
     }
     int tot = block_sum_bcast(roots, scratch);
     if (threadIdx.x == 0) blk_cnt[blockIdx.x] = tot;

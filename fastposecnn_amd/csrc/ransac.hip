@@ -124,7 +124,7 @@ static Ws carve(void* base, int n, int H, int W, int hn) {
     w.meta = (int32_t*)(p + off); off = align_up(off + sizeof(int32_t) * (size_t)n * kMeta, 256);
     w.hyp = (float*)(p + off); off = align_up(off + sizeof(float) * (size_t)n * hn * 2, 256);
     w.partial = (double*)(p + off); off = align_up(off + sizeof(double) * (size_t)n * kSelP * kPartial, 256);
-    w.partial_i = (int32_t*)(p + off); off = align_up(off + sizeof(int32_t) * (size_t)n * kSelP * 8, 256);
+    w.partial_i = (int32_t*)(p + off); off = align_up(off + sizeof(int32_t) * (size_t)n * kSelP * 16, 256);
     w.px = (float4*)(p + off); off = align_up(off + sizeof(float4) * (size_t)n * HW, 256);
     w.total = off;
     return w;
@@ -153,7 +153,8 @@ __device__ __forceinline__ int chunk_flags(const float* __restrict__ m, const ui
 }
 
 __global__ __launch_bounds__(256) void k_chunk_count(const float* __restrict__ mask, int HW, int nch,
-                                                     int32_t* __restrict__ chunk_fg) {
+                                                     int32_t* __restrict__ chunk_fg, const int32_t* __restrict__ n_dev) {
+    if (n_dev && (int)(blockIdx.y) >= *n_dev) return;   // capacity rows past the device-side instance count
     __shared__ int scratch[4];
     int inst = blockIdx.y, c = blockIdx.x;
     const float* m = mask + (size_t)inst * HW;
@@ -179,7 +180,8 @@ __device__ __forceinline__ void total_and_prefix(const int32_t* __restrict__ arr
 __global__ __launch_bounds__(256) void k_chunk_kept(const float* __restrict__ mask, const uint8_t* __restrict__ keep,
                                                     int HW, int nch, uint64_t seed, int max_num,
                                                     const int32_t* __restrict__ chunk_fg,
-                                                    int32_t* __restrict__ chunk_kept) {
+                                                    int32_t* __restrict__ chunk_kept, const int32_t* __restrict__ n_dev) {
+    if (n_dev && (int)(blockIdx.y) >= *n_dev) return;   // capacity rows past the device-side instance count
     __shared__ int scratch[4];
     int inst = blockIdx.y, c = blockIdx.x;
     int fg, pf;
@@ -198,7 +200,8 @@ __global__ __launch_bounds__(256) void k_compact(const float* __restrict__ mask,
                                                  uint64_t seed, int min_num, int max_num,
                                                  const int32_t* __restrict__ chunk_fg,
                                                  const int32_t* __restrict__ chunk_kept,
-                                                 int32_t* __restrict__ meta, float4* __restrict__ px) {
+                                                 int32_t* __restrict__ meta, float4* __restrict__ px, const int32_t* __restrict__ n_dev) {
+    if (n_dev && (int)(blockIdx.y) >= *n_dev) return;   // capacity rows past the device-side instance count
     __shared__ int scratch[4];
     __shared__ int wave_off[4];
     int inst = blockIdx.y, c = blockIdx.x;
@@ -262,7 +265,8 @@ __device__ __forceinline__ void make_hypothesis(const float4* __restrict__ P, in
 
 __global__ __launch_bounds__(256) void k_hypothesis(const float4* __restrict__ px, int HW, int hn,
                                                     const int32_t* __restrict__ idxs, uint64_t seed,
-                                                    const int32_t* __restrict__ meta, float* __restrict__ hyp) {
+                                                    const int32_t* __restrict__ meta, float* __restrict__ hyp, const int32_t* __restrict__ n_dev) {
+    if (n_dev && (int)(blockIdx.y) >= *n_dev) return;   // capacity rows past the device-side instance count
     int inst = blockIdx.y;
     int hi = blockIdx.x * blockDim.x + threadIdx.x;
     if (hi >= hn) return;
@@ -277,7 +281,8 @@ __global__ __launch_bounds__(256) void k_hypothesis(const float4* __restrict__ p
 // outside the filter's domain (th <= 2e-6).
 __global__ __launch_bounds__(256) void k_count_exact(const float4* __restrict__ px, int HW, int hn, float thresh,
                                                      const int32_t* __restrict__ meta, const float* __restrict__ hyp,
-                                                     int32_t* __restrict__ counts) {
+                                                     int32_t* __restrict__ counts, const int32_t* __restrict__ n_dev) {
+    if (n_dev && (int)(blockIdx.z) >= *n_dev) return;   // capacity rows past the device-side instance count
     __shared__ float4 s_px[kTile];
     __shared__ float s_n1[kTile];
     int inst = blockIdx.z;
@@ -323,8 +328,9 @@ __global__ __launch_bounds__(256) void k_count_exact(const float4* __restrict__ 
 template <int T>
 __global__ __launch_bounds__(256) void k_count_hi(const float4* __restrict__ px, int HW, int hn, float wh,
                                                   float kappa, const int32_t* __restrict__ idxs, uint64_t seed,
-                                                  const int32_t* __restrict__ meta, float* __restrict__ hyp,
-                                                  int32_t* __restrict__ counts) {
+                                                  const int32_t* __restrict__ meta, const float* __restrict__ hyp,
+                                                  int32_t* __restrict__ counts, const int32_t* __restrict__ n_dev) {
+    if (n_dev && (int)blockIdx.z >= *n_dev) return;
     constexpr int kBlk = 4 * kWave * T;
     __shared__ int s_cnt[kWave];
     int inst = blockIdx.z;
@@ -334,22 +340,17 @@ __global__ __launch_bounds__(256) void k_count_hi(const float4* __restrict__ px,
     const float4* P = px + (size_t)inst * HW;
     if (threadIdx.x < kWave) s_cnt[threadIdx.x] = 0;
 
-    // this lane's hypothesis: (hx, hy, -E_h); (0, 0, -inf) outside the filter's domain
-    // (every voting pixel then counts: still an upper bound), (0, 0, +inf) past hn (never counts)
+    // this lane's hypothesis (generated once by k_hypothesis): (hx, hy, -E_h); (0, 0, -inf) outside the
+    // filter's domain (every voting pixel then counts: still an upper bound), (0, 0, +inf) past hn
     float hx = 0.f, hy = 0.f, ne = __builtin_huge_valf();
     int hi = h0 + lane;
     if (hi < hn) {
-        float x, y;
-        make_hypothesis(P, tn, hn, inst, hi, idxs, seed, x, y);
-        if (blockIdx.y == 0 && w == 0) {
-            hyp[((size_t)inst * hn + hi) * 2] = x;
-            hyp[((size_t)inst * hn + hi) * 2 + 1] = y;
-        }
+        float x = hyp[((size_t)inst * hn + hi) * 2], y = hyp[((size_t)inst * hn + hi) * 2 + 1];
         float s = fabsf(x) + fabsf(y);
         if (s <= 1e18f) { hx = x; hy = y; ne = -2e-6f * (s + wh); }   // false for inf / NaN
         else ne = -__builtin_huge_valf();
     }
-    if (tn == 0) return;   // uniform; hypotheses of empty instances are written as zeros above
+    if (tn == 0) return;   // uniform
     __syncthreads();
 
     int cnt_v = 0;
@@ -399,11 +400,12 @@ __global__ __launch_bounds__(256) void k_count_hi(const float4* __restrict__ px,
 
 // ---- k_select / k_refine ------------------------------------------------------
 
-constexpr int kCand = 8;   // candidates re-counted exactly in the first, parallel pass
+constexpr int kCand = 8;           // candidates re-counted exactly in the first, parallel pass
+constexpr int kSelLds = 4096;      // counts of up to this many hypotheses are staged in LDS for the arg-max rounds
 
 // (max count, lowest index) over counts[0..hn) skipping entries whose bit is set in `done`.
 // Result broadcast to the block through s_int[0..7].
-__device__ __forceinline__ void block_argmax(const int32_t* __restrict__ counts, int hn, const uint32_t* done,
+__device__ __forceinline__ void block_argmax(const int32_t* counts, int hn, const uint32_t* done,
                                              int* s_int, int& bc, int& bi) {
     bc = -1; bi = 0x7fffffff;
     for (int h = threadIdx.x; h < hn; h += blockDim.x) {
@@ -482,12 +484,14 @@ __device__ __forceinline__ bool arrive_last(int32_t* ticket, int nwg, int* s_fla
 __global__ __launch_bounds__(256) void k_select(const float4* __restrict__ px, int HW, int hn, float thresh,
                                                 int32_t* __restrict__ meta, const float* __restrict__ hyp,
                                                 const int32_t* __restrict__ counts_all,
-                                                int32_t* __restrict__ partial_all, int32_t* __restrict__ tickets) {
+                                                int32_t* __restrict__ partial_all, int32_t* __restrict__ tickets, const int32_t* __restrict__ n_dev) {
+    if (n_dev && (int)(blockIdx.y) >= *n_dev) return;   // capacity rows past the device-side instance count
     __shared__ int s_int[8];
     __shared__ int s_flag;
     __shared__ int s_cidx[kCand], s_chi[kCand];
     __shared__ int s_wc[4][kCand];
     __shared__ uint32_t s_done[2048];
+    __shared__ int32_t s_counts[kSelLds];
     int inst = blockIdx.y;
     int tn = meta[inst * kMeta + 1];
     if (tn == 0) {
@@ -500,12 +504,17 @@ __global__ __launch_bounds__(256) void k_select(const float4* __restrict__ px, i
     int32_t* partial = partial_all + (size_t)inst * kSelP * kCand;
 
     for (int i = threadIdx.x; i < 2048; i += blockDim.x) s_done[i] = 0;
+    // arg-max rounds run on an LDS copy of the bounds (a global re-scan per round costs an L2 round trip each)
+    const bool in_lds = hn <= kSelLds;
+    if (in_lds)
+        for (int i = threadIdx.x; i < hn; i += blockDim.x) s_counts[i] = counts[i];
     __syncthreads();
+    const int32_t* cnt_src = in_lds ? s_counts : counts;
     // the same candidate list in every workgroup
     int ncand = 0;
     for (int k = 0; k < kCand; ++k) {
         int c_hi, c_idx;
-        block_argmax(counts, hn, s_done, s_int, c_hi, c_idx);
+        block_argmax(cnt_src, hn, s_done, s_int, c_hi, c_idx);
         if (c_hi <= 0) break;
         if (threadIdx.x == 0) { s_cidx[k] = c_idx; s_chi[k] = c_hi; s_done[c_idx >> 5] |= 1u << (c_idx & 31); }
         __syncthreads();
@@ -553,7 +562,7 @@ __global__ __launch_bounds__(256) void k_select(const float4* __restrict__ px, i
     // anything outside the candidate set whose bound can still win (or tie with a lower index)?
     while (true) {
         int n_hi, n_idx;
-        block_argmax(counts, hn, s_done, s_int, n_hi, n_idx);
+        block_argmax(cnt_src, hn, s_done, s_int, n_hi, n_idx);
         if (n_hi <= 0 || n_hi < best_cnt || (n_hi == best_cnt && best_idx >= 0 && n_idx > best_idx)) break;
         int qc = exact_count(P, tn, threadIdx.x, 256, H[2 * n_idx], H[2 * n_idx + 1], thresh, s_int);
         if (threadIdx.x == 0) { s_done[n_idx >> 5] |= 1u << (n_idx & 31); s_int[0] = qc; }
@@ -591,7 +600,8 @@ __device__ __forceinline__ void solve2_sym(double a00, double a01, double a11, d
 __global__ __launch_bounds__(256) void k_refine(const float4* __restrict__ px, int HW, int hn, float thresh,
                                                 int32_t* __restrict__ meta, const float* __restrict__ hyp,
                                                 double* __restrict__ partial_all, int32_t* __restrict__ tickets,
-                                                float* __restrict__ out_xy) {
+                                                float* __restrict__ out_xy, const int32_t* __restrict__ n_dev) {
+    if (n_dev && (int)(blockIdx.y) >= *n_dev) return;   // capacity rows past the device-side instance count
     __shared__ double s_sum[4][6];
     __shared__ int s_flag;
     int inst = blockIdx.y;
@@ -684,9 +694,9 @@ extern "C" size_t fpc_ransac_workspace_bytes(int n, int H, int W, int hn) {
 }
 
 extern "C" int fpc_ransac_voting_v3(const float* mask, const float* vertex, int64_t vs_n, int64_t vs_h, int64_t vs_w,
-                                    int64_t vs_c, int n, int H, int W, int hn, const int32_t* idxs,
-                                    const uint8_t* keep, uint64_t seed, float inlier_thresh, int min_num,
-                                    int max_num, float* out_xy, int32_t* out_tn, int32_t* out_win_idx,
+                                    int64_t vs_c, int n, const int32_t* n_dev, int H, int W, int hn,
+                                    const int32_t* idxs, const uint8_t* keep, uint64_t seed, float inlier_thresh,
+                                    int min_num, int max_num, float* out_xy, int32_t* out_tn, int32_t* out_win_idx,
                                     int32_t* out_win_count, int32_t* out_inl_count, float* out_hyp,
                                     int32_t* out_counts, void* ws, size_t ws_bytes, fpc_stream_t stream) {
     if (n < 0 || H < 1 || W < 1 || hn < 1 || hn > 65536 || max_num < 1) return FPC_EINVAL;
@@ -702,11 +712,13 @@ extern "C" int fpc_ransac_voting_v3(const float* mask, const float* vertex, int6
 
     hipError_t e = hipMemsetAsync(w.counts, 0, w.zero_bytes, s);
     if (e != hipSuccess) { set_hip_error(e); return FPC_ELAUNCH; }
-    hipLaunchKernelGGL(k_chunk_count, dim3(nch, n), dim3(256), 0, s, mask, HW, nch, w.chunk_fg);
+    hipLaunchKernelGGL(k_chunk_count, dim3(nch, n), dim3(256), 0, s, mask, HW, nch, w.chunk_fg, n_dev);
     hipLaunchKernelGGL(k_chunk_kept, dim3(nch, n), dim3(256), 0, s, mask, keep, HW, nch, seed, max_num, w.chunk_fg,
-                       w.chunk_kept);
+                       w.chunk_kept, n_dev);
     hipLaunchKernelGGL(k_compact, dim3(nch, n), dim3(256), 0, s, mask, vertex, vs_n, vs_h, vs_w, vs_c, keep, W, HW,
-                       nch, seed, min_num, max_num, w.chunk_fg, w.chunk_kept, w.meta, w.px);
+                       nch, seed, min_num, max_num, w.chunk_fg, w.chunk_kept, w.meta, w.px, n_dev);
+    hipLaunchKernelGGL(k_hypothesis, dim3(cdiv(hn, 256), n), dim3(256), 0, s, w.px, HW, hn, idxs, seed, w.meta, w.hyp,
+                       n_dev);
 
     // the filter needs th' = th - 1e-6 > 0; otherwise count exactly
     bool fast = inlier_thresh > 2e-6f && inlier_thresh < 3.0e38f;
@@ -715,7 +727,7 @@ extern "C" int fpc_ransac_voting_v3(const float* mask, const float* vertex, int6
         int split = 2048 / (n * hb);
         split = split < 8 ? 8 : (split > 128 ? 128 : split);
         hipLaunchKernelGGL(k_count_exact, dim3(hb, split, n), dim3(256), 0, s, w.px, HW, hn, inlier_thresh, w.meta,
-                           w.hyp, dst);
+                           w.hyp, dst, n_dev);
     };
     if (fast) {
         double thp = (double)inlier_thresh - 1e-6;
@@ -725,17 +737,15 @@ extern "C" int fpc_ransac_voting_v3(const float* mask, const float* vertex, int6
         int split = cdiv(max_num < HW ? max_num + max_num / 8 + 64 : HW, kBlkPx);
         split = split < 1 ? 1 : (split > 64 ? 64 : split);
         hipLaunchKernelGGL(k_count_hi<kT>, dim3(cdiv(hn, kWave), split, n), dim3(256), 0, s, w.px, HW, hn, wh, kappa,
-                           idxs, seed, w.meta, w.hyp, w.counts);
+                           idxs, seed, w.meta, w.hyp, w.counts, n_dev);
         if (out_counts) exact_counts(w.counts_ex);
     } else {
-        hipLaunchKernelGGL(k_hypothesis, dim3(cdiv(hn, 256), n), dim3(256), 0, s, w.px, HW, hn, idxs, seed, w.meta,
-                           w.hyp);
         exact_counts(w.counts);
     }
     hipLaunchKernelGGL(k_select, dim3(kSelP, n), dim3(256), 0, s, w.px, HW, hn, inlier_thresh, w.meta, w.hyp,
-                       w.counts, w.partial_i, w.tickets);
+                       w.counts, w.partial_i, w.tickets, n_dev);
     hipLaunchKernelGGL(k_refine, dim3(kSelP, n), dim3(256), 0, s, w.px, HW, hn, inlier_thresh, w.meta, w.hyp,
-                       w.partial, w.tickets + n, out_xy);
+                       w.partial, w.tickets + n, out_xy, n_dev);
     if (out_tn || out_win_idx || out_win_count || out_inl_count)
         hipLaunchKernelGGL(k_export_meta, dim3(cdiv(n, 256)), dim3(256), 0, s, w.meta, n, out_tn, out_win_idx,
                            out_win_count, out_inl_count);

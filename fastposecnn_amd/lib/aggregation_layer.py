@@ -34,7 +34,7 @@ class AggregationLayer(nn.Module):
         cm = class_mask if class_mask.dtype == torch.int64 else class_mask.to(torch.int64)
         cm = cm.contiguous()
         labels = torch.empty((B, H, W), dtype=torch.int32, device=dev)
-        n_dev = torch.zeros(1, dtype=torch.int32, device=dev)
+        n_dev = torch.empty(1, dtype=torch.int32, device=dev)      # always written by fpc_cc_label
         L = nat.lib()
         with torch.cuda.device(dev):
             ws = nat.workspace("cc", dev, L.fpc_cc_workspace_bytes(B, H, W))
@@ -44,14 +44,10 @@ class AggregationLayer(nn.Module):
             return labels, n_dev
         return labels, int(n_dev.item())
 
-    def forward(self, cat_data):
-        cat_mask = cat_data['mask']
-        nat.require_gpu(cat_mask, what="AggregationLayer")
-        dev = cat_mask.device
-        cm = cat_mask.to(torch.int64).contiguous()
+    def _aggregate(self, cat_data, cm, labels, N, n_dev):
+        """Shared body: N is the exact count (n_dev None) or a capacity gated on the device by n_dev."""
+        dev = cm.device
         B, H, W = cm.shape
-        labels, N = self.batchwise_break_segmentation_mask(cm)
-
         f32 = dict(dtype=torch.float32, device=dev)
         out = {
             'class_ids': torch.empty((N,), dtype=torch.int64, device=dev),
@@ -72,8 +68,25 @@ class AggregationLayer(nn.Module):
         with torch.cuda.device(dev):
             ws = nat.workspace("agg", dev, L.fpc_aggregate_workspace_bytes(N))
             nat.check(L.fpc_aggregate(nat.ptr(labels), nat.ptr(cm), nat.ptr(q), nat.ptr(s), nat.ptr(xy), nat.ptr(z),
-                                      B, H, W, N, nat.ptr(out['class_ids']), nat.ptr(out['sample_ids']),
+                                      B, H, W, N, nat.ptr(n_dev), nat.ptr(out['class_ids']), nat.ptr(out['sample_ids']),
                                       nat.ptr(out['instance_masks']), nat.ptr(out['quaternion']),
                                       nat.ptr(out['scales']), nat.ptr(out['z']), nat.ptr(out['xy']),
                                       nat.ptr(ws), ws.numel(), nat.stream()), "fpc_aggregate")
         return out
+
+    def forward(self, cat_data):
+        cat_mask = cat_data['mask']
+        nat.require_gpu(cat_mask, what="AggregationLayer")
+        cm = cat_mask.to(torch.int64).contiguous()
+        labels, N = self.batchwise_break_segmentation_mask(cm)      # one host read: N shapes the outputs
+        return self._aggregate(cat_data, cm, labels, N, None)
+
+    def forward_deferred(self, cat_data, capacity):
+        """Same result in the first n rows of `capacity`-row tensors, WITHOUT reading n back: returns
+        (agg_data, n_dev).  Used by the model's fused post-network path, which enqueues voting and RT
+        behind it and synchronises once at the end (lib/pose_regressor.py)."""
+        cat_mask = cat_data['mask']
+        nat.require_gpu(cat_mask, what="AggregationLayer")
+        cm = cat_mask.to(torch.int64).contiguous()
+        labels, n_dev = self.batchwise_break_segmentation_mask(cm, return_device_count=True)
+        return self._aggregate(cat_data, cm, labels, int(capacity), n_dev), n_dev

@@ -13,7 +13,7 @@ class HoughVotingLayer(nn.Module):
         super().__init__()
         self.HPARAM = HPARAM
 
-    def forward(self, agg_data):
+    def forward(self, agg_data, n_dev=None, seed=None):
         uv_img = agg_data['xy']                # [n,2,H,W] masked vote field
         mask = agg_data['instance_masks']      # [n,H,W]
         # [n,H,W,1,2] strided VIEW of the two planes — read in place by the kernel
@@ -22,6 +22,8 @@ class HoughVotingLayer(nn.Module):
             mask=mask,
             vertex=reshaped_uv_img,
             round_hyp_num=self.HPARAM.HV_NUM_OF_HYPOTHESES,
+            n_dev=n_dev,
+            seed=seed,
         )
         good_output = torch.squeeze(output, dim=1)
         agg_data.update({'hypothesis': output, 'pruned_hypothesis': output, 'xy': good_output, 'xy_mask': uv_img})

@@ -58,15 +58,37 @@ class Model(object):
         return gtf.samplewise_get_RT(agg_data, self.inv_intrinsics)
 
     def agg_hough_and_generate_RT(self, categorical_data) -> Union[None, dict]:
-        if self.HPARAM.PERFORM_AGGREGATION:
-            agg_data = self.aggregate(categorical_data)
-            if self.HPARAM.PERFORM_HOUGH_VOTING:
-                agg_data = self.hough_voting(agg_data)
-                if self.HPARAM.PERFORM_RT_CALCULATION:
-                    agg_data = self.perform_RT_calculation(agg_data)
-        else:
+        if not self.HPARAM.PERFORM_AGGREGATION:
             return None
+        if categorical_data['mask'].is_cuda and self.HPARAM.PERFORM_HOUGH_VOTING and not self.HPARAM.RUNTIME_TIMING:
+            return self._post_network_deferred(categorical_data)
+        agg_data = self.aggregate(categorical_data)
+        if self.HPARAM.PERFORM_HOUGH_VOTING:
+            agg_data = self.hough_voting(agg_data)
+            if self.HPARAM.PERFORM_RT_CALCULATION:
+                agg_data = self.perform_RT_calculation(agg_data)
         return agg_data
+
+    def _post_network_deferred(self, categorical_data):
+        """aggregate -> hough voting -> RT enqueued back to back on capacity-sized buffers, the instance
+        count staying on the device (the reference synchronises >= 3 + rounds times PER INSTANCE,
+        RV/ransac_voting_gpu.py:532-581); ONE host read at the end trims every tensor to [:n].
+        Same dict as the stage-by-stage path.  If more than `capacity` instances exist the stages are
+        simply re-run at the exact size."""
+        cap = int(getattr(self.HPARAM, 'MAX_INSTANCES', 32)) * categorical_data['mask'].shape[0]
+        seed = int(torch.randint(0, 2 ** 62, (1,)).item())      # one draw, also when the stages are re-run
+        while True:
+            agg, n_dev = self.aggregation_layer.forward_deferred(categorical_data, cap)
+            agg = self.hough_voting_layer(agg, n_dev=n_dev, seed=seed)
+            if self.HPARAM.PERFORM_RT_CALCULATION:
+                agg = gtf.samplewise_get_RT(agg, self.inv_intrinsics)
+            n = int(n_dev.item())
+            if n <= cap:
+                break
+            cap = n
+        if n == 0:
+            agg['class_ids'] = agg['class_ids'].float()      # reference: float class ids when empty (:116)
+        return {k: v[:n] for k, v in agg.items()}
 
     @classmethod
     def load_from_ckpt(self, ckpt_path, HPARAM):

@@ -13,7 +13,9 @@ Keyword-only extensions (not in the reference): `idxs` (i32 [b,hn,vn,2]) injects
 pairs, `keep` (u8/bool [b,h,w]) injects the > max_num thinning selection, `seed` fixes the
 built-in counter-based sampler (include/fpc_rng.h; default: drawn from torch's CPU generator,
 so torch.manual_seed() makes runs repeatable), `return_debug` also returns per-instance
-diagnostics (tn, win_idx, win_count, inlier_count, hyp, counts).
+diagnostics (tn, win_idx, win_count, inlier_count, hyp, counts), `n_dev` (device i32[1]) limits the work
+to the first n_dev instances of a capacity-sized batch without a host read (rows past it are left
+uninitialised).
 """
 import torch
 
@@ -29,7 +31,7 @@ def b_inv(b_mat):
 
 
 def ransac_voting_layer_v3(mask, vertex, round_hyp_num, inlier_thresh=0.999, confidence=0.99, max_iter=20,
-                           min_num=5, max_num=30000, *, idxs=None, keep=None, seed=None, return_debug=False):
+                           min_num=5, max_num=30000, *, idxs=None, keep=None, seed=None, return_debug=False, n_dev=None):
     """
     :param mask:      [b,h,w]   foreground where != 0
     :param vertex:    [b,h,w,vn,2]  (any strides; the permuted view of hough_voting.py:51 is read in place)
@@ -42,7 +44,8 @@ def ransac_voting_layer_v3(mask, vertex, round_hyp_num, inlier_thresh=0.999, con
         raise RuntimeError("ransac_voting_layer_v3: mask [b,h,w] / vertex [b,h,w,vn,2] shape mismatch")
     hn = int(round_hyp_num)
     dev = mask.device
-    out = torch.zeros((b, vn, 2), dtype=torch.float32, device=dev)
+    # every processed row is written by the kernels (instances below min_num get zeros)
+    out = torch.empty((b, vn, 2), dtype=torch.float32, device=dev)
     dbg = []
     if b == 0:
         # the reference's torch.cat([]) guard (:602-605)
@@ -77,7 +80,7 @@ def ransac_voting_layer_v3(mask, vertex, round_hyp_num, inlier_thresh=0.999, con
                          hyp=torch.empty((b, hn, 2), dtype=torch.float32, device=dev),
                          counts=torch.empty((b, hn), dtype=torch.int32, device=dev))
             nat.check(L.fpc_ransac_voting_v3(
-                nat.ptr(mask), v.data_ptr(), sn, sh, sw, sc, b, h, w, hn, nat.ptr(ii), nat.ptr(keep),
+                nat.ptr(mask), v.data_ptr(), sn, sh, sw, sc, b, nat.ptr(n_dev), h, w, hn, nat.ptr(ii), nat.ptr(keep),
                 (seed + vi) & (2 ** 64 - 1), float(inlier_thresh), int(min_num), int(max_num), nat.ptr(xy),
                 nat.ptr(d["tn"]) if d else None, nat.ptr(d["win_idx"]) if d else None,
                 nat.ptr(d["win_count"]) if d else None, nat.ptr(d["inlier_count"]) if d else None,

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define FPC_ABI_VERSION 1
+#define FPC_ABI_VERSION 2
 
 #define FPC_OK 0
 #define FPC_EINVAL (-1)      /* bad argument (shape, null pointer, ...) */
@@ -70,12 +70,15 @@ int fpc_voting_for_hypothesis(const float* direct, const float* coords, const fl
  * out_xy  f32 [n,2]
  * optional diagnostics (NULL to skip): out_tn, out_win_idx, out_win_count,
  *         out_inl_count i32 [n]; out_hyp f32 [n,hn,2]; out_counts i32 [n,hn]
+ * n_dev   NULL, or DEVICE i32[1]: only the first min(n, *n_dev) instances are processed (rows past it are
+ *         left untouched).  Lets a caller size buffers by a capacity `n` and enqueue the vote behind
+ *         fpc_cc_label without reading the instance count back to the host.
  * ws      device workspace of at least fpc_ransac_workspace_bytes(n,H,W,hn) bytes,
  *         256-byte aligned.  Contents are scratch. */
 size_t fpc_ransac_workspace_bytes(int n, int H, int W, int hn);
 int fpc_ransac_voting_v3(const float* mask, const float* vertex,
                          int64_t vs_n, int64_t vs_h, int64_t vs_w, int64_t vs_c,
-                         int n, int H, int W, int hn,
+                         int n, const int32_t* n_dev, int H, int W, int hn,
                          const int32_t* idxs, const uint8_t* keep, uint64_t seed,
                          float inlier_thresh, int min_num, int max_num,
                          float* out_xy, int32_t* out_tn, int32_t* out_win_idx,
@@ -106,14 +109,15 @@ int fpc_cc_label(const int64_t* cat_mask, int B, int H, int W,
                  void* ws, size_t ws_bytes, fpc_stream_t stream);
 
 /* ---- aggregation ------------------------------------------------------------
- * labels i32 [B,H,W] from fpc_cc_label, N instances (host value, read back by the
- * caller), categorical planes quat [B,4,HW], scales [B,3,HW], xy [B,2,HW], z [B,HW].
+ * labels i32 [B,H,W] from fpc_cc_label, N instances (host value: the count read back by the caller,
+ * or a capacity when n_dev — DEVICE i32[1], fpc_cc_label's n_out — is given: then only the first
+ * min(N, *n_dev) instances are produced and the remaining rows are left untouched), categorical planes quat [B,4,HW], scales [B,3,HW], xy [B,2,HW], z [B,HW].
  * -> class_ids i64 [N], sample_ids i64 [N], inst_masks f32 [N,HW] (nullable),
  *    oq [N,4], os [N,3], oz [N], oxy f32 [N,2,HW] (nullable). */
 size_t fpc_aggregate_workspace_bytes(int N);
 int fpc_aggregate(const int32_t* labels, const int64_t* cat_mask,
                   const float* quat, const float* scales, const float* xy, const float* z,
-                  int B, int H, int W, int N,
+                  int B, int H, int W, int N, const int32_t* n_dev,
                   int64_t* class_ids, int64_t* sample_ids, float* inst_masks,
                   float* oq, float* os, float* oz, float* oxy,
                   void* ws, size_t ws_bytes, fpc_stream_t stream);

@@ -379,3 +379,30 @@ def test_v3_exact_mode_for_nonpositive_threshold(lib, oracle, dev):
         want, wdbg = oracle.ransac_voting_layer_v3(g["mask"], g["xy"].transpose(0, 2, 3, 1)[:, :, :, None, :], 64,
                                                    seed=3, inlier_thresh=th, return_debug=True)
         _assert_v3_equal(out, dbg, want, wdbg)
+
+
+# ----------------------------------------------------------------------------- deferred post-network path
+
+def test_deferred_post_network_equals_staged(lib, oracle, dev):
+    """Model.agg_hough_and_generate_RT on capacity-sized buffers with the instance count kept on the
+    device (one host read at the end) returns exactly what the stage-by-stage path returns."""
+    from fastposecnn_amd import config, synth
+    hp = config.INFERENCE()
+    hp.RUNTIME_TIMING = False
+    hp.HV_NUM_OF_HYPOTHESES = 200
+    model = lib.pose_regressor.MODELS['PoseRegressor'].load_from_ckpt(None, hp).to(dev).eval()
+    for frames, cap in (([0, 1], 32), ([2], 2), ([3], 32)):            # cap 2 < 6 instances: re-run at exact size
+        hp.MAX_INSTANCES = cap
+        cat_cpu, _ = synth.make_vote_batch(frames)
+        if frames == [3]:
+            cat_cpu = {k: torch.zeros_like(v) for k, v in cat_cpu.items()}      # no instance at all
+        cat = {k: v.to(dev) for k, v in cat_cpu.items()}
+        torch.manual_seed(5)
+        fused = model.agg_hough_and_generate_RT(cat)
+        torch.manual_seed(5)
+        staged = model.perform_RT_calculation(model.hough_voting(model.aggregate(cat)))
+        assert set(fused) == set(staged)
+        for k in staged:
+            assert fused[k].shape == staged[k].shape and fused[k].dtype == staged[k].dtype, k
+            assert torch.equal(fused[k], staged[k]), k
+        assert fused["class_ids"].shape[0] == (0 if frames == [3] else 6 * len(frames))
