@@ -29,11 +29,13 @@ struct PackedConv {
     int p_bn = -1;           // first of (weight, bias, running_mean, running_var) or -1
     int p_bias = -1;         // conv bias or -1
     size_t w_off = 0, scale_off = 0, shift_off = 0;   // float offsets into the workspace
+    size_t wino_off = 0;     // Winograd-packed copy (eligible convs only)
+    bool wino_ok = false;    // 3x3, stride 1, pad 1, Cin % 8 == 0, Cout % 64 == 0
 };
 
 struct Act { size_t off = 0; int H = 0, W = 0, C = 0; };
 
-struct ConvPlan { int bm = 64, bn = 64, nsplit = 1, mtiles = 1, ntiles = 1; };
+struct ConvPlan { int bm = 64, bn = 64, nsplit = 1, mtiles = 1, ntiles = 1, wino = 0; };
 
 static ConvPlan plan_conv(int HoWo, int B, int Cout, int ksteps, int groups, int force_bm = 0, int force_bn = 0,
                           int force_split = 0) {
@@ -55,7 +57,7 @@ static ConvPlan plan_conv(int HoWo, int B, int Cout, int ksteps, int groups, int
                 double nblk = (double)groups * B * mt * nt * ns;
                 double work = (double)(bm / 64) * (bn / 64) * per * 16.0 * 64.0 + 4000.0;
                 double t = ceil(nblk / 256.0) * work + (ns > 1 ? 10000.0 + 200.0 * ns : 0.0);
-                if (t < best_t) { best_t = t; best = ConvPlan{bm, bn, ns, mt, nt}; }
+                if (t < best_t) { best_t = t; best = ConvPlan{bm, bn, ns, mt, nt, 0}; }
             }
         }
     return best;
@@ -74,7 +76,7 @@ static std::vector<ConvPlan> conv_candidates(int HoWo, int B, int Cout, int kste
                 int per = cdiv(ksteps, ns);
                 if (ns > 1 && (per < 2 || (ns - 1) * per >= ksteps || Cout % 4 != 0)) continue;
                 if (ns > 1 && base * ns > 4096) continue;          // already plenty of workgroups
-                out.push_back(ConvPlan{bm, bn, ns, mt, nt});
+                out.push_back(ConvPlan{bm, bn, ns, mt, nt, 0});
             }
         }
     return out;
@@ -150,6 +152,8 @@ struct fpc_net {
         if (bias_name) c.p_bias = add_param(bias_name, Cout);
         c.w_off = alloc((size_t)c.Npad * c.Kpad);
         if (bn_prefix) { c.scale_off = alloc(Cout); c.shift_off = alloc(Cout); }
+        c.wino_ok = (k == 3 && stride == 1 && pad == 1 && c.Cinp == Cin && Cin % 8 == 0 && Cout % 64 == 0);
+        if (c.wino_ok) c.wino_off = alloc((size_t)16 * Cout * Cin);
         convs.push_back(c);
         return (int)convs.size() - 1;
     }
@@ -311,6 +315,10 @@ extern "C" int fpc_net_load_params(fpc_net_t* n, const float* const* params, int
     for (const PackedConv& c : n->convs) {
         int rc = launch_pack_weight(n->pptr[c.p_w], n->ws + c.w_off, c.Cout, c.Cin, c.Cinp, c.Kh, c.Kw, c.Npad, c.Kpad, s);
         if (rc) return rc;
+        if (c.wino_ok) {
+            rc = launch_wino_pack(n->pptr[c.p_w], n->ws + c.wino_off, c.Cout, c.Cin, s);
+            if (rc) return rc;
+        }
         if (c.p_bn >= 0) {
             rc = launch_fold_bn(n->pptr[c.p_bn], n->pptr[c.p_bn + 1], n->pptr[c.p_bn + 2], n->pptr[c.p_bn + 3], 1e-5f,
                                 c.Cout, n->ws + c.scale_off, n->ws + c.shift_off, s);
@@ -342,11 +350,28 @@ void fill_conv_args(const fpc_net* n, ConvArgs& a, const PackedConv& c, const Co
 }
 
 int launch_conv_plan(ConvArgs& a, const ConvPlan& p, int groups, hipStream_t s) {
+    if (p.wino) {
+        WinoArgs w;
+        memset(&w, 0, sizeof(w));
+        for (int g = 0; g < groups; ++g) {
+            if (!a.wino_w[g] || a.p[g].up) return FPC_EINVAL;
+            w.p[g] = a.p[g];
+            w.p[g].w = a.wino_w[g];
+        }
+        w.B = a.B; w.H = a.Ho; w.W = a.Wo; w.Cin = a.Cin; w.Cout = a.Cout; w.relu = a.relu;
+        w.tbx = cdiv(cdiv(a.Wo, 2), 8); w.tby = cdiv(cdiv(a.Ho, 2), 4);
+        return launch_conv_wino(w, groups, s);
+    }
     a.bm = p.bm; a.bn = p.bn; a.nsplit = p.nsplit; a.mtiles = p.mtiles; a.ntiles = p.ntiles;
     int rc = launch_conv(a, groups, s);
     if (rc) return rc;
     if (a.nsplit > 1) rc = launch_conv_splitk_epilogue(a, groups, s);
     return rc;
+}
+
+// number of GroupNorm partial rows per image a plan writes
+int plan_gn_rows(const ConvPlan& p, int Ho, int Wo) {
+    return p.wino ? cdiv(cdiv(Wo, 2), 8) * cdiv(cdiv(Ho, 2), 4) : p.mtiles * p.bm / 32;
 }
 
 // Runs conv site `ci` with its current plan; in tuning mode first times every candidate tiling
@@ -358,7 +383,9 @@ int run_conv(fpc_net* n, ConvArgs& a, int groups, int ci, hipStream_t s) {
         float best_ms = 1e30f;
         ConvPlan best = n->cplan[ci];
         size_t cap = n->splitk_floats;
-        for (const ConvPlan& q : conv_candidates(a.Ho * a.Wo, a.B, a.Cout, a.ksteps, groups)) {
+        std::vector<ConvPlan> cands = conv_candidates(a.Ho * a.Wo, a.B, a.Cout, a.ksteps, groups);
+        if (a.wino_w[0] && !a.p[0].up) { ConvPlan wq; wq.wino = 1; cands.push_back(wq); }
+        for (const ConvPlan& q : cands) {
             if (splitk_floats_for(q, groups, a.B, a.Npad) > cap) continue;
             int rc = launch_conv_plan(a, q, groups, s);     // warm-up (also validates the launch)
             if (rc) { hipEventDestroy(e0); hipEventDestroy(e1); return rc; }
@@ -378,7 +405,7 @@ int run_conv(fpc_net* n, ConvArgs& a, int groups, int ci, hipStream_t s) {
         hipEventDestroy(e1);
         n->cplan[ci] = best;
     }
-    const ConvPlan& p = n ? n->cplan[ci] : ConvPlan{a.bm, a.bn, a.nsplit, a.mtiles, a.ntiles};
+    ConvPlan p = n ? n->cplan[ci] : ConvPlan{a.bm, a.bn, a.nsplit, a.mtiles, a.ntiles, 0};
     return launch_conv_plan(a, p, groups, s);
 }
 
@@ -426,6 +453,7 @@ extern "C" int fpc_net_forward(fpc_net_t* n, const float* x, float* logits_mask,
             const PackedConv& c1 = n->convs[blk.conv1];
             fill_conv_args(n, a, c1, n->cplan[blk.conv1], cur.H, cur.W, T.H, T.W, sb, sh, sw, sc, true, 0);
             a.p[0] = ConvPtrs{ws + cur.off, ws + c1.w_off, ws + T.off, ws + c1.scale_off, ws + c1.shift_off, nullptr, nullptr, nullptr};
+            if (c1.wino_ok) a.wino_w[0] = ws + c1.wino_off;
             FPC_TRY(run_conv(n, a, 1, blk.conv1, s));
             const float* res = ws + cur.off;
             if (blk.ds >= 0) {
@@ -440,6 +468,7 @@ extern "C" int fpc_net_forward(fpc_net_t* n, const float* x, float* logits_mask,
             const PackedConv& c2 = n->convs[blk.conv2];
             fill_conv_args(n, a, c2, n->cplan[blk.conv2], T.H, T.W, Y.H, Y.W, sb, sh, sw, sc, true, 0);
             a.p[0] = ConvPtrs{ws + T.off, ws + c2.w_off, ws + Y.off, ws + c2.scale_off, ws + c2.shift_off, res, nullptr, nullptr};
+            if (c2.wino_ok) a.wino_w[0] = ws + c2.wino_off;
             FPC_TRY(run_conv(n, a, 1, blk.conv2, s));
             cur = Y;
         }
@@ -475,6 +504,7 @@ extern "C" int fpc_net_forward(fpc_net_t* n, const float* x, float* logits_mask,
             const Act& in = which < 0 ? n->a_p[d][-which - 1] : n->a_up[d][which];
             a.p[d] = ConvPtrs{ws + in.off, ws + c.w_off, ws + n->a_seg[d][si].off, nullptr, nullptr, nullptr, nullptr,
                               ws + n->gn_part_off[d][si]};
+            if (c.wino_ok) a.wino_w[d] = ws + c.wino_off;
         }
         int rc = run_conv(n, a, 4, ci0, s);
         if (rc) return rc;
@@ -486,7 +516,7 @@ extern "C" int fpc_net_forward(fpc_net_t* n, const float* x, float* logits_mask,
             g.beta[d] = n->pptr[n->dec[d].p_gn[si] + 1];
             g.affine[d] = ws + n->gn_aff_off[d][si];
         }
-        g.B = B; g.P = n->cplan[ci0].mtiles * n->cplan[ci0].bm / 32; g.C = 128; g.groups = 32; g.count = (long long)o0.H * o0.W * 4; g.eps = 1e-5f;
+        g.B = B; g.P = plan_gn_rows(n->cplan[ci0], o0.H, o0.W); g.C = 128; g.groups = 32; g.count = (long long)o0.H * o0.W * 4; g.eps = 1e-5f;
         return launch_gn_finalize(g, 4, s);
     };
     auto gn_up = [&](int si, int ui) -> int {
@@ -559,7 +589,7 @@ extern "C" int fpc_net_autotune_next(fpc_net_t* n) {
 extern "C" int fpc_net_conv_count(const fpc_net_t* n) { return n ? (int)n->convs.size() : 0; }
 extern "C" int fpc_net_conv_plan(const fpc_net_t* n, int i, int* out5) {
     if (!n || !out5 || i < 0 || i >= (int)n->convs.size()) return FPC_EINVAL;
-    out5[0] = n->cplan[i].bm; out5[1] = n->cplan[i].bn; out5[2] = n->cplan[i].nsplit;
+    out5[0] = n->cplan[i].bm; out5[1] = n->cplan[i].bn; out5[2] = n->cplan[i].wino ? -1 : n->cplan[i].nsplit;
     out5[3] = n->convs[i].Cout; out5[4] = n->convs[i].K;
     return FPC_OK;
 }
@@ -590,7 +620,8 @@ extern "C" size_t fpc_conv2d_workspace_bytes(int B, int Ho, int Wo, int Cin, int
     int K = Cin * Kh * Kw, Kpad = cdiv(K, kConvBK) * kConvBK, Npad = cdiv(Cout, kConvNAlign) * kConvNAlign;
     size_t packed = ((size_t)Npad * Kpad + 63) / 64 * 64;
     size_t splitk = (size_t)32 * B * (cdiv(Ho * Wo, 128) * 128) * Npad;
-    return (packed + splitk) * sizeof(float);
+    size_t wino = (size_t)16 * Cout * Cin;
+    return (packed + splitk + wino) * sizeof(float);
 }
 
 extern "C" int fpc_conv2d_plan(int B, int Ho, int Wo, int Cin, int Cout, int Kh, int Kw, int bm, int bn, int nsplit,
@@ -598,7 +629,8 @@ extern "C" int fpc_conv2d_plan(int B, int Ho, int Wo, int Cin, int Cout, int Kh,
     if (!out4) return FPC_EINVAL;
     int Kpad = cdiv(Cin * Kh * Kw, kConvBK) * kConvBK;
     ConvPlan p = plan_conv(Ho * Wo, B, Cout, Kpad / kConvBK, 1, bm, bn, nsplit);
-    out4[0] = p.bm; out4[1] = p.bn; out4[2] = p.nsplit; out4[3] = p.mtiles * p.bm / 32;
+    if (nsplit == -1) { p.wino = 1; p.nsplit = -1; }
+    out4[0] = p.bm; out4[1] = p.bn; out4[2] = p.nsplit; out4[3] = plan_gn_rows(p, Ho, Wo);
     return FPC_OK;
 }
 
@@ -616,7 +648,8 @@ extern "C" int fpc_conv2d(const float* in, int64_t sb, int64_t sh, int64_t sw, i
     hipStream_t s = (hipStream_t)stream;
     float* packed = (float*)ws;
     FPC_TRY(launch_pack_weight(w_oihw, packed, Cout, Cin, Cin, Kh, Kw, c.Npad, c.Kpad, s));
-    ConvPlan p = plan_conv(Ho * Wo, B, Cout, c.Kpad / kConvBK, 1, bm, bn, nsplit);
+    bool wino = nsplit == -1;
+    ConvPlan p = plan_conv(Ho * Wo, B, Cout, c.Kpad / kConvBK, 1, bm, bn, wino ? 1 : nsplit);
     int mode = (sc == 1 && Cin % kConvBK == 0) ? 0
                : (sc == 1 && Cin % 4 == 0 && sw % 4 == 0 && sh % 4 == 0 && sb % 4 == 0 && ((uintptr_t)in & 15) == 0) ? 2 : 1;
     fpc_net tmp;
@@ -626,5 +659,15 @@ extern "C" int fpc_conv2d(const float* in, int64_t sb, int64_t sh, int64_t sw, i
     ConvArgs a;
     fill_conv_args(&tmp, a, c, p, Hi, Wi, Ho, Wo, sb, sh, sw, sc, relu != 0, mode);
     a.p[0] = ConvPtrs{in, packed, out, scale, shift, res, up, gn_part};
+    if (wino) {
+        if (Kh != 3 || stride != 1 || pad != 1 || Cin % 8 || Cout % 64 || sc != 1 || up || sw != Cin ||
+            sh != (int64_t)Wi * Cin || sb != (int64_t)Hi * Wi * Cin)
+            return FPC_EINVAL;
+        float* wp = packed + tmp.splitk_off + (size_t)32 * B * (cdiv(Ho * Wo, 128) * 128) * c.Npad;
+        FPC_TRY(launch_wino_pack(w_oihw, wp, Cout, Cin, s));
+        a.wino_w[0] = wp;
+        p.wino = 1;
+        return launch_conv_plan(a, p, 1, s);
+    }
     return run_conv(nullptr, a, 1, 0, s);
 }

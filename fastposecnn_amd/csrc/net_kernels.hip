@@ -720,6 +720,237 @@ int launch_up4_compress(const Up4Args& a, hipStream_t s) {
     return check_launch();
 }
 
+
+// ------------------------------------------------------------------------------------------
+// Winograd F(2x2, 3x3) convolution (3x3, stride 1, pad 1) on the f32 matrix cores: 2.25x fewer
+// multiply-adds than the direct form, all in f32.
+//   Y = A^T [ (G g G^T) .* (B^T d B) ] A  per 4x4 input patch d / 2x2 output tile, summed over Cin:
+//   16 independent GEMMs  M_xi[tile][co] = sum_ci V_xi[tile][ci] * U_xi[ci][co].
+// One workgroup = an 8x4 patch of tiles (16x8 output pixels) x 64 output channels x all 16 xi.
+// Wave w owns transform row i = w (xi = 4i..4i+3): 4 xi x 2 column tiles of 32 = 8 MFMA accumulators.
+// Per K-step of 8 input channels the RAW 18x10 input region and the pre-transformed weights
+// (fpc::k_wino_pack, 32 KB contiguous per step) are staged global -> registers -> LDS; each lane builds
+// its four V_xi fragments from 8 LDS reads + 8 vector adds, so the transformed input never exists in
+// memory.  The output transform runs through LDS (wave i holds row i of M) and feeds the same
+// epilogue as the direct kernel (BatchNorm / bias, residual, ReLU, GroupNorm partial sums).
+constexpr int kWinoTX = 8, kWinoTY = 4;                 // tile patch per workgroup
+constexpr int kWinoRW = 2 * kWinoTX + 2, kWinoRH = 2 * kWinoTY + 2;   // input region 18 x 10
+constexpr int kWinoPos = kWinoRW * kWinoRH;             // 180 positions
+constexpr int kWinoIS = 12;                             // floats per staged position (8 + pad)
+constexpr int kWinoBN = 64;
+constexpr int kWinoLdsIn = kWinoPos * kWinoIS;          // 2160 floats
+constexpr int kWinoLdsW = 16 * kWinoBN * 8;             // 8192 floats
+constexpr int kWinoLds = kWinoLdsIn + kWinoLdsW;        // 41.4 KB (the output transform reuses 32 KB of it)
+
+
+__global__ __launch_bounds__(256, 2) void k_conv_wino(const WinoArgs a) {
+    __shared__ __attribute__((aligned(16))) float lds[kWinoLds];
+    ConvPtrs P = a.p[0];
+    if (blockIdx.y == 1) P = a.p[1];
+    if (blockIdx.y == 2) P = a.p[2];
+    if (blockIdx.y == 3) P = a.p[3];
+    const int t = threadIdx.x, lane = t & 63, wi = t >> 6;     // wi = transform row of this wave
+    const int li = lane & 31, lh = lane >> 5;
+    const int H = a.H, W = a.W, Cin = a.Cin, Cout = a.Cout, HW = H * W;
+    const int nkb = Cin >> 3;
+    int bid = blockIdx.x;
+    const int bx = bid % a.tbx; bid /= a.tbx;
+    const int by = bid % a.tby; bid /= a.tby;
+    const int b = bid % a.B;
+    const int nb = bid / a.B;
+    const int ty0 = by * kWinoTY, tx0 = bx * kWinoTX;
+    const int y_in0 = 2 * ty0 - 1, x_in0 = 2 * tx0 - 1;
+
+    // ---- staging: 8 weight float4 + 2 input float4 per thread and K-step
+    const float* wsrc = P.w + (size_t)nb * nkb * kWinoLdsW + 4 * t;
+    int w_dst[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        int f = t + 256 * i;                       // float4 index inside the 32 KB step image [xi][co][2]
+        int co = (f >> 1) & 63;
+        w_dst[i] = kWinoLdsIn + 4 * (f ^ ((co >> 3) & 1));   // swap the two halves on odd 8-channel groups
+    }
+    long long i_src[2];
+    int i_dst[2];
+    bool i_ok[2], i_use[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        int f = t + 256 * i;
+        int q = f >> 1, half = f & 1;
+        i_use[i] = q < kWinoPos;
+        int ry = q / kWinoRW, rx = q - ry * kWinoRW;
+        int y = y_in0 + ry, x = x_in0 + rx;
+        i_ok[i] = i_use[i] && y >= 0 && y < H && x >= 0 && x < W;
+        i_src[i] = ((long long)b * HW + (long long)y * W + x) * Cin + 4 * half;
+        i_dst[i] = q * kWinoIS + 4 * half;
+    }
+    f32x4 rw[8], ri[2];
+#define FPC_WINO_LOAD(KB)                                                                                     \
+    do {                                                                                                      \
+        _Pragma("unroll") for (int i = 0; i < 8; ++i) rw[i] =                                                 \
+            *reinterpret_cast<const f32x4*>(wsrc + (size_t)(KB) * kWinoLdsW + 1024 * i);                      \
+        _Pragma("unroll") for (int i = 0; i < 2; ++i) ri[i] =                                                 \
+            i_ok[i] ? *reinterpret_cast<const f32x4*>(P.in + i_src[i] + 8 * (KB)) : f32x4{0.f, 0.f, 0.f, 0.f}; \
+    } while (0)
+#define FPC_WINO_STORE()                                                                                      \
+    do {                                                                                                      \
+        _Pragma("unroll") for (int i = 0; i < 8; ++i) *reinterpret_cast<f32x4*>(lds + w_dst[i]) = rw[i];      \
+        _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                         \
+            if (i_use[i]) *reinterpret_cast<f32x4*>(lds + i_dst[i]) = ri[i];                                  \
+    } while (0)
+
+    // ---- fragment addressing
+    const int tyl = li >> 3, txl = li & 7;                     // this lane's tile inside the patch
+    // row pair (ra, rb) and sign of B^T row wi:  0: d0-d2   1: d1+d2   2: d2-d1   3: d1-d3
+    const int ra = (wi == 0) ? 0 : (wi == 2 ? 2 : 1);
+    const int rb = (wi == 0) ? 2 : (wi == 1 ? 2 : (wi == 2 ? 1 : 3));
+    const float sgn = (wi == 1) ? 1.f : -1.f;
+    const float* in_a = lds + ((2 * tyl + ra) * kWinoRW + 2 * txl) * kWinoIS + 4 * lh;
+    const float* in_b = lds + ((2 * tyl + rb) * kWinoRW + 2 * txl) * kWinoIS + 4 * lh;
+    const float* w_frag[2];
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+        int co = nt * 32 + li;
+        w_frag[nt] = lds + kWinoLdsIn + ((4 * wi) * kWinoBN + co) * 8 + 4 * (lh ^ ((co >> 3) & 1));
+    }
+
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[j][nt][r] = 0.f;
+
+    FPC_WINO_LOAD(0);
+    for (int kb = 0; kb < nkb; ++kb) {
+        __syncthreads();                 // previous step's fragments are consumed
+        FPC_WINO_STORE();
+        __syncthreads();
+        if (kb + 1 < nkb) FPC_WINO_LOAD(kb + 1);
+        f32x4 e[4], v[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            f32x4 da = *reinterpret_cast<const f32x4*>(in_a + c * kWinoIS);
+            f32x4 db = *reinterpret_cast<const f32x4*>(in_b + c * kWinoIS);
+            e[c] = da + sgn * db;
+        }
+        v[0] = e[0] - e[2]; v[1] = e[1] + e[2]; v[2] = e[2] - e[1]; v[3] = e[1] - e[3];
+        // lanes 0-31 carry ci = q, lanes 32-63 carry ci = 4 + q of this K-step
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            f32x4 u0 = *reinterpret_cast<const f32x4*>(w_frag[0] + j * kWinoBN * 8);
+            f32x4 u1 = *reinterpret_cast<const f32x4*>(w_frag[1] + j * kWinoBN * 8);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                acc[j][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[j][q], u0[q], acc[j][0], 0, 0, 0);
+                acc[j][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[j][q], u1[q], acc[j][1], 0, 0, 0);
+            }
+        }
+    }
+#undef FPC_WINO_LOAD
+#undef FPC_WINO_STORE
+
+    // ---- output transform.  Column part inside the wave: z0 = m0 + m1 + m2, z1 = m1 - m2 - m3;
+    // row part across the four waves through LDS: y0 = z[0] + z[1] + z[2], y1 = z[1] - z[2] - z[3].
+    // LDS image Z[row i][cc][tile 32][co 32] (32 KB), one 32-channel half (nt) at a time.
+    const int ot = t >> 3, oc4 = (t & 7) * 4;                 // output stage: thread = one tile x 4 channels
+    const int oty = ty0 + (ot >> 3), otx = tx0 + (ot & 7);
+    for (int nt = 0; nt < 2; ++nt) {
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            int m = (r & 3) + 8 * (r >> 2) + 4 * lh;
+            float m0 = acc[0][nt][r], m1 = acc[1][nt][r], m2 = acc[2][nt][r], m3 = acc[3][nt][r];
+            lds[((wi * 2 + 0) * 32 + m) * 32 + li] = m0 + m1 + m2;
+            lds[((wi * 2 + 1) * 32 + m) * 32 + li] = m1 - m2 - m3;
+        }
+        __syncthreads();
+        const int n = nb * kWinoBN + nt * 32 + oc4;
+        f32x4 z[4][2];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int cc = 0; cc < 2; ++cc) z[i][cc] = *reinterpret_cast<const f32x4*>(lds + ((i * 2 + cc) * 32 + ot) * 32 + oc4);
+        f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
+        if (P.scale) sc = *reinterpret_cast<const f32x4*>(P.scale + n);
+        if (P.shift) sh = *reinterpret_cast<const f32x4*>(P.shift + n);
+        f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int rr = 0; rr < 2; ++rr)
+#pragma unroll
+            for (int cc = 0; cc < 2; ++cc) {
+                int y = 2 * oty + rr, x = 2 * otx + cc;
+                if (y >= H || x >= W) continue;
+                f32x4 val = rr == 0 ? z[0][cc] + z[1][cc] + z[2][cc] : z[1][cc] - z[2][cc] - z[3][cc];
+                if (P.scale) val = val * sc;
+                val = val + sh;
+                size_t o = ((size_t)b * HW + (size_t)y * W + x) * Cout + n;
+                if (P.res) val += *reinterpret_cast<const f32x4*>(P.res + o);
+                if (a.relu) { val[0] = fmaxf(val[0], 0.f); val[1] = fmaxf(val[1], 0.f); val[2] = fmaxf(val[2], 0.f); val[3] = fmaxf(val[3], 0.f); }
+                *reinterpret_cast<f32x4*>(P.out + o) = val;
+                s1 += val;
+                s2 += val * val;
+            }
+        if (P.gn_part) {
+            // per-channel sums of this workgroup's outputs: 32 tile slots -> LDS -> 32 threads
+            __syncthreads();
+            float* red = lds;                                  // [32 slots][32 ch][2]
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { red[(ot * 32 + oc4 + k) * 2] = s1[k]; red[(ot * 32 + oc4 + k) * 2 + 1] = s2[k]; }
+            __syncthreads();
+            if (t < 32) {
+                float u1 = 0.f, u2 = 0.f;
+                for (int sI = 0; sI < 32; ++sI) { u1 += red[(sI * 32 + t) * 2]; u2 += red[(sI * 32 + t) * 2 + 1]; }
+                int Pn = a.tbx * a.tby;
+                float* g = P.gn_part + (((size_t)b * Pn + by * a.tbx + bx) * Cout + nb * kWinoBN + nt * 32 + t) * 2;
+                g[0] = u1; g[1] = u2;
+            }
+        }
+    }
+}
+
+// OIHW 3x3 weights -> U = G g G^T, packed [Cout/64][Cin/8][16 xi][64 co][8 ci] (one K-step image = 32 KB)
+__global__ __launch_bounds__(256) void k_wino_pack(const float* __restrict__ w, float* __restrict__ out, int Cout,
+                                                   int Cin) {
+    long long total = (long long)Cout * Cin;
+    for (long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (long long)gridDim.x * blockDim.x) {
+        int ci = (int)(g % Cin), co = (int)(g / Cin);
+        const float* k = w + ((size_t)co * Cin + ci) * 9;
+        float gg[4][3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            float g0 = k[c], g1 = k[3 + c], g2 = k[6 + c];
+            gg[0][c] = g0;
+            gg[1][c] = 0.5f * (g0 + g1 + g2);
+            gg[2][c] = 0.5f * (g0 - g1 + g2);
+            gg[3][c] = g2;
+        }
+        int nb = co >> 6, col = co & 63, kb = ci >> 3, cil = ci & 7;
+        float* dst = out + (((size_t)nb * (Cin >> 3) + kb) * 16) * 512 + col * 8 + cil;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            float r0 = gg[i][0], r1 = gg[i][1], r2 = gg[i][2];
+            dst[(4 * i + 0) * 512] = r0;
+            dst[(4 * i + 1) * 512] = 0.5f * (r0 + r1 + r2);
+            dst[(4 * i + 2) * 512] = 0.5f * (r0 - r1 + r2);
+            dst[(4 * i + 3) * 512] = r2;
+        }
+    }
+}
+
+int launch_conv_wino(const WinoArgs& a, int groups, hipStream_t s) {
+    if (groups < 1 || groups > kMaxGroup || a.Cin % 8 != 0 || a.Cout % kWinoBN != 0) return FPC_EINVAL;
+    hipLaunchKernelGGL(k_conv_wino, dim3(a.tbx * a.tby * a.B * (a.Cout / kWinoBN), groups), dim3(256), 0, s, a);
+    return check_launch();
+}
+
+int launch_wino_pack(const float* w_oihw, float* packed, int Cout, int Cin, hipStream_t s) {
+    if (Cin % 8 != 0 || Cout % kWinoBN != 0) return FPC_EINVAL;
+    hipLaunchKernelGGL(k_wino_pack, dim3(stream_grid((long long)Cout * Cin)), dim3(256), 0, s, w_oihw, packed, Cout, Cin);
+    return check_launch();
+}
+
 int launch_pack_weight(const float* w, float* packed, int Cout, int Cin, int Cinp, int Kh, int Kw, int Npad, int Kpad,
                        hipStream_t s) {
     hipLaunchKernelGGL(k_pack_weight, dim3(stream_grid((long long)Npad * Kpad)), dim3(256), 0, s, w, packed, Cout, Cin,

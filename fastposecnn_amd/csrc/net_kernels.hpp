@@ -26,6 +26,7 @@ struct ConvArgs {
     int B, Hi, Wi, Cin, Ho, Wo, Cout, Npad, Kh, Kw, stride, pad, K, Kpad;
     long long in_sb, in_sh, in_sw, in_sc;   // element strides of the input
     int relu, nsplit, mtiles, ntiles, ksteps, bm, bn, generic;
+    const float* wino_w[kMaxGroup];   // host side only: Winograd-packed weights per group (or null)
 };
 
 struct GnFinArgs {
@@ -66,6 +67,13 @@ struct Up4Args {
     int B, hl, wl, H, W, C;                                               // C classes incl. background
 };
 
+// Winograd F(2x2,3x3) convolution (3x3, stride 1, pad 1, NHWC, Cin % 8 == 0, Cout % 64 == 0)
+struct WinoArgs {
+    ConvPtrs p[kMaxGroup];   // .w = Winograd-packed weights [Cout/64][Cin/8][16][64][8]; .up unused
+    int B, H, W, Cin, Cout, relu, tbx, tby;   // tbx = ceil(ceil(W/2)/8), tby = ceil(ceil(H/2)/4) tile patches
+};
+int launch_conv_wino(const WinoArgs& a, int groups, hipStream_t s);
+int launch_wino_pack(const float* w_oihw, float* packed, int Cout, int Cin, hipStream_t s);
 int launch_conv(const ConvArgs& a, int groups, hipStream_t s);
 int launch_conv_splitk_epilogue(const ConvArgs& a, int groups, hipStream_t s);
 int launch_maxpool3x3s2(const float* in, float* out, int B, int Hi, int Wi, int C, int Ho, int Wo, hipStream_t s);

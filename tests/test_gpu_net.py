@@ -91,6 +91,11 @@ CONV_CASES = [
     (2, 3, 64, 96, 64, 7, 2, 3, (0, 0, 0), "stem"),             # 7x7/2 on the NCHW image (generic loader)
     (1, 128, 12, 16, 7, 1, 1, 0, (64, 64, 1), "bias"),          # Cout not a multiple of anything
     (1, 32, 9, 11, 24, 3, 1, 1, (64, 64, 1), "bias_relu"),
+    # Winograd F(2x2,3x3) kernel (nsplit = -1 requests it)
+    (1, 64, 30, 40, 64, 3, 1, 1, (0, 0, -1), "bn_relu_res"),
+    (2, 256, 15, 20, 128, 3, 1, 1, (0, 0, -1), "gn"),            # odd height: half-empty last tile row
+    (1, 128, 34, 50, 128, 3, 1, 1, (0, 0, -1), "gn"),            # ragged tile patches in both directions
+    (1, 8, 7, 9, 64, 3, 1, 1, (0, 0, -1), "bias_relu"),
 ]
 
 
