@@ -200,59 +200,103 @@ __global__ __launch_bounds__(256, 2) void k_conv_igemm(const ConvArgs a) {
         __syncthreads();
     }
 
-    // C/D layout of the 32x32 tile: column = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
-    if (nsplit > 1) {
-        float* ws = a.splitk_ws +
-                    ((((size_t)blockIdx.y * nsplit + sp) * nB + b) * ((size_t)mtiles * BM)) * Npad;
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                int n = n0 + wn * (BN / 2) + j * 32 + li;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    int p = m0 + wm * (BM / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                    ws[(size_t)p * Npad + n] = acc[i][j][r];
-                }
-            }
-        return;
-    }
+    // C/D layout of the 32x32 tile: column = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5),
+    // i.e. a lane holds 16 rows of ONE channel.  Each wave transposes its tile through a private LDS
+    // patch (the operand buffers are free after the last barrier) so that a lane owns 4 consecutive
+    // channels of 4 rows: every global access of the epilogue is then 16 bytes per lane and a row's
+    // 32 channels are one 128-byte segment (scalar 4-byte stores made the 1x1 laterals store-issue bound).
+    constexpr int kTS = 36;                                   // floats per transposed row
+    float* tp = lds + wave * 32 * kTS;
+    const int trow = lane >> 3, tc4 = (lane & 7) * 4;         // rows trow + 8k (k < 4), channels tc4 .. tc4+3
+    const bool vec = (Cout & 3) == 0;
     const int Wu = Wo >> 1, Hu = a.Ho >> 1;
+    float* ws = nsplit > 1 ? a.splitk_ws + ((((size_t)blockIdx.y * nsplit + sp) * nB + b) * ((size_t)mtiles * BM)) * Npad
+                           : nullptr;
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
-            int n = n0 + wn * (BN / 2) + j * 32 + li;
-            bool nv = n < Cout;
-            float sc = (P.scale && nv) ? P.scale[n] : 1.f;
-            float sh = (P.shift && nv) ? P.shift[n] : 0.f;
-            int prow = m0 + wm * (BM / 2) + i * 32;
-            float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                int p = prow + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                if (p < HoWo && nv) {
-                    float v = acc[i][j][r];
-                    if (P.scale) v = v * sc;
-                    v = v + sh;
+            for (int r = 0; r < 16; ++r) tp[((r & 3) + 8 * (r >> 2) + 4 * lh) * kTS + li] = acc[i][j][r];
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // same wave: LDS ops complete in order
+            f32x4 v[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v[k] = *reinterpret_cast<const f32x4*>(tp + (trow + 8 * k) * kTS + tc4);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // reads done before the next tile overwrites the patch
+            const int prow = m0 + wm * (BM / 2) + i * 32;
+            const int n = n0 + wn * (BN / 2) + j * 32 + tc4;
+            if (ws) {                                          // split-K: raw partial sums, padded rows / columns exist
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    *reinterpret_cast<f32x4*>(ws + (size_t)(prow + trow + 8 * k) * Npad + n) = v[k];
+                continue;
+            }
+            f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};
+            if (vec) {
+                const bool nv = n < Cout;
+                f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
+                if (nv && P.scale) sc = *reinterpret_cast<const f32x4*>(P.scale + n);
+                if (nv && P.shift) sh = *reinterpret_cast<const f32x4*>(P.shift + n);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    int p = prow + trow + 8 * k;
+                    if (!(nv && p < HoWo)) continue;
+                    f32x4 x = v[k];
+                    if (P.scale) x = x * sc;
+                    x = x + sh;
                     size_t o = ((size_t)b * HoWo + p) * Cout + n;
-                    if (P.res) v += P.res[o];
+                    if (P.res) x += *reinterpret_cast<const f32x4*>(P.res + o);
                     if (P.up) {
                         int ho = p / Wo, wo = p - ho * Wo;
-                        v += P.up[(((size_t)b * Hu + (ho >> 1)) * Wu + (wo >> 1)) * Cout + n];
+                        x += *reinterpret_cast<const f32x4*>(P.up + (((size_t)b * Hu + (ho >> 1)) * Wu + (wo >> 1)) * Cout + n);
                     }
-                    if (a.relu) v = fmaxf(v, 0.f);
-                    P.out[o] = v;
-                    s1 += v; s2 += v * v;
+                    if (a.relu) { x[0] = fmaxf(x[0], 0.f); x[1] = fmaxf(x[1], 0.f); x[2] = fmaxf(x[2], 0.f); x[3] = fmaxf(x[3], 0.f); }
+                    *reinterpret_cast<f32x4*>(P.out + o) = x;
+                    s1 += x;
+                    s2 += x * x;
+                }
+            } else {                                           // any Cout: scalar accesses
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    int p = prow + trow + 8 * k;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        int ne = n + e;
+                        if (!(ne < Cout && p < HoWo)) continue;
+                        float x = v[k][e];
+                        if (P.scale) x = x * P.scale[ne];
+                        if (P.shift) x = x + P.shift[ne];
+                        size_t o = ((size_t)b * HoWo + p) * Cout + ne;
+                        if (P.res) x += P.res[o];
+                        if (P.up) {
+                            int ho = p / Wo, wo = p - ho * Wo;
+                            x += P.up[(((size_t)b * Hu + (ho >> 1)) * Wu + (wo >> 1)) * Cout + ne];
+                        }
+                        if (a.relu) x = fmaxf(x, 0.f);
+                        P.out[o] = x;
+                        s1[e] += x;
+                        s2[e] += x * x;
+                    }
                 }
             }
             if (P.gn_part) {
-                s1 += __shfl_xor(s1, 32, 64);
-                s2 += __shfl_xor(s2, 32, 64);
-                if (lh == 0 && nv) {
+                // column sums over the tile's 32 rows: lanes with equal (lane & 7) hold the same channels
+#pragma unroll
+                for (int o = 8; o < 64; o <<= 1) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        s1[e] += __shfl_xor(s1[e], o, 64);
+                        s2[e] += __shfl_xor(s2[e], o, 64);
+                    }
+                }
+                if (lane < 8) {
                     int P32 = mtiles * (BM / 32);
-                    float* g = P.gn_part + (((size_t)b * P32 + prow / 32) * Cout + n) * 2;
-                    g[0] = s1; g[1] = s2;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (n + e < Cout) {
+                            float* g = P.gn_part + (((size_t)b * P32 + prow / 32) * Cout + n + e) * 2;
+                            g[0] = s1[e]; g[1] = s2[e];
+                        }
                 }
             }
         }
@@ -459,7 +503,7 @@ __global__ __launch_bounds__(256) void k_gn_relu_up2(const GnUpArgs a) {
 //   logits_lowres[pixel][ch] = bias[ch] + sum_c merged[pixel][c] * W[ch][c]
 // One workgroup = 64 pixels of one image; merged tile and head weights live in LDS.
 // Dropout2d is the identity in eval mode.  grid (ceil(H2*W2/64), B, G).
-constexpr int kMhPx = 64;
+constexpr int kMhPx = 32;
 constexpr int kMhMaxC = 128;
 constexpr int kMhMaxCh = 32;
 
@@ -471,31 +515,44 @@ __global__ __launch_bounds__(256) void k_merge_head(const MergeHeadArgs a) {
     const int ch = a.ch[z], chp = a.chp[z];
     for (int i = threadIdx.x; i < ch * C; i += 256) s_w[i / C][i % C] = a.hw[z][i];
     const int p0 = blockIdx.x * kMhPx;
+    // C4 divides 256 (C = 128): a thread's channel quad is fixed, its GroupNorm affines are loaded once
+    const int c4f = threadIdx.x % C4;
+    f32x4 la[3], lb[3], ha, hb;
+    {
+        float4 sa, sb;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            load_affine4(a.a_lo[z][k] + ((size_t)b * C + 4 * c4f) * 2, sa, sb);
+            la[k] = f32x4{sa.x, sa.y, sa.z, sa.w}; lb[k] = f32x4{sb.x, sb.y, sb.z, sb.w};
+        }
+        load_affine4(a.a_hi[z] + ((size_t)b * C + 4 * c4f) * 2, sa, sb);
+        ha = f32x4{sa.x, sa.y, sa.z, sa.w}; hb = f32x4{sb.x, sb.y, sb.z, sb.w};
+    }
+    auto gnr = [](const float* ptr, f32x4 sa, f32x4 sb) {
+        f32x4 v = *reinterpret_cast<const f32x4*>(ptr) * sa + sb;
+        v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f);
+        return v;
+    };
+#pragma unroll 2
     for (int e = threadIdx.x; e < kMhPx * C4; e += 256) {
         int c4 = e % C4, pl = e / C4;
         int p = p0 + pl;
-        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
         if (p < H2 * W2) {
             int y = p / W2, x = p - y * W2;
             Lerp ly = lerp_coord(y, a.h, H2), lx = lerp_coord(x, a.w, W2);
 #pragma unroll
             for (int k = 0; k < 3; ++k) {
-                float4 sa, sb;
-                load_affine4(a.a_lo[z][k] + ((size_t)b * C + 4 * c4) * 2, sa, sb);
                 const float* base = a.t_lo[z][k] + (size_t)b * a.h * a.w * C + 4 * c4;
-                float4 v00 = gn_relu4(base + ((size_t)ly.i0 * a.w + lx.i0) * C, sa, sb);
-                float4 v01 = gn_relu4(base + ((size_t)ly.i0 * a.w + lx.i1) * C, sa, sb);
-                float4 v10 = gn_relu4(base + ((size_t)ly.i1 * a.w + lx.i0) * C, sa, sb);
-                float4 v11 = gn_relu4(base + ((size_t)ly.i1 * a.w + lx.i1) * C, sa, sb);
-                float4 u = bilerp4(v00, v01, v10, v11, ly, lx);
-                acc.x += u.x; acc.y += u.y; acc.z += u.z; acc.w += u.w;
+                f32x4 v00 = gnr(base + ((size_t)ly.i0 * a.w + lx.i0) * C, la[k], lb[k]);
+                f32x4 v01 = gnr(base + ((size_t)ly.i0 * a.w + lx.i1) * C, la[k], lb[k]);
+                f32x4 v10 = gnr(base + ((size_t)ly.i1 * a.w + lx.i0) * C, la[k], lb[k]);
+                f32x4 v11 = gnr(base + ((size_t)ly.i1 * a.w + lx.i1) * C, la[k], lb[k]);
+                acc += ly.l0 * (lx.l0 * v00 + lx.l1 * v01) + ly.l1 * (lx.l0 * v10 + lx.l1 * v11);
             }
-            float4 sa, sb;
-            load_affine4(a.a_hi[z] + ((size_t)b * C + 4 * c4) * 2, sa, sb);
-            float4 u = gn_relu4(a.t_hi[z] + ((size_t)b * H2 * W2 + p) * C + 4 * c4, sa, sb);
-            acc.x += u.x; acc.y += u.y; acc.z += u.z; acc.w += u.w;
+            acc += gnr(a.t_hi[z] + ((size_t)b * H2 * W2 + p) * C + 4 * c4, ha, hb);
         }
-        *reinterpret_cast<float4*>(&s_m[pl][4 * c4]) = acc;
+        *reinterpret_cast<f32x4*>(&s_m[pl][4 * c4]) = acc;
     }
     __syncthreads();
     // head: lanes along the pixel axis read LDS rows at stride C+4 (conflict-free), weights broadcast
@@ -586,6 +643,86 @@ __global__ __launch_bounds__(256) void k_up4_compress(const Up4Args a) {
         if (a.o_z) a.o_z[((size_t)b * G + k) * HW + p] = u;
         if (k == g) zz = u;
     }
+    float nq = sqrtf(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+    if (nq == 0.0f) nq = 1.0f;
+    float nv = sqrtf(vxy[0] * vxy[0] + vxy[1] * vxy[1]);
+    if (nv == 0.0f) nv = 1.0f;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) a.cq[((size_t)b * 4 + e) * HW + p] = q[e] / nq;
+#pragma unroll
+    for (int e = 0; e < 3; ++e) a.cs[((size_t)b * 3 + e) * HW + p] = sc[e];
+#pragma unroll
+    for (int e = 0; e < 2; ++e) a.cxy[((size_t)b * 2 + e) * HW + p] = vxy[e] / nv;
+    a.cz[(size_t)b * HW + p] = zz;
+}
+
+// The same for the reference's 7 classes (bg + 6): every channel index is a compile-time constant, so the
+// four low-res taps are fetched as 18 float4 (channel strides 8 / 24 / 20 / 20, 16-byte aligned pixels)
+// instead of 67 scalars each, and all 67 interpolated values stay in registers.
+__global__ __launch_bounds__(256) void k_up4_compress7(const Up4Args a) {
+    const int b = blockIdx.z, y = blockIdx.y;
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    if (x >= a.W) return;
+    constexpr int C = 7, G = 6;
+    const int HW = a.H * a.W;
+    const size_t p = (size_t)y * a.W + x;
+    Lerp ly = lerp_coord(y, a.hl, a.H), lx = lerp_coord(x, a.wl, a.W);
+    const size_t t00 = ((size_t)b * a.hl + ly.i0) * a.wl + lx.i0, t01 = ((size_t)b * a.hl + ly.i0) * a.wl + lx.i1;
+    const size_t t10 = ((size_t)b * a.hl + ly.i1) * a.wl + lx.i0, t11 = ((size_t)b * a.hl + ly.i1) * a.wl + lx.i1;
+    auto quad = [&](const float* L, int stride, int q) {
+        f32x4 v00 = *reinterpret_cast<const f32x4*>(L + t00 * stride + 4 * q);
+        f32x4 v01 = *reinterpret_cast<const f32x4*>(L + t01 * stride + 4 * q);
+        f32x4 v10 = *reinterpret_cast<const f32x4*>(L + t10 * stride + 4 * q);
+        f32x4 v11 = *reinterpret_cast<const f32x4*>(L + t11 * stride + 4 * q);
+        return ly.l0 * (lx.l0 * v00 + lx.l1 * v01) + ly.l1 * (lx.l0 * v10 + lx.l1 * v11);
+    };
+    float vm[8], vq[24], vt[20], vs[20];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) { f32x4 r = quad(a.lm, 8, q); vm[4 * q] = r[0]; vm[4 * q + 1] = r[1]; vm[4 * q + 2] = r[2]; vm[4 * q + 3] = r[3]; }
+#pragma unroll
+    for (int q = 0; q < 6; ++q) { f32x4 r = quad(a.lq, 24, q); vq[4 * q] = r[0]; vq[4 * q + 1] = r[1]; vq[4 * q + 2] = r[2]; vq[4 * q + 3] = r[3]; }
+#pragma unroll
+    for (int q = 0; q < 5; ++q) { f32x4 r = quad(a.lt, 20, q); vt[4 * q] = r[0]; vt[4 * q + 1] = r[1]; vt[4 * q + 2] = r[2]; vt[4 * q + 3] = r[3]; }
+#pragma unroll
+    for (int q = 0; q < 5; ++q) { f32x4 r = quad(a.ls, 20, q); vs[4 * q] = r[0]; vs[4 * q + 1] = r[1]; vs[4 * q + 2] = r[2]; vs[4 * q + 3] = r[3]; }
+    // arg-max of the log-softmax, first maximal index on ties (as class_compress.hip)
+    float mx = vm[0];
+#pragma unroll
+    for (int c = 1; c < C; ++c) mx = fmaxf(mx, vm[c]);
+    float sum = 0.f;
+#pragma unroll
+    for (int c = 0; c < C; ++c) sum += expf(vm[c] - mx);
+    float lse = logf(sum);
+    float best = (vm[0] - mx) - lse;
+    int cls = 0;
+#pragma unroll
+    for (int c = 1; c < C; ++c) {
+        float val = (vm[c] - mx) - lse;
+        if (val > best) { best = val; cls = c; }
+    }
+    a.cat_mask[(size_t)b * HW + p] = cls;
+    if (a.o_mask) {
+#pragma unroll
+        for (int c = 0; c < C; ++c) a.o_mask[((size_t)b * C + c) * HW + p] = vm[c];
+#pragma unroll
+        for (int c = 0; c < 4 * G; ++c) a.o_quat[((size_t)b * 4 * G + c) * HW + p] = vq[c];
+#pragma unroll
+        for (int c = 0; c < 3 * G; ++c) a.o_scales[((size_t)b * 3 * G + c) * HW + p] = vs[c];
+#pragma unroll
+        for (int k = 0; k < G; ++k) {
+            a.o_xy[((size_t)b * 2 * G + 2 * k) * HW + p] = vt[3 * k];
+            a.o_xy[((size_t)b * 2 * G + 2 * k + 1) * HW + p] = vt[3 * k + 1];
+            a.o_z[((size_t)b * G + k) * HW + p] = vt[3 * k + 2];
+        }
+    }
+    float q[4] = {0, 0, 0, 0}, sc[3] = {0, 0, 0}, vxy[2] = {0, 0}, zz = 0.f;
+#pragma unroll
+    for (int k = 0; k < G; ++k)
+        if (k == cls - 1) {
+            q[0] = vq[4 * k]; q[1] = vq[4 * k + 1]; q[2] = vq[4 * k + 2]; q[3] = vq[4 * k + 3];
+            sc[0] = vs[3 * k]; sc[1] = vs[3 * k + 1]; sc[2] = vs[3 * k + 2];
+            vxy[0] = vt[3 * k]; vxy[1] = vt[3 * k + 1]; zz = vt[3 * k + 2];
+        }
     float nq = sqrtf(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
     if (nq == 0.0f) nq = 1.0f;
     float nv = sqrtf(vxy[0] * vxy[0] + vxy[1] * vxy[1]);
@@ -705,7 +842,7 @@ int launch_gn_relu_up2(const GnUpArgs& a, int groups, hipStream_t s) {
 }
 
 int launch_merge_head(const MergeHeadArgs& a, int groups, hipStream_t s) {
-    if (a.C > kMhMaxC || a.C % 4 != 0) return FPC_EINVAL;
+    if (a.C > kMhMaxC || a.C % 4 != 0 || 256 % (a.C / 4) != 0) return FPC_EINVAL;
     for (int z = 0; z < groups; ++z)
         if (a.ch[z] > kMhMaxCh || a.chp[z] > kMhMaxCh || a.chp[z] < a.ch[z]) return FPC_EINVAL;
     hipLaunchKernelGGL(k_merge_head, dim3(cdiv(4 * a.h * a.w, kMhPx), a.B, groups), dim3(256), 0, s, a);
@@ -715,7 +852,9 @@ int launch_merge_head(const MergeHeadArgs& a, int groups, hipStream_t s) {
 int launch_up4_compress(const Up4Args& a, hipStream_t s) {
     if (a.C < 2 || a.C > 32 || a.H > 65535 || a.B > 65535) return FPC_EINVAL;
     dim3 grid(cdiv(a.W, 256), a.H, a.B);
-    if (a.C <= 8) hipLaunchKernelGGL(k_up4_compress<8>, grid, dim3(256), 0, s, a);
+    if (a.C == 7 && a.pm == 8 && a.pq == 24 && a.pt == 20 && a.ps == 20)
+        hipLaunchKernelGGL(k_up4_compress7, dim3(cdiv(a.W, 128), a.H, a.B), dim3(128), 0, s, a);
+    else if (a.C <= 8) hipLaunchKernelGGL(k_up4_compress<8>, grid, dim3(256), 0, s, a);
     else hipLaunchKernelGGL(k_up4_compress<32>, grid, dim3(256), 0, s, a);
     return check_launch();
 }

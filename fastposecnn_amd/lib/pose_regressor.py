@@ -53,9 +53,16 @@ class Model(object):
     def hough_voting(self, agg_data):
         return self.hough_voting_layer(agg_data)
 
+    def _inv_k(self, dev):
+        """Inverse intrinsics resident on `dev` (moved once, as forward() does at :749-751)."""
+        if self.intrinsics.device != dev:
+            self.intrinsics = self.intrinsics.to(dev)
+            self.inv_intrinsics = torch.inverse(self.intrinsics)
+        return self.inv_intrinsics
+
     @RT_CAL_TIMER
     def perform_RT_calculation(self, agg_data):
-        return gtf.samplewise_get_RT(agg_data, self.inv_intrinsics)
+        return gtf.samplewise_get_RT(agg_data, self._inv_k(agg_data['quaternion'].device))
 
     def agg_hough_and_generate_RT(self, categorical_data) -> Union[None, dict]:
         if not self.HPARAM.PERFORM_AGGREGATION:
@@ -81,7 +88,7 @@ class Model(object):
             agg, n_dev = self.aggregation_layer.forward_deferred(categorical_data, cap)
             agg = self.hough_voting_layer(agg, n_dev=n_dev, seed=seed)
             if self.HPARAM.PERFORM_RT_CALCULATION:
-                agg = gtf.samplewise_get_RT(agg, self.inv_intrinsics)
+                agg = gtf.samplewise_get_RT(agg, self._inv_k(agg['quaternion'].device))
             n = int(n_dev.item())
             if n <= cap:
                 break
@@ -255,9 +262,7 @@ class PoseRegressor(Model, torch.nn.Module):
 
     @FORWARD_TIMER
     def forward(self, x: torch.Tensor):
-        if self.intrinsics.device != x.device:
-            self.intrinsics = self.intrinsics.to(x.device)
-            self.inv_intrinsics = torch.inverse(self.intrinsics)
+        self._inv_k(x.device)
         logits = self.pure_model_forward(x)
         categorical_data = self.class_compression(logits)
         agg_pred = self.agg_hough_and_generate_RT(categorical_data)
