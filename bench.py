@@ -48,6 +48,7 @@ def parse():
     ap.add_argument("--encoder", default="resnet18")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--vote-only", action="store_true", help="time only the post-network stages (profiling aid)")
+    ap.add_argument("--no-pipeline", action="store_true", help="finish every frame before starting the next (latency mode)")
     return ap.parse_args()
 
 
@@ -113,18 +114,39 @@ def main():
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
     vote_ms = []
 
-    def step():
-        """One frame: backbone + class compression on the image, then aggregation -> hough voting -> RT on
-        the vote-bench frame through Model.agg_hough_and_generate_RT (capacity-sized buffers, instance
-        count kept on the device, ONE host read at the end of the frame)."""
-        with torch.no_grad():
-            if not args.vote_only:
-                logits = model_gpu.pure_model_forward(x)
-                model_gpu.class_compression(logits)
-            agg = model_gpu.agg_hough_and_generate_RT(cat)
-            if world > 1:
-                parallel.all_gather_pose_records(agg, rank, cap)
+    # Two HIP streams: the network of frame i+1 (stream A) overlaps the small, latency-bound
+    # post-network kernels of frame i (stream B).  Every frame still does all of its work and its
+    # results are complete (instance count read back, tensors trimmed) one step later.
+    s_net, s_post = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)
+    pending = []
+
+    def finish(ticket):
+        agg = model_gpu.post_network_finish(ticket)
+        if world > 1:
+            parallel.all_gather_pose_records(agg, rank, cap)
         return agg
+
+    def step(pipelined=True):
+        """One frame: backbone + class compression on the image (stream A), then aggregation -> hough
+        voting -> RT on the vote-bench frame (stream B, after the network's event); the previous
+        frame is finished (one host wait on ITS event) while this one runs."""
+        with torch.no_grad():
+            with torch.cuda.stream(s_net):
+                if not args.vote_only:
+                    logits = model_gpu.pure_model_forward(x)
+                    model_gpu.class_compression(logits)
+                ev_net = torch.cuda.Event()
+                ev_net.record()
+            with torch.cuda.stream(s_post):
+                s_post.wait_event(ev_net)
+                pending.append(model_gpu.post_network_enqueue(cat))
+            if len(pending) > (1 if (pipelined and not args.no_pipeline) else 0):
+                return finish(pending.pop(0))
+        return None
+
+    def drain():
+        while pending:
+            finish(pending.pop(0))
 
     def vote_probe():
         """HIP events around the hough-voting enqueue alone (its inputs produced just before)."""
@@ -142,16 +164,27 @@ def main():
 
     for _ in range(args.warmup):
         step()
+    drain()
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
+    drain()
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+
+    # per-frame latency with ONE frame in flight (not the headline number)
+    nlat = max(5, min(args.steps, 20))
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    for _ in range(nlat):
+        step(pipelined=False)
+    torch.cuda.synchronize()
+    latency_ms = (time.perf_counter() - t1) / nlat * 1e3
 
     # vote roofline: separate, untimed-for-throughput loop with HIP events around the vote call
     for _ in range(max(5, min(args.steps, 30))):
@@ -172,7 +205,9 @@ def main():
             "config": {"workload": f"{args.encoder}-FPN + all heads, batch=1 640x480 per GPU, hn={args.hn}, "
                                    f"{n_inst} instances/frame (vote-bench fixture), random-init weights",
                        "global_batch": world, "parallelism": f"image-sharded dp{world}" if world > 1 else "single GPU",
-                       "vote_only": bool(args.vote_only)},
+                       "vote_only": bool(args.vote_only),
+                       "frames_in_flight": 1 if args.no_pipeline else 2,
+                       "ms_per_frame_one_in_flight": round(latency_ms, 4)},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": None,
                          "kernel": "fpc_ransac_voting_v3 launch sequence (k_chunk_count..k_select_refine)",

@@ -80,19 +80,39 @@ class Model(object):
         """aggregate -> hough voting -> RT enqueued back to back on capacity-sized buffers, the instance
         count staying on the device (the reference synchronises >= 3 + rounds times PER INSTANCE,
         RV/ransac_voting_gpu.py:532-581); ONE host read at the end trims every tensor to [:n].
-        Same dict as the stage-by-stage path.  If more than `capacity` instances exist the stages are
-        simply re-run at the exact size."""
-        cap = int(getattr(self.HPARAM, 'MAX_INSTANCES', 32)) * categorical_data['mask'].shape[0]
-        seed = int(torch.randint(0, 2 ** 62, (1,)).item())      # one draw, also when the stages are re-run
-        while True:
-            agg, n_dev = self.aggregation_layer.forward_deferred(categorical_data, cap)
-            agg = self.hough_voting_layer(agg, n_dev=n_dev, seed=seed)
-            if self.HPARAM.PERFORM_RT_CALCULATION:
-                agg = gtf.samplewise_get_RT(agg, self._inv_k(agg['quaternion'].device))
-            n = int(n_dev.item())
-            if n <= cap:
-                break
-            cap = n
+        Same dict as the stage-by-stage path."""
+        return self.post_network_finish(self.post_network_enqueue(categorical_data))
+
+    def post_network_enqueue(self, categorical_data, capacity=None, seed=None):
+        """Enqueues aggregate -> hough voting -> RT on the CURRENT stream without any host read and
+        returns a ticket for `post_network_finish`.  A caller that streams frames can enqueue the next
+        frame's network before finishing this one (bench.py runs the two on separate HIP streams)."""
+        B = categorical_data['mask'].shape[0]
+        cap = int(capacity) if capacity else int(getattr(self.HPARAM, 'MAX_INSTANCES', 32)) * B
+        if seed is None:
+            seed = int(torch.randint(0, 2 ** 62, (1,)).item())      # one draw, also if the stages are re-run
+        agg, n_dev = self.aggregation_layer.forward_deferred(categorical_data, cap)
+        agg = self.hough_voting_layer(agg, n_dev=n_dev, seed=seed)
+        if self.HPARAM.PERFORM_RT_CALCULATION:
+            agg = gtf.samplewise_get_RT(agg, self._inv_k(agg['quaternion'].device))
+        # asynchronous read-back of the instance count into pinned memory + an event to wait on
+        pool = self.__dict__.setdefault('_pinned_counts', [])
+        if len(pool) < 8:
+            pool.append(torch.empty(1, dtype=torch.int32).pin_memory())
+        slot = self.__dict__['_pinned_next'] = (self.__dict__.get('_pinned_next', -1) + 1) % len(pool)
+        n_host = pool[slot]
+        n_host.copy_(n_dev, non_blocking=True)
+        event = torch.cuda.Event()
+        event.record()
+        return {'agg': agg, 'n_host': n_host, 'event': event, 'cat': categorical_data, 'cap': cap, 'seed': seed}
+
+    def post_network_finish(self, ticket):
+        """Waits for the ticket's work (only), trims every tensor to the n instances found."""
+        ticket['event'].synchronize()
+        n = int(ticket['n_host'][0])
+        if n > ticket['cap']:       # more instances than the capacity: run again at the exact size
+            return self.post_network_finish(self.post_network_enqueue(ticket['cat'], capacity=n, seed=ticket['seed']))
+        agg = ticket['agg']
         if n == 0:
             agg['class_ids'] = agg['class_ids'].float()      # reference: float class ids when empty (:116)
         return {k: v[:n] for k, v in agg.items()}
