@@ -358,11 +358,14 @@ int launch_conv_plan(ConvArgs& a, const ConvPlan& p, int groups, hipStream_t s) 
             w.p[g] = a.p[g];
             w.p[g].w = a.wino_w[g];
         }
+        w.variant = p.wino == 3 ? 1 : 0;
+        w.groups = groups;
         w.B = a.B; w.H = a.Ho; w.W = a.Wo; w.Cin = a.Cin; w.Cout = a.Cout; w.relu = a.relu;
-        w.tbx = cdiv(cdiv(a.Wo, 2), 8); w.tby = cdiv(cdiv(a.Ho, 2), 4);
+        w.waves = p.wino == 2 ? 8 : 4;
+        w.tbx = cdiv(cdiv(a.Wo, 2), 8); w.tby = cdiv(cdiv(a.Ho, 2), w.waves);
         return launch_conv_wino(w, groups, s);
     }
-    a.bm = p.bm; a.bn = p.bn; a.nsplit = p.nsplit; a.mtiles = p.mtiles; a.ntiles = p.ntiles;
+    a.bm = p.bm; a.bn = p.bn; a.nsplit = p.nsplit; a.mtiles = p.mtiles; a.ntiles = p.ntiles; a.groups = groups;
     int rc = launch_conv(a, groups, s);
     if (rc) return rc;
     if (a.nsplit > 1) rc = launch_conv_splitk_epilogue(a, groups, s);
@@ -371,7 +374,7 @@ int launch_conv_plan(ConvArgs& a, const ConvPlan& p, int groups, hipStream_t s) 
 
 // number of GroupNorm partial rows per image a plan writes
 int plan_gn_rows(const ConvPlan& p, int Ho, int Wo) {
-    return p.wino ? cdiv(cdiv(Wo, 2), 8) * cdiv(cdiv(Ho, 2), 4) : p.mtiles * p.bm / 32;
+    return p.wino ? cdiv(cdiv(Wo, 2), 8) * cdiv(cdiv(Ho, 2), p.wino == 2 ? 8 : 4) : p.mtiles * p.bm / 32;
 }
 
 // Runs conv site `ci` with its current plan; in tuning mode first times every candidate tiling
@@ -384,7 +387,12 @@ int run_conv(fpc_net* n, ConvArgs& a, int groups, int ci, hipStream_t s) {
         ConvPlan best = n->cplan[ci];
         size_t cap = n->splitk_floats;
         std::vector<ConvPlan> cands = conv_candidates(a.Ho * a.Wo, a.B, a.Cout, a.ksteps, groups);
-        if (a.wino_w[0] && !a.p[0].up) { ConvPlan wq; wq.wino = 1; cands.push_back(wq); }
+        if (a.wino_w[0] && !a.p[0].up) {
+            ConvPlan wq;
+            wq.wino = 1; cands.push_back(wq);
+            wq.wino = 2; cands.push_back(wq);
+            wq.wino = 3; cands.push_back(wq);
+        }
         for (const ConvPlan& q : cands) {
             if (splitk_floats_for(q, groups, a.B, a.Npad) > cap) continue;
             int rc = launch_conv_plan(a, q, groups, s);     // warm-up (also validates the launch)
@@ -589,7 +597,7 @@ extern "C" int fpc_net_autotune_next(fpc_net_t* n) {
 extern "C" int fpc_net_conv_count(const fpc_net_t* n) { return n ? (int)n->convs.size() : 0; }
 extern "C" int fpc_net_conv_plan(const fpc_net_t* n, int i, int* out5) {
     if (!n || !out5 || i < 0 || i >= (int)n->convs.size()) return FPC_EINVAL;
-    out5[0] = n->cplan[i].bm; out5[1] = n->cplan[i].bn; out5[2] = n->cplan[i].wino ? -1 : n->cplan[i].nsplit;
+    out5[0] = n->cplan[i].bm; out5[1] = n->cplan[i].bn; out5[2] = n->cplan[i].wino ? -n->cplan[i].wino : n->cplan[i].nsplit;
     out5[3] = n->convs[i].Cout; out5[4] = n->convs[i].K;
     return FPC_OK;
 }
@@ -629,7 +637,7 @@ extern "C" int fpc_conv2d_plan(int B, int Ho, int Wo, int Cin, int Cout, int Kh,
     if (!out4) return FPC_EINVAL;
     int Kpad = cdiv(Cin * Kh * Kw, kConvBK) * kConvBK;
     ConvPlan p = plan_conv(Ho * Wo, B, Cout, Kpad / kConvBK, 1, bm, bn, nsplit);
-    if (nsplit == -1) { p.wino = 1; p.nsplit = -1; }
+    if (nsplit <= -1 && nsplit >= -3) { p.wino = -nsplit; p.nsplit = nsplit; }
     out4[0] = p.bm; out4[1] = p.bn; out4[2] = p.nsplit; out4[3] = plan_gn_rows(p, Ho, Wo);
     return FPC_OK;
 }
@@ -648,8 +656,8 @@ extern "C" int fpc_conv2d(const float* in, int64_t sb, int64_t sh, int64_t sw, i
     hipStream_t s = (hipStream_t)stream;
     float* packed = (float*)ws;
     FPC_TRY(launch_pack_weight(w_oihw, packed, Cout, Cin, Cin, Kh, Kw, c.Npad, c.Kpad, s));
-    bool wino = nsplit == -1;
-    ConvPlan p = plan_conv(Ho * Wo, B, Cout, c.Kpad / kConvBK, 1, bm, bn, wino ? 1 : nsplit);
+    bool wino = nsplit <= -1 && nsplit >= -3;      // -1: 4 waves, -2: 8 waves, -3: 4 waves, wave-private K loop
+    ConvPlan p = plan_conv(Ho * Wo, B, Cout, c.Kpad / kConvBK, 1, wino ? 0 : bm, bn, wino ? 1 : nsplit);
     int mode = (sc == 1 && Cin % kConvBK == 0) ? 0
                : (sc == 1 && Cin % 4 == 0 && sw % 4 == 0 && sh % 4 == 0 && sb % 4 == 0 && ((uintptr_t)in & 15) == 0) ? 2 : 1;
     fpc_net tmp;
@@ -666,7 +674,7 @@ extern "C" int fpc_conv2d(const float* in, int64_t sb, int64_t sh, int64_t sw, i
         float* wp = packed + tmp.splitk_off + (size_t)32 * B * (cdiv(Ho * Wo, 128) * 128) * c.Npad;
         FPC_TRY(launch_wino_pack(w_oihw, wp, Cout, Cin, s));
         a.wino_w[0] = wp;
-        p.wino = 1;
+        p.wino = -nsplit;
         return launch_conv_plan(a, p, 1, s);
     }
     return run_conv(nullptr, a, 1, 0, s);

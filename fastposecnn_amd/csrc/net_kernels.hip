@@ -26,11 +26,6 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));   // native vector: sta
 
 constexpr int kLdsRow = kConvBK + 4;   // 36 floats: 16 distinct 16-byte slots for 16 consecutive rows
 
-__device__ __forceinline__ int xcd_swizzle(int bid, int nwg) {
-    // consecutive logical blocks on one XCD (shared L2): bijective for any nwg (guide T1)
-    int q = nwg >> 3, r = nwg & 7, x = bid & 7, k = bid >> 3;
-    return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + k;
-}
 
 // ------------------------------------------------------------------------------------------
 // implicit-GEMM convolution
@@ -100,16 +95,13 @@ __device__ __forceinline__ int xcd_swizzle(int bid, int nwg) {
             *reinterpret_cast<f32x4*>(Bs_ + (sr + 32 * i) * kLdsRow + 4 * sq) = rb[i];                       \
     } while (0)
 
+// (the 128x128 tiling keeps 64 accumulator + 64 staging registers per lane: one workgroup per CU, no spills)
 template <int BM, int BN, int MODE>
-__global__ __launch_bounds__(256, 2) void k_conv_igemm(const ConvArgs a) {
+__global__ __launch_bounds__(256, (BM * BN >= 128 * 128) ? 1 : 2) void k_conv_igemm(const ConvArgs a) {
     constexpr int TM = BM / 64, TN = BN / 64;     // 32x32 tiles per wave
     constexpr int AR = BM / 32, BR = BN / 32;     // float4 rows staged per thread
     __shared__ __attribute__((aligned(16))) float lds[2 * (BM + BN) * kLdsRow];
 
-    ConvPtrs P = a.p[0];
-    if (blockIdx.y == 1) P = a.p[1];
-    if (blockIdx.y == 2) P = a.p[2];
-    if (blockIdx.y == 3) P = a.p[3];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int li = lane & 31, lh = lane >> 5;
@@ -118,12 +110,21 @@ __global__ __launch_bounds__(256, 2) void k_conv_igemm(const ConvArgs a) {
     const int nsplit = a.nsplit, ksteps = a.ksteps;
     const long long in_sb = a.in_sb, in_sh = a.in_sh, in_sw = a.in_sw, in_sc = a.in_sc;
 
-    // block -> (m tile, image, n tile, k split); m fastest so neighbours share weights and halos
-    int bid = xcd_swizzle(blockIdx.x, gridDim.x);
-    const int mt = bid % mtiles; bid /= mtiles;
-    const int b = bid % nB; bid /= nB;
-    const int nt = bid % ntiles;
-    const int sp = bid / ntiles;
+    // Block order: the WEIGHT SLICE (group, n tile, k split) varies fastest, then the m tile.  Workgroups
+    // are dealt round-robin over the 8 XCDs, so blockIdx % 8 — hence the weight slice, whenever the slice
+    // count is 1, 2, 4 or a multiple of 8 — is fixed per XCD: an XCD's private L2 then holds ~1 MB of
+    // weights that every one of its workgroups re-reads, instead of all slices thrashing all L2s
+    // (measured before: 45-55 % L2 misses, ~5 TB/s of fabric reads for 85 MB of unique operands).
+    int bid = blockIdx.x;
+    const int sp = bid % nsplit; bid /= nsplit;
+    const int nt = bid % ntiles; bid /= ntiles;
+    const int grp = bid % a.groups; bid /= a.groups;
+    const int mt = bid % mtiles;
+    const int b = bid / mtiles;
+    ConvPtrs P = a.p[0];
+    if (grp == 1) P = a.p[1];
+    if (grp == 2) P = a.p[2];
+    if (grp == 3) P = a.p[3];
     const int HoWo = a.Ho * Wo;
     const int m0 = mt * BM, n0 = nt * BN;
     int ks0 = 0, ks1 = ksteps;
@@ -161,23 +162,45 @@ __global__ __launch_bounds__(256, 2) void k_conv_igemm(const ConvArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+    // Fragments of the next 8-deep k group are read from LDS BEFORE the current group's MFMAs are issued
+    // (sched_barrier keeps hipcc from sinking the reads to their first use): the ~128-cycle LDS latency
+    // is then hidden behind 8..32 MFMAs instead of stalling the wave four times per K-step.
+#define FPC_CONV_FRAG(KK, FA, FB)                                                                             \
+    do {                                                                                                      \
+        _Pragma("unroll") for (int i = 0; i < TM; ++i) FA[i] =                                                \
+            *reinterpret_cast<const f32x4*>(As + i * 32 * kLdsRow + (KK) * 8);                                \
+        _Pragma("unroll") for (int j = 0; j < TN; ++j) FB[j] =                                                \
+            *reinterpret_cast<const f32x4*>(Bs + j * 32 * kLdsRow + (KK) * 8);                                \
+    } while (0)
+    /* lanes 0-31 carry k = kk*8 + e, lanes 32-63 carry k = kk*8 + 4 + e: each MFMA sums two k */
+#define FPC_CONV_MFMA(FA, FB)                                                                                 \
+    do {                                                                                                      \
+        _Pragma("unroll") for (int e = 0; e < 4; ++e)                                                         \
+            _Pragma("unroll") for (int i = 0; i < TM; ++i)                                                    \
+                _Pragma("unroll") for (int j = 0; j < TN; ++j)                                                \
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(FA[i][e], FB[j][e], acc[i][j], 0, 0, 0); \
+    } while (0)
 #define FPC_CONV_COMPUTE(BUF)                                                                                  \
     do {                                                                                                      \
         const float* As = lds + (BUF) * (BM + BN) * kLdsRow + (wm * (BM / 2) + li) * kLdsRow + 4 * lh;        \
         const float* Bs = lds + (BUF) * (BM + BN) * kLdsRow + BM * kLdsRow + (wn * (BN / 2) + li) * kLdsRow + \
                           4 * lh;                                                                             \
-        _Pragma("unroll") for (int kk = 0; kk < kConvBK / 8; ++kk) {                                          \
-            f32x4 fa[TM], fb[TN];                                                                             \
-            _Pragma("unroll") for (int i = 0; i < TM; ++i) fa[i] =                                            \
-                *reinterpret_cast<const f32x4*>(As + i * 32 * kLdsRow + kk * 8);                              \
-            _Pragma("unroll") for (int j = 0; j < TN; ++j) fb[j] =                                            \
-                *reinterpret_cast<const f32x4*>(Bs + j * 32 * kLdsRow + kk * 8);                              \
-            /* lanes 0-31 carry k = kk*8 + e, lanes 32-63 carry k = kk*8 + 4 + e: each MFMA sums two k */     \
-            _Pragma("unroll") for (int e = 0; e < 4; ++e)                                                     \
-                _Pragma("unroll") for (int i = 0; i < TM; ++i)                                                \
-                    _Pragma("unroll") for (int j = 0; j < TN; ++j)                                            \
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][e], fb[j][e], acc[i][j], 0, 0, 0); \
-        }                                                                                                     \
+        f32x4 fa0[TM], fb0[TN], fa1[TM], fb1[TN];                                                             \
+        FPC_CONV_FRAG(0, fa0, fb0);                                                                           \
+        FPC_CONV_FRAG(1, fa1, fb1);                                                                           \
+        __builtin_amdgcn_sched_barrier(0);                                                                    \
+        __builtin_amdgcn_s_setprio(1);                                                                        \
+        FPC_CONV_MFMA(fa0, fb0);                                                                              \
+        __builtin_amdgcn_sched_barrier(0);                                                                    \
+        FPC_CONV_FRAG(2, fa0, fb0);                                                                           \
+        __builtin_amdgcn_sched_barrier(0);                                                                    \
+        FPC_CONV_MFMA(fa1, fb1);                                                                              \
+        __builtin_amdgcn_sched_barrier(0);                                                                    \
+        FPC_CONV_FRAG(3, fa1, fb1);                                                                           \
+        __builtin_amdgcn_sched_barrier(0);                                                                    \
+        FPC_CONV_MFMA(fa0, fb0);                                                                              \
+        FPC_CONV_MFMA(fa1, fb1);                                                                              \
+        __builtin_amdgcn_s_setprio(0);                                                                        \
     } while (0)
 
     if (ks0 < ks1) {
@@ -210,7 +233,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_igemm(const ConvArgs a) {
     const int trow = lane >> 3, tc4 = (lane & 7) * 4;         // rows trow + 8k (k < 4), channels tc4 .. tc4+3
     const bool vec = (Cout & 3) == 0;
     const int Wu = Wo >> 1, Hu = a.Ho >> 1;
-    float* ws = nsplit > 1 ? a.splitk_ws + ((((size_t)blockIdx.y * nsplit + sp) * nB + b) * ((size_t)mtiles * BM)) * Npad
+    float* ws = nsplit > 1 ? a.splitk_ws + ((((size_t)grp * nsplit + sp) * nB + b) * ((size_t)mtiles * BM)) * Npad
                            : nullptr;
 #pragma unroll
     for (int i = 0; i < TM; ++i)
@@ -785,7 +808,7 @@ __global__ void k_fold_bn(const float* __restrict__ gamma, const float* __restri
 
 template <int BM, int BN>
 static void launch_conv_t(const ConvArgs& a, int groups, hipStream_t s) {
-    dim3 grid(a.mtiles * a.B * a.ntiles * a.nsplit, groups);
+    dim3 grid(a.mtiles * a.B * a.ntiles * a.nsplit * groups);
     if (a.generic == 0)
         hipLaunchKernelGGL((k_conv_igemm<BM, BN, 0>), grid, dim3(256), 0, s, a);
     else if (a.generic == 2)
@@ -872,86 +895,54 @@ int launch_up4_compress(const Up4Args& a, hipStream_t s) {
 // its four V_xi fragments from 8 LDS reads + 8 vector adds, so the transformed input never exists in
 // memory.  The output transform runs through LDS (wave i holds row i of M) and feeds the same
 // epilogue as the direct kernel (BatchNorm / bias, residual, ReLU, GroupNorm partial sums).
-constexpr int kWinoTX = 8, kWinoTY = 4;                 // tile patch per workgroup
-constexpr int kWinoRW = 2 * kWinoTX + 2, kWinoRH = 2 * kWinoTY + 2;   // input region 18 x 10
-constexpr int kWinoPos = kWinoRW * kWinoRH;             // 180 positions
-constexpr int kWinoIS = 12;                             // floats per staged position (8 + pad)
+constexpr int kWinoTX = 8;                              // tile patch per workgroup: 8 wide, NW tall (NW = 4 or 8 waves)
+constexpr int kWinoRW = 2 * kWinoTX + 2;                // input region width 18
+constexpr int kWinoIS = 8;                              // floats per staged position (one 32-byte K-step slice)
 constexpr int kWinoBN = 64;
-constexpr int kWinoLdsIn = kWinoPos * kWinoIS;          // 2160 floats
-constexpr int kWinoLdsW = 16 * kWinoBN * 8;             // 8192 floats
-constexpr int kWinoLds = kWinoLdsIn + kWinoLdsW;        // 41.4 KB (the output transform reuses 32 KB of it)
+constexpr int kWinoLdsW = 16 * kWinoBN * 8;             // 8192 floats (32 KB) per weight buffer
 
-
-__global__ __launch_bounds__(256, 2) void k_conv_wino(const WinoArgs a) {
-    __shared__ __attribute__((aligned(16))) float lds[kWinoLds];
-    ConvPtrs P = a.p[0];
-    if (blockIdx.y == 1) P = a.p[1];
-    if (blockIdx.y == 2) P = a.p[2];
-    if (blockIdx.y == 3) P = a.p[3];
-    const int t = threadIdx.x, lane = t & 63, wi = t >> 6;     // wi = transform row of this wave
+// NW = 4: 32 tiles (16x8 output pixels) per workgroup, 2 workgroups per CU.
+// NW = 8: 64 tiles (16x16 pixels), waves 4-7 work on the lower half of the patch with the SAME weights in
+//         LDS: 11.8 instead of 6.7 multiply-adds per staged byte.  The kernels sit on the ~10 B/clk/CU the
+//         global -> LDS path delivers (measured: MFMA busy 52 % at 6.7 MAC/B), so this is the lever for
+//         the large maps; the 4-wave form keeps more workgroups for the small ones.
+// WP ("wave private", NW = 4): no barrier inside the K loop.  A wave needs only ITS four xi rows of the
+// weight image (exactly the 8 KB it DMAs itself) and 5 or 8 rows of the input region, which it stages
+// into a private LDS patch; every fragment of a K-step is pulled into registers first, so the single
+// LDS buffer can be refilled (DMA + ds_write) under that step's 32 MFMAs.  Ablation of the barrier form:
+// the two barriers per step cost 17 % of the kernel, they also force the four waves into lockstep.
+template <int NW, bool WP>
+__global__ __launch_bounds__(64 * NW, 2) void k_conv_wino(const WinoArgs a) {
+    constexpr int TY = NW;                                  // tile rows of the patch
+    constexpr int RH = 2 * TY + 2, POS = kWinoRW * RH;      // staged input region
+    constexpr int LIN = POS * kWinoIS;                      // floats per input buffer
+    constexpr int NT = 8 * NW;                              // tiles per workgroup
+    constexpr int NTHR = 64 * NW;
+    constexpr int WPI = 8 * kWinoRW * kWinoIS;              // WP: floats of a wave's private input patch (8 rows)
+    constexpr int kLdsFloats = WP ? (kWinoLdsW + 4 * WPI) : (2 * LIN + 2 * kWinoLdsW);
+    static_assert(!WP || NW == 4, "wave-private form is written for 4 waves");
+    static_assert(kLdsFloats >= 2 * 4 * NT * 32, "output transform needs 2*4*NT*32 floats");
+    __shared__ __attribute__((aligned(16))) float lds[kLdsFloats];
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    const int wi = wv & 3, half = wv >> 2;                  // transform row of this wave, tile-row group
     const int li = lane & 31, lh = lane >> 5;
     const int H = a.H, W = a.W, Cin = a.Cin, Cout = a.Cout, HW = H * W;
     const int nkb = Cin >> 3;
+    // weight slice (group, 64-channel block) fastest: fixed per XCD under round-robin dispatch, so each
+    // XCD's L2 keeps the 16*64*Cin*4 bytes of transformed weights all its workgroups stream (see k_conv_igemm)
     int bid = blockIdx.x;
+    const int nnb = Cout / kWinoBN;
+    const int nb = bid % nnb; bid /= nnb;
+    const int grp = bid % a.groups; bid /= a.groups;
     const int bx = bid % a.tbx; bid /= a.tbx;
-    const int by = bid % a.tby; bid /= a.tby;
-    const int b = bid % a.B;
-    const int nb = bid / a.B;
-    const int ty0 = by * kWinoTY, tx0 = bx * kWinoTX;
+    const int by = bid % a.tby;
+    const int b = bid / a.tby;
+    ConvPtrs P = a.p[0];
+    if (grp == 1) P = a.p[1];
+    if (grp == 2) P = a.p[2];
+    if (grp == 3) P = a.p[3];
+    const int ty0 = by * TY, tx0 = bx * kWinoTX;
     const int y_in0 = 2 * ty0 - 1, x_in0 = 2 * tx0 - 1;
-
-    // ---- staging: 8 weight float4 + 2 input float4 per thread and K-step
-    const float* wsrc = P.w + (size_t)nb * nkb * kWinoLdsW + 4 * t;
-    int w_dst[8];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        int f = t + 256 * i;                       // float4 index inside the 32 KB step image [xi][co][2]
-        int co = (f >> 1) & 63;
-        w_dst[i] = kWinoLdsIn + 4 * (f ^ ((co >> 3) & 1));   // swap the two halves on odd 8-channel groups
-    }
-    long long i_src[2];
-    int i_dst[2];
-    bool i_ok[2], i_use[2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        int f = t + 256 * i;
-        int q = f >> 1, half = f & 1;
-        i_use[i] = q < kWinoPos;
-        int ry = q / kWinoRW, rx = q - ry * kWinoRW;
-        int y = y_in0 + ry, x = x_in0 + rx;
-        i_ok[i] = i_use[i] && y >= 0 && y < H && x >= 0 && x < W;
-        i_src[i] = ((long long)b * HW + (long long)y * W + x) * Cin + 4 * half;
-        i_dst[i] = q * kWinoIS + 4 * half;
-    }
-    f32x4 rw[8], ri[2];
-#define FPC_WINO_LOAD(KB)                                                                                     \
-    do {                                                                                                      \
-        _Pragma("unroll") for (int i = 0; i < 8; ++i) rw[i] =                                                 \
-            *reinterpret_cast<const f32x4*>(wsrc + (size_t)(KB) * kWinoLdsW + 1024 * i);                      \
-        _Pragma("unroll") for (int i = 0; i < 2; ++i) ri[i] =                                                 \
-            i_ok[i] ? *reinterpret_cast<const f32x4*>(P.in + i_src[i] + 8 * (KB)) : f32x4{0.f, 0.f, 0.f, 0.f}; \
-    } while (0)
-#define FPC_WINO_STORE()                                                                                      \
-    do {                                                                                                      \
-        _Pragma("unroll") for (int i = 0; i < 8; ++i) *reinterpret_cast<f32x4*>(lds + w_dst[i]) = rw[i];      \
-        _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                         \
-            if (i_use[i]) *reinterpret_cast<f32x4*>(lds + i_dst[i]) = ri[i];                                  \
-    } while (0)
-
-    // ---- fragment addressing
-    const int tyl = li >> 3, txl = li & 7;                     // this lane's tile inside the patch
-    // row pair (ra, rb) and sign of B^T row wi:  0: d0-d2   1: d1+d2   2: d2-d1   3: d1-d3
-    const int ra = (wi == 0) ? 0 : (wi == 2 ? 2 : 1);
-    const int rb = (wi == 0) ? 2 : (wi == 1 ? 2 : (wi == 2 ? 1 : 3));
-    const float sgn = (wi == 1) ? 1.f : -1.f;
-    const float* in_a = lds + ((2 * tyl + ra) * kWinoRW + 2 * txl) * kWinoIS + 4 * lh;
-    const float* in_b = lds + ((2 * tyl + rb) * kWinoRW + 2 * txl) * kWinoIS + 4 * lh;
-    const float* w_frag[2];
-#pragma unroll
-    for (int nt = 0; nt < 2; ++nt) {
-        int co = nt * 32 + li;
-        w_frag[nt] = lds + kWinoLdsIn + ((4 * wi) * kWinoBN + co) * 8 + 4 * (lh ^ ((co >> 3) & 1));
-    }
 
     f32x16 acc[4][2];
 #pragma unroll
@@ -960,49 +951,211 @@ __global__ __launch_bounds__(256, 2) void k_conv_wino(const WinoArgs a) {
         for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[j][nt][r] = 0.f;
+    // row pair (ra, rb) and sign of B^T row wi:  0: d0-d2   1: d1+d2   2: d2-d1   3: d1-d3
+    const float sgn = (wi == 1) ? 1.f : -1.f;
 
-    FPC_WINO_LOAD(0);
+    if constexpr (WP) {
+        // ---- wave-private staging
+        float* const Wp = lds + wi * 2048;                        // this wave's xi rows [4][64][8]
+        float* const Ip = lds + kWinoLdsW + wi * WPI;             // this wave's input rows [<=8][18][8]
+        const float* wsrc = P.w + (size_t)nb * nkb * kWinoLdsW + wi * 2048 + 4 * lane;
+        const bool outer = (wi == 0 || wi == 3);                  // 5 region rows (every other one), else rows 1..8
+        const int nrows = outer ? 5 : 8;
+        long long i_src[5];
+        int i_dst[5];
+        bool i_ok[5], i_use[5];
+#pragma unroll
+        for (int i = 0; i < 5; ++i) {
+            int f = lane + 64 * i;
+            int q = f >> 1, hf = f & 1;
+            int lr = q / kWinoRW, rx = q - lr * kWinoRW;
+            i_use[i] = lr < nrows;
+            int ry = outer ? 2 * lr + (wi == 3 ? 1 : 0) : lr + 1;  // region row of private row lr
+            int y = y_in0 + ry, x = x_in0 + rx;
+            i_ok[i] = i_use[i] && y >= 0 && y < H && x >= 0 && x < W;
+            i_src[i] = ((long long)b * HW + (long long)y * W + x) * Cin + 4 * hf;
+            i_dst[i] = q * kWinoIS + 4 * hf;
+        }
+        const int tyl = li >> 3, txl = li & 7;
+        // private rows holding patch rows (2*tyl + ra) and (2*tyl + rb)
+        const int lra = outer ? tyl : (wi == 1 ? 2 * tyl : 2 * tyl + 1);
+        const int lrb = outer ? tyl + 1 : (wi == 1 ? 2 * tyl + 1 : 2 * tyl);
+        const int in_a = (lra * kWinoRW + 2 * txl) * kWinoIS + 4 * lh;
+        const int in_b = (lrb * kWinoRW + 2 * txl) * kWinoIS + 4 * lh;
+        int w_frag[2];
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+            int co = nt * 32 + li;
+            w_frag[nt] = co * 8 + 4 * (lh ^ ((co >> 3) & 1));
+        }
+        f32x4 ri[5];
+#define FPC_WP_ISSUE(KB)                                                                                      \
+    do {                                                                                                      \
+        _Pragma("unroll") for (int i = 0; i < 8; ++i) __builtin_amdgcn_global_load_lds(                       \
+            (const __attribute__((address_space(1))) void*)(wsrc + (size_t)(KB) * kWinoLdsW + 256 * i),      \
+            (__attribute__((address_space(3))) void*)(Wp + i * 256), 16, 0, 0);                               \
+        _Pragma("unroll") for (int i = 0; i < 5; ++i) ri[i] =                                                 \
+            i_ok[i] ? *reinterpret_cast<const f32x4*>(P.in + i_src[i] + 8 * (KB)) : f32x4{0.f, 0.f, 0.f, 0.f}; \
+    } while (0)
+#define FPC_WP_LAND()                                                                                         \
+    do {                                                                                                      \
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                      \
+        _Pragma("unroll") for (int i = 0; i < 5; ++i)                                                         \
+            if (i_use[i]) *reinterpret_cast<f32x4*>(Ip + i_dst[i]) = ri[i];                                   \
+    } while (0)
+        FPC_WP_ISSUE(0);
+        FPC_WP_LAND();
+        for (int kb = 0; kb < nkb; ++kb) {
+            // every fragment of this K-step into registers
+            f32x4 e[4], v[4], u[4][2];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                f32x4 da = *reinterpret_cast<const f32x4*>(Ip + in_a + c * kWinoIS);
+                f32x4 db = *reinterpret_cast<const f32x4*>(Ip + in_b + c * kWinoIS);
+                e[c] = da + sgn * db;
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                u[j][0] = *reinterpret_cast<const f32x4*>(Wp + j * 512 + w_frag[0]);
+                u[j][1] = *reinterpret_cast<const f32x4*>(Wp + j * 512 + w_frag[1]);
+            }
+            v[0] = e[0] - e[2]; v[1] = e[1] + e[2]; v[2] = e[2] - e[1]; v[3] = e[1] - e[3];
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    // LDS reads complete: the patch may be refilled
+            __builtin_amdgcn_sched_barrier(0);
+            if (kb + 1 < nkb) FPC_WP_ISSUE(kb + 1);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    acc[j][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[j][q], u[j][0][q], acc[j][0], 0, 0, 0);
+                    acc[j][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[j][q], u[j][1][q], acc[j][1], 0, 0, 0);
+                }
+            __builtin_amdgcn_sched_barrier(0);
+            if (kb + 1 < nkb) FPC_WP_LAND();
+        }
+#undef FPC_WP_ISSUE
+#undef FPC_WP_LAND
+    } else {
+    // ---- staging.  Weights: the K-step image (32 KB, already in its LDS layout) goes global -> LDS by
+    // LDS-DMA (global_load_lds_dwordx4: no VGPRs, no ds_write; every wave moves 32/NW pieces of 1 KB).
+    // Input: 2 float4 per thread through registers (zero fill at the image border).
+    constexpr int NPIECE = 32 / NW;
+    const float* wsrc = P.w + (size_t)nb * nkb * kWinoLdsW + (wv * NPIECE * 256) + 4 * lane;
+    long long i_src[2];
+    int i_dst[2];
+    bool i_ok[2], i_use[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        int f = t + NTHR * i;
+        int q = f >> 1, hf = f & 1;
+        i_use[i] = q < POS;
+        int ry = q / kWinoRW, rx = q - ry * kWinoRW;
+        int y = y_in0 + ry, x = x_in0 + rx;
+        i_ok[i] = i_use[i] && y >= 0 && y < H && x >= 0 && x < W;
+        i_src[i] = ((long long)b * HW + (long long)y * W + x) * Cin + 4 * hf;
+        i_dst[i] = q * kWinoIS + 4 * hf;
+    }
+    f32x4 ri[2];
+    float* const lds_w = lds + 2 * LIN;
+#define FPC_WINO_DMA(KB, BUF)                                                                                 \
+    do {                                                                                                      \
+        _Pragma("unroll") for (int i = 0; i < NPIECE; ++i) __builtin_amdgcn_global_load_lds(                  \
+            (const __attribute__((address_space(1))) void*)(wsrc + (size_t)(KB) * kWinoLdsW + 256 * i),      \
+            (__attribute__((address_space(3))) void*)(lds_w + (BUF) * kWinoLdsW + (wv * NPIECE + i) * 256), 16, 0, 0); \
+    } while (0)
+#define FPC_WINO_LOAD_IN(KB)                                                                                  \
+    do {                                                                                                      \
+        _Pragma("unroll") for (int i = 0; i < 2; ++i) ri[i] =                                                 \
+            i_ok[i] ? *reinterpret_cast<const f32x4*>(P.in + i_src[i] + 8 * (KB)) : f32x4{0.f, 0.f, 0.f, 0.f}; \
+    } while (0)
+#define FPC_WINO_STORE_IN(BUF)                                                                                \
+    do {                                                                                                      \
+        _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                         \
+            if (i_use[i]) *reinterpret_cast<f32x4*>(lds + (BUF) * LIN + i_dst[i]) = ri[i];                    \
+    } while (0)
+
+    // ---- fragment addressing
+    const int tyl = (li >> 3) + 4 * half, txl = li & 7;        // this lane's tile inside the patch
+    // row pair (ra, rb) and sign of B^T row wi:  0: d0-d2   1: d1+d2   2: d2-d1   3: d1-d3
+    const int ra = (wi == 0) ? 0 : (wi == 2 ? 2 : 1);
+    const int rb = (wi == 0) ? 2 : (wi == 1 ? 2 : (wi == 2 ? 1 : 3));
+    const int in_a = ((2 * tyl + ra) * kWinoRW + 2 * txl) * kWinoIS + 4 * lh;
+    const int in_b = ((2 * tyl + rb) * kWinoRW + 2 * txl) * kWinoIS + 4 * lh;
+    int w_frag[2];
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+        int co = nt * 32 + li;
+        w_frag[nt] = ((4 * wi) * kWinoBN + co) * 8 + 4 * (lh ^ ((co >> 3) & 1));   // halves swapped on odd 8-channel groups (k_wino_pack)
+    }
+
+    // prologue: step 0 operands
+    FPC_WINO_DMA(0, 0);
+    FPC_WINO_LOAD_IN(0);
+    FPC_WINO_STORE_IN(0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
     for (int kb = 0; kb < nkb; ++kb) {
-        __syncthreads();                 // previous step's fragments are consumed
-        FPC_WINO_STORE();
-        __syncthreads();
-        if (kb + 1 < nkb) FPC_WINO_LOAD(kb + 1);
+        const int cur = kb & 1;
+        if (kb + 1 < nkb) {              // buffers cur^1 were last read in step kb-1, which ended with a barrier
+            FPC_WINO_DMA(kb + 1, cur ^ 1);
+            FPC_WINO_LOAD_IN(kb + 1);
+        }
+        const float* Ib = lds + cur * LIN;
+        const float* Wb = lds_w + cur * kWinoLdsW;
         f32x4 e[4], v[4];
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-            f32x4 da = *reinterpret_cast<const f32x4*>(in_a + c * kWinoIS);
-            f32x4 db = *reinterpret_cast<const f32x4*>(in_b + c * kWinoIS);
+            f32x4 da = *reinterpret_cast<const f32x4*>(Ib + in_a + c * kWinoIS);
+            f32x4 db = *reinterpret_cast<const f32x4*>(Ib + in_b + c * kWinoIS);
             e[c] = da + sgn * db;
         }
         v[0] = e[0] - e[2]; v[1] = e[1] + e[2]; v[2] = e[2] - e[1]; v[3] = e[1] - e[3];
         // lanes 0-31 carry ci = q, lanes 32-63 carry ci = 4 + q of this K-step
+        __builtin_amdgcn_s_setprio(1);      // MFMA issue ahead of the co-resident workgroup's staging (measured -4 %)
+        f32x4 u0 = *reinterpret_cast<const f32x4*>(Wb + w_frag[0]);
+        f32x4 u1 = *reinterpret_cast<const f32x4*>(Wb + w_frag[1]);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            f32x4 u0 = *reinterpret_cast<const f32x4*>(w_frag[0] + j * kWinoBN * 8);
-            f32x4 u1 = *reinterpret_cast<const f32x4*>(w_frag[1] + j * kWinoBN * 8);
+            // weight fragments of xi j+1 are requested before xi j's MFMAs (LDS latency behind 8 MFMAs)
+            f32x4 n0 = u0, n1 = u1;
+            if (j < 3) {
+                n0 = *reinterpret_cast<const f32x4*>(Wb + w_frag[0] + (j + 1) * kWinoBN * 8);
+                n1 = *reinterpret_cast<const f32x4*>(Wb + w_frag[1] + (j + 1) * kWinoBN * 8);
+            }
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 acc[j][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[j][q], u0[q], acc[j][0], 0, 0, 0);
                 acc[j][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[j][q], u1[q], acc[j][1], 0, 0, 0);
             }
+            __builtin_amdgcn_sched_barrier(0);
+            u0 = n0; u1 = n1;
         }
+        __builtin_amdgcn_s_setprio(0);
+        if (kb + 1 < nkb) FPC_WINO_STORE_IN(cur ^ 1);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's DMA pieces have landed
+        __syncthreads();                                      // everybody's have; step kb's reads are done
     }
-#undef FPC_WINO_LOAD
-#undef FPC_WINO_STORE
+#undef FPC_WINO_DMA
+#undef FPC_WINO_LOAD_IN
+#undef FPC_WINO_STORE_IN
+
+    }
 
     // ---- output transform.  Column part inside the wave: z0 = m0 + m1 + m2, z1 = m1 - m2 - m3;
-    // row part across the four waves through LDS: y0 = z[0] + z[1] + z[2], y1 = z[1] - z[2] - z[3].
-    // LDS image Z[row i][cc][tile 32][co 32] (32 KB), one 32-channel half (nt) at a time.
+    // row part across the four transform-row waves through LDS: y0 = z[0] + z[1] + z[2], y1 = z[1] - z[2] - z[3].
+    // LDS image Z[row i][cc][tile NT][co 32], one 32-channel half (nt) at a time.
     const int ot = t >> 3, oc4 = (t & 7) * 4;                 // output stage: thread = one tile x 4 channels
     const int oty = ty0 + (ot >> 3), otx = tx0 + (ot & 7);
     for (int nt = 0; nt < 2; ++nt) {
         __syncthreads();
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            int m = (r & 3) + 8 * (r >> 2) + 4 * lh;
+            int m = half * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
             float m0 = acc[0][nt][r], m1 = acc[1][nt][r], m2 = acc[2][nt][r], m3 = acc[3][nt][r];
-            lds[((wi * 2 + 0) * 32 + m) * 32 + li] = m0 + m1 + m2;
-            lds[((wi * 2 + 1) * 32 + m) * 32 + li] = m1 - m2 - m3;
+            lds[((wi * 2 + 0) * NT + m) * 32 + li] = m0 + m1 + m2;
+            lds[((wi * 2 + 1) * NT + m) * 32 + li] = m1 - m2 - m3;
         }
         __syncthreads();
         const int n = nb * kWinoBN + nt * 32 + oc4;
@@ -1010,7 +1163,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_wino(const WinoArgs a) {
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int cc = 0; cc < 2; ++cc) z[i][cc] = *reinterpret_cast<const f32x4*>(lds + ((i * 2 + cc) * 32 + ot) * 32 + oc4);
+            for (int cc = 0; cc < 2; ++cc) z[i][cc] = *reinterpret_cast<const f32x4*>(lds + ((i * 2 + cc) * NT + ot) * 32 + oc4);
         f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
         if (P.scale) sc = *reinterpret_cast<const f32x4*>(P.scale + n);
         if (P.shift) sh = *reinterpret_cast<const f32x4*>(P.shift + n);
@@ -1032,15 +1185,15 @@ __global__ __launch_bounds__(256, 2) void k_conv_wino(const WinoArgs a) {
                 s2 += val * val;
             }
         if (P.gn_part) {
-            // per-channel sums of this workgroup's outputs: 32 tile slots -> LDS -> 32 threads
+            // per-channel sums of this workgroup's outputs: NT tile slots -> LDS -> 32 threads
             __syncthreads();
-            float* red = lds;                                  // [32 slots][32 ch][2]
+            float* red = lds;                                  // [NT slots][32 ch][2]
 #pragma unroll
             for (int k = 0; k < 4; ++k) { red[(ot * 32 + oc4 + k) * 2] = s1[k]; red[(ot * 32 + oc4 + k) * 2 + 1] = s2[k]; }
             __syncthreads();
             if (t < 32) {
                 float u1 = 0.f, u2 = 0.f;
-                for (int sI = 0; sI < 32; ++sI) { u1 += red[(sI * 32 + t) * 2]; u2 += red[(sI * 32 + t) * 2 + 1]; }
+                for (int sI = 0; sI < NT; ++sI) { u1 += red[(sI * 32 + t) * 2]; u2 += red[(sI * 32 + t) * 2 + 1]; }
                 int Pn = a.tbx * a.tby;
                 float* g = P.gn_part + (((size_t)b * Pn + by * a.tbx + bx) * Cout + nb * kWinoBN + nt * 32 + t) * 2;
                 g[0] = u1; g[1] = u2;
@@ -1066,7 +1219,8 @@ __global__ __launch_bounds__(256) void k_wino_pack(const float* __restrict__ w, 
             gg[3][c] = g2;
         }
         int nb = co >> 6, col = co & 63, kb = ci >> 3, cil = ci & 7;
-        float* dst = out + (((size_t)nb * (Cin >> 3) + kb) * 16) * 512 + col * 8 + cil;
+        // the step image IS the LDS image: halves (4 channels) swapped on odd 8-channel groups
+        float* dst = out + (((size_t)nb * (Cin >> 3) + kb) * 16) * 512 + col * 8 + (cil ^ (4 * ((col >> 3) & 1)));
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             float r0 = gg[i][0], r1 = gg[i][1], r2 = gg[i][2];
@@ -1079,8 +1233,12 @@ __global__ __launch_bounds__(256) void k_wino_pack(const float* __restrict__ w, 
 }
 
 int launch_conv_wino(const WinoArgs& a, int groups, hipStream_t s) {
-    if (groups < 1 || groups > kMaxGroup || a.Cin % 8 != 0 || a.Cout % kWinoBN != 0) return FPC_EINVAL;
-    hipLaunchKernelGGL(k_conv_wino, dim3(a.tbx * a.tby * a.B * (a.Cout / kWinoBN), groups), dim3(256), 0, s, a);
+    if (groups < 1 || groups > kMaxGroup || a.Cin % 8 != 0 || a.Cout % kWinoBN != 0 || (a.waves != 4 && a.waves != 8))
+        return FPC_EINVAL;
+    dim3 grid(a.tbx * a.tby * a.B * (a.Cout / kWinoBN) * groups);
+    if (a.waves == 8) hipLaunchKernelGGL((k_conv_wino<8, false>), grid, dim3(512), 0, s, a);
+    else if (a.variant == 1) hipLaunchKernelGGL((k_conv_wino<4, true>), grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((k_conv_wino<4, false>), grid, dim3(256), 0, s, a);
     return check_launch();
 }
 

@@ -25,7 +25,7 @@ struct ConvArgs {
     float* splitk_ws;     // [G][nsplit][B][mtiles*BM][Npad] raw partial sums (nsplit > 1)
     int B, Hi, Wi, Cin, Ho, Wo, Cout, Npad, Kh, Kw, stride, pad, K, Kpad;
     long long in_sb, in_sh, in_sw, in_sc;   // element strides of the input
-    int relu, nsplit, mtiles, ntiles, ksteps, bm, bn, generic;
+    int relu, nsplit, mtiles, ntiles, ksteps, bm, bn, generic, groups;
     const float* wino_w[kMaxGroup];   // host side only: Winograd-packed weights per group (or null)
 };
 
@@ -70,7 +70,10 @@ struct Up4Args {
 // Winograd F(2x2,3x3) convolution (3x3, stride 1, pad 1, NHWC, Cin % 8 == 0, Cout % 64 == 0)
 struct WinoArgs {
     ConvPtrs p[kMaxGroup];   // .w = Winograd-packed weights [Cout/64][Cin/8][16][64][8]; .up unused
-    int B, H, W, Cin, Cout, relu, tbx, tby;   // tbx = ceil(ceil(W/2)/8), tby = ceil(ceil(H/2)/4) tile patches
+    int variant;             // 0: barrier form, 1: wave-private barrier-free K loop (4 waves only)
+    int groups;
+    int waves;               // 4: 8x4 tile patch per workgroup; 8: 8x8 patch (512 threads)
+    int B, H, W, Cin, Cout, relu, tbx, tby;   // tbx = ceil(ceil(W/2)/8), tby = ceil(ceil(H/2)/waves) tile patches
 };
 int launch_conv_wino(const WinoArgs& a, int groups, hipStream_t s);
 int launch_wino_pack(const float* w_oihw, float* packed, int Cout, int Cin, hipStream_t s);

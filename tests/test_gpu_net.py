@@ -96,6 +96,14 @@ CONV_CASES = [
     (2, 256, 15, 20, 128, 3, 1, 1, (0, 0, -1), "gn"),            # odd height: half-empty last tile row
     (1, 128, 34, 50, 128, 3, 1, 1, (0, 0, -1), "gn"),            # ragged tile patches in both directions
     (1, 8, 7, 9, 64, 3, 1, 1, (0, 0, -1), "bias_relu"),
+    # wave-private, barrier-free K loop (nsplit = -3)
+    (1, 64, 30, 40, 64, 3, 1, 1, (0, 0, -3), "bn_relu_res"),
+    (2, 256, 15, 20, 128, 3, 1, 1, (0, 0, -3), "gn"),
+    (1, 128, 34, 50, 128, 3, 1, 1, (0, 0, -3), "gn"),
+    # 8-wave form (8x8 tile patch per workgroup, nsplit = -2)
+    (1, 64, 30, 40, 64, 3, 1, 1, (0, 0, -2), "bn_relu_res"),
+    (2, 256, 15, 20, 128, 3, 1, 1, (0, 0, -2), "gn"),
+    (1, 128, 34, 50, 128, 3, 1, 1, (0, 0, -2), "gn"),
 ]
 
 
