@@ -6,21 +6,29 @@
 
 Workload (BASELINE.json configs[1]): ResNet18-FPN + all four heads, batch = 1 frame of 640x480
 per GPU per step, HV_NUM_OF_HYPOTHESES = 1000 (config.INFERENCE), random-init weights
-(torch.manual_seed(0)), synthetic data.  One step is one pass of the hot path over one frame:
+(torch.manual_seed(0)), synthetic data, f32 throughout.  One step is one pass of the hot path over
+one frame:
 
-    image -> encoder -> 4 FPN decoders -> 4 heads -> class compression          (on the synthetic image)
+    image -> native engine (fpc_net_forward): encoder -> 4 FPN decoders -> 4 heads -> x4 upsample
+             -> class compression                                           (on the synthetic image)
           -> aggregation (CC + per-instance means) -> RANSAC hough voting -> RT (on the synthetic
              post-network "vote bench" frame: 6 elliptical instances — random-init weights give no
              usable instances)
           -> [N > 1] RCCL all-gather of the per-instance pose records
 
-All inputs are resident in HBM before the timed region.  Weak scaling: every rank runs its own
+All inputs are resident in HBM before the timed region.  Frames are streamed with two in flight
+(network of frame i+1 on one HIP stream, post-network of frame i on another; every frame completes
+all of its work, one step later) — `--no-pipeline` finishes each frame before starting the next and
+`config.ms_per_frame_one_in_flight` reports that latency.  Weak scaling: every rank runs its own
 frame per step; `value` = N * K / max-over-ranks(time).
 
 Extra objects on the JSON line:
   roofline      the hough-vote launch sequence (fpc_ransac_voting_v3): algorithmic bytes
                 n_instances * 12*H*W per call / HIP-event time of the call on its stream,
-                against the 8 TB/s HBM peak of MI355X_MICROARCH.md
+                against the 8 TB/s HBM peak of MI355X_MICROARCH.md; `traffic` = PMC-measured HBM bytes
+                per launch (profiles/r01_vote_traffic.json: FETCH_SIZE doubled per the guide + WRITE_SIZE)
+  backbone      the network part: algorithmic f32 FLOP of the direct convolutions (100.1 GFLOP/frame,
+                ResNet18) / HIP-event time, against the 157.3 TFLOP/s f32 matrix-core peak
   cpu_baseline  the same step on the host: torch-CPU backbone + the C oracle's post-network path
 """
 import argparse
@@ -36,6 +44,8 @@ if REPO not in sys.path:
     sys.path.insert(0, REPO)
 
 HBM_PEAK_GBPS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured float4 copy)
+MFMA_F32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: f32-input MFMA = f32 vector peak (155 measured)
+BACKBONE_GFLOP = {"resnet18": 2 * (11.10 + 4 * 9.70 + 0.16), "resnet34": 2 * (22.43 + 4 * 9.70 + 0.16)}
 H, W = 480, 640
 
 
@@ -186,6 +196,20 @@ def main():
     torch.cuda.synchronize()
     latency_ms = (time.perf_counter() - t1) / nlat * 1e3
 
+    # backbone alone: HIP events around the engine call on its stream
+    net_ms = []
+    if not args.vote_only:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        for _ in range(max(5, min(args.steps, 30))):
+            with torch.no_grad(), torch.cuda.stream(s_net):
+                e0.record()
+                logits = model_gpu.pure_model_forward(x)
+                model_gpu.class_compression(logits)
+                e1.record()
+            e1.synchronize()
+            net_ms.append(e0.elapsed_time(e1))
+        net_ms.sort()
+
     # vote roofline: separate, untimed-for-throughput loop with HIP events around the vote call
     for _ in range(max(5, min(args.steps, 30))):
         vote_probe()
@@ -195,6 +219,11 @@ def main():
     vote_t = vote_ms[len(vote_ms) // 2] * 1e-3
     alg_bytes = n_inst * 12 * H * W
     achieved = alg_bytes / vote_t / 1e9
+    traffic = None
+    tpath = os.path.join(REPO, "profiles", "r01_vote_traffic.json")
+    if os.path.exists(tpath) and args.hn == 1000:
+        with open(tpath) as f:
+            traffic = json.load(f).get("traffic_bytes_per_launch")
 
     if rank == 0:
         line = {
@@ -209,12 +238,20 @@ def main():
                        "frames_in_flight": 1 if args.no_pipeline else 2,
                        "ms_per_frame_one_in_flight": round(latency_ms, 4)},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": None,
+                         "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": traffic,
                          "kernel": "fpc_ransac_voting_v3 launch sequence (k_chunk_count..k_select_refine)",
                          "algorithmic_bytes_per_launch": alg_bytes, "launch_ms": round(vote_t * 1e3, 4),
                          "note": "HIP events on the launch stream around the whole call; at hn=1000 the count "
-                                 "kernel is VALU-bound (DESIGN.md)"},
+                                 "kernel is VALU-bound (DESIGN.md); traffic from profiles/r01_vote_traffic.json (PMC)"},
         }
+        if net_ms:
+            t_net = net_ms[len(net_ms) // 2] * 1e-3
+            tf = BACKBONE_GFLOP.get(args.encoder, 0.0) / t_net / 1e3
+            line["backbone"] = {"bound": "mfma", "achieved": round(tf, 2), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                "frac": round(tf / MFMA_F32_PEAK_TFLOPS, 4), "ms": round(t_net * 1e3, 4),
+                                "algorithmic_gflop_per_frame": round(BACKBONE_GFLOP.get(args.encoder, 0.0), 2),
+                                "note": "direct-convolution FLOP count; the engine runs the large 3x3 layers as "
+                                        "Winograd F(2x2,3x3) on f32 MFMA (2.25x fewer multiply-adds)"}
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(model.to("cpu"), image, cat_cpu, args.hn,
                                                 torch.inverse(torch.from_numpy(hp.NUMPY_INTRINSICS).float()).numpy())
