@@ -56,6 +56,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--hn", type=int, default=1000, help="HV_NUM_OF_HYPOTHESES (1000 = config.INFERENCE)")
     ap.add_argument("--encoder", default="resnet18")
+    ap.add_argument("--batch", type=int, default=1, help="frames per GPU per step (1 = BASELINE.json configs[1]; 32 = configs[2]/[3])")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--vote-only", action="store_true", help="time only the post-network stages (profiling aid)")
     ap.add_argument("--no-pipeline", action="store_true", help="finish every frame before starting the next (latency mode)")
@@ -114,12 +115,13 @@ def main():
     torch.manual_seed(0)
     model = L.pose_regressor.MODELS[hp.MODEL].load_from_ckpt(None, hp).eval()
     model_gpu = model.to(dev)
-    image = synth.make_image(rank)[None]                      # per-rank frame (weak scaling)
-    cat_cpu, _ = synth.make_vote_frame(rank)
+    Bq = args.batch
+    image = torch.stack([synth.make_image(rank * Bq + i) for i in range(Bq)])      # per-rank frames (weak scaling)
+    cat_cpu, _ = synth.make_vote_batch(range(rank * Bq, rank * Bq + Bq))
     x = image.to(dev)
     cat = {k: v.to(dev) for k, v in cat_cpu.items()}
-    n_inst = int((torch.unique(cat_cpu["mask"]) != 0).sum())
-    cap = 64
+    n_inst = 6 * Bq                                           # vote-bench fixture: 6 instances per frame
+    cap = 64 * Bq
 
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
     vote_ms = []
@@ -228,12 +230,12 @@ def main():
     if rank == 0:
         line = {
             "metric": "img/s end-to-end 640x480 inference; hough-vote kernel HBM GB/s vs roofline",
-            "value": round(world * args.steps / dt, 3), "unit": "img/s", "n_gpus": world, "steps": args.steps,
+            "value": round(world * Bq * args.steps / dt, 3), "unit": "img/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"{args.encoder}-FPN + all heads, batch=1 640x480 per GPU, hn={args.hn}, "
+            "config": {"workload": f"{args.encoder}-FPN + all heads, batch={Bq} 640x480 per GPU, hn={args.hn}, "
                                    f"{n_inst} instances/frame (vote-bench fixture), random-init weights",
-                       "global_batch": world, "parallelism": f"image-sharded dp{world}" if world > 1 else "single GPU",
+                       "global_batch": world * Bq, "parallelism": f"image-sharded dp{world}" if world > 1 else "single GPU",
                        "vote_only": bool(args.vote_only),
                        "frames_in_flight": 1 if args.no_pipeline else 2,
                        "ms_per_frame_one_in_flight": round(latency_ms, 4)},
@@ -246,14 +248,15 @@ def main():
         }
         if net_ms:
             t_net = net_ms[len(net_ms) // 2] * 1e-3
-            tf = BACKBONE_GFLOP.get(args.encoder, 0.0) / t_net / 1e3
+            tf = Bq * BACKBONE_GFLOP.get(args.encoder, 0.0) / t_net / 1e3
             line["backbone"] = {"bound": "mfma", "achieved": round(tf, 2), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
                                 "frac": round(tf / MFMA_F32_PEAK_TFLOPS, 4), "ms": round(t_net * 1e3, 4),
                                 "algorithmic_gflop_per_frame": round(BACKBONE_GFLOP.get(args.encoder, 0.0), 2),
                                 "note": "direct-convolution FLOP count; the engine runs the large 3x3 layers as "
                                         "Winograd F(2x2,3x3) on f32 MFMA (2.25x fewer multiply-adds)"}
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(model.to("cpu"), image, cat_cpu, args.hn,
+            one = {k: v[:1] for k, v in cat_cpu.items()}
+            line["cpu_baseline"] = cpu_baseline(model.to("cpu"), image[:1], one, args.hn,
                                                 torch.inverse(torch.from_numpy(hp.NUMPY_INTRINSICS).float()).numpy())
         print(json.dumps(line), flush=True)
     if world > 1:
