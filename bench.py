@@ -16,9 +16,10 @@ one frame:
              usable instances)
           -> [N > 1] RCCL all-gather of the per-instance pose records
 
-All inputs are resident in HBM before the timed region.  Frames are streamed with two in flight
-(network of frame i+1 on one HIP stream, post-network of frame i on another; every frame completes
-all of its work, one step later) — `--no-pipeline` finishes each frame before starting the next and
+All inputs are resident in HBM before the timed region.  Frames are streamed with three in flight
+(fastposecnn_amd/streaming.py: consecutive frames alternate between two native plans on their own
+HIP streams, the post-network stages of finished networks run on a third; every frame completes all of
+its work, it is only collected two submissions later) — `--no-pipeline` finishes each frame before starting the next and
 `config.ms_per_frame_one_in_flight` reports that latency.  Weak scaling: every rank runs its own
 frame per step; `value` = N * K / max-over-ranks(time).
 
@@ -59,6 +60,7 @@ def parse():
     ap.add_argument("--batch", type=int, default=1, help="frames per GPU per step (1 = BASELINE.json configs[1]; 32 = configs[2]/[3])")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--vote-only", action="store_true", help="time only the post-network stages (profiling aid)")
+    ap.add_argument("--net-streams", type=int, default=2, help="network plans / HIP streams that alternate frames (1 or 2)")
     ap.add_argument("--no-pipeline", action="store_true", help="finish every frame before starting the next (latency mode)")
     return ap.parse_args()
 
@@ -126,34 +128,33 @@ def main():
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
     vote_ms = []
 
-    # Two HIP streams: the network of frame i+1 (stream A) overlaps the small, latency-bound
-    # post-network kernels of frame i (stream B).  Every frame still does all of its work and its
-    # results are complete (instance count read back, tensors trimmed) one step later.
-    s_net, s_post = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)
+    # Frame-streaming runtime (fastposecnn_amd/streaming.py): consecutive frames alternate between
+    # `--net-streams` native plans on their own HIP streams, the post-network stages run on one more stream.
+    # Every frame does all of its work and is complete (instance count read back, tensors trimmed) when it
+    # is collected, `depth` submissions later.
+    from fastposecnn_amd.streaming import FrameStreamer
+    streamer = FrameStreamer(model_gpu, net_streams=1 if args.no_pipeline else args.net_streams)
+    s_net = streamer.net_streams[0]
+    depth = 0 if args.no_pipeline else len(streamer.models)
     pending = []
 
     def finish(ticket):
-        agg = model_gpu.post_network_finish(ticket)
+        out = streamer.collect(ticket) if isinstance(ticket, dict) and "model" in ticket else \
+            {"aggregated": model_gpu.post_network_finish(ticket)}
         if world > 1:
-            parallel.all_gather_pose_records(agg, rank, cap)
-        return agg
+            parallel.all_gather_pose_records(out["aggregated"], rank * Bq, cap)
+        return out
 
     def step(pipelined=True):
-        """One frame: backbone + class compression on the image (stream A), then aggregation -> hough
-        voting -> RT on the vote-bench frame (stream B, after the network's event); the previous
-        frame is finished (one host wait on ITS event) while this one runs."""
-        with torch.no_grad():
-            with torch.cuda.stream(s_net):
-                if not args.vote_only:
-                    logits = model_gpu.pure_model_forward(x)
-                    model_gpu.class_compression(logits)
-                ev_net = torch.cuda.Event()
-                ev_net.record()
-            with torch.cuda.stream(s_post):
-                s_post.wait_event(ev_net)
+        """One step = one batch of frames through the whole hot path (network on the image, post-network on
+        the vote-bench fixture)."""
+        if args.vote_only:
+            with torch.no_grad():
                 pending.append(model_gpu.post_network_enqueue(cat))
-            if len(pending) > (1 if (pipelined and not args.no_pipeline) else 0):
-                return finish(pending.pop(0))
+        else:
+            pending.append(streamer.submit(x, categorical_override=cat))
+        if len(pending) > (depth if pipelined else 0):
+            return finish(pending.pop(0))
         return None
 
     def drain():
@@ -237,7 +238,7 @@ def main():
                                    f"{n_inst} instances/frame (vote-bench fixture), random-init weights",
                        "global_batch": world * Bq, "parallelism": f"image-sharded dp{world}" if world > 1 else "single GPU",
                        "vote_only": bool(args.vote_only),
-                       "frames_in_flight": 1 if args.no_pipeline else 2,
+                       "frames_in_flight": 1 + depth, "net_streams": len(streamer.models),
                        "ms_per_frame_one_in_flight": round(latency_ms, 4)},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": traffic,

@@ -241,7 +241,10 @@ class PoseRegressor(Model, torch.nn.Module):
         eng = self._engines.get(key)
         if eng is None:
             from fastposecnn_amd.engine import NetEngine
-            eng = NetEngine(self, key[0], key[1], key[2], x.device)
+            # ENGINE_AUTOTUNE=False keeps the static planner's tilings: results are then reproducible run to
+            # run (tuned plans may differ in split-K, i.e. in f32 summation order)
+            eng = NetEngine(self, key[0], key[1], key[2], x.device,
+                            autotune=getattr(self.HPARAM, 'ENGINE_AUTOTUNE', True))
             self._engines[key] = eng
         return eng
 

@@ -245,3 +245,44 @@ def test_engine_invalidation(lib, dev):
     m.train()
     out = m(x)                                                # training mode: torch modules, autograd works
     assert not m._engines and out["logits"]["mask"].requires_grad
+
+
+def test_frame_streamer_matches_forward(lib, dev):
+    """Three frames in flight on the streaming runtime give, frame by frame, what forward() gives."""
+    from fastposecnn_amd import config, synth
+    from fastposecnn_amd.streaming import FrameStreamer
+    hp = config.INFERENCE()
+    hp.RUNTIME_TIMING = False
+    hp.HV_NUM_OF_HYPOTHESES = 128
+    torch.manual_seed(0)
+    m = lib.pose_regressor.MODELS['PoseRegressor'].load_from_ckpt(None, hp).to(dev).eval()
+    H, W = 96, 128
+    xs = [synth.make_image(i, H, W)[None].to(dev) for i in range(5)]
+    cats = []
+    for i in range(5):
+        c, _ = synth.make_vote_frame(i, K=3, H=H, W=W, rmin=8, rmax=20)
+        cats.append({k: v.to(dev) for k, v in c.items()})
+    ref = []
+    with torch.no_grad():
+        for i in range(5):
+            logits = m.pure_model_forward(xs[i])
+            cat = m.class_compression(logits)
+            torch.manual_seed(100 + i)
+            ref.append((logits, cat, m.agg_hough_and_generate_RT(cats[i])))
+    st = FrameStreamer(m, net_streams=2)
+    tickets = []
+    for i in range(5):
+        torch.manual_seed(100 + i)                     # the vote's sampler seed is drawn at submit time
+        tickets.append(st.submit(xs[i], categorical_override=cats[i]))
+    for i in range(5):
+        out = st.collect(tickets[i])
+        # the two plans are autotuned separately (different split-K / tilings -> different f32 summation
+        # order), so the network outputs agree to rounding, not bit for bit
+        for k in ("mask", "quaternion", "scales", "xy", "z"):
+            a, b = out["logits"][k], ref[i][0][k]
+            assert (a - b).abs().max().item() <= 1e-4 * max(1.0, b.abs().max().item()), (i, k)
+        assert (out["categorical"]["mask"] != ref[i][1]["mask"]).float().mean().item() < 1e-3
+        assert set(out["aggregated"]) == set(ref[i][2])
+        for k, v in ref[i][2].items():
+            assert torch.equal(out["aggregated"][k], v), (i, k)
+        assert out["aggregated"]["class_ids"].shape[0] == 3
