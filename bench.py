@@ -242,7 +242,7 @@ def main():
                        "ms_per_frame_one_in_flight": round(latency_ms, 4)},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": traffic,
-                         "kernel": "fpc_ransac_voting_v3 launch sequence (k_chunk_count..k_select_refine)",
+                         "kernel": "fpc_ransac_voting_v3 launch sequence (k_chunk_count .. k_count_hi .. k_refine)",
                          "algorithmic_bytes_per_launch": alg_bytes, "launch_ms": round(vote_t * 1e3, 4),
                          "note": "HIP events on the launch stream around the whole call; at hn=1000 the count "
                                  "kernel is VALU-bound (DESIGN.md); traffic from profiles/r01_vote_traffic.json (PMC)"},

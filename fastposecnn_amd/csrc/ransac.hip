@@ -9,22 +9,21 @@
 //      k_chunk_kept    only for instances above max_num: Bernoulli keep   (rare)
 //      k_compact       order-preserving stream compaction -> float4 {x,y,dx,dy} list
 //                                                                          (HBM: mask + vote planes)
-//      k_count_hi      pair sampling + 2-line intersection in the prologue, then an UPPER
-//                      BOUND of every hypothesis' inlier count: 4 FMA + 2 compares per
-//                      (pixel, hypothesis), wavefront ballot + popcount, no sqrt / divide
-//      k_select        candidates in decreasing bound order are re-counted with the exact
-//                      reference arithmetic until the bound of the next one cannot beat the
-//                      best exact count: the winner, its count, its inlier set and hence the
-//                      result are those of the reference's exhaustive vote, bit for bit.
-//                      The same pass accumulates the fp64 normal equations; 16 workgroups per
-//                      instance, last arriver (agent-scope release/acquire ticket) finishes.
+//      k_hypothesis    pair sampling + 2-line intersection
+//      k_count_hi      EXACT inlier count of every hypothesis in one pass: per (pixel, hypothesis) two
+//                      affine forms t = d.e and s = d x e (4 FMA) decide almost every pair — "surely an
+//                      inlier" (inside a slightly narrower cone) or "surely not" (outside a slightly wider
+//                      one); only the pairs in the thin band between the cones (~1e-3 of them) take the
+//                      reference's own arithmetic (sqrt, divide).  Wavefront ballot + popcount.
+//      k_refine        arg-max (lowest index on ties), winner re-vote, fp64 normal equations; 16 workgroups
+//                      per instance, last arriver (agent-scope release/acquire ticket) finishes.
 //
-// Why the bound is sound (DESIGN.md "vote filter"): the reference accepts a pair when
-// fl(cos) > th where fl(cos) carries at most 8 ulp(1) of rounding, so every accepted pair has
-// true cos >= th' = th - 1e-6, i.e. |d x e| <= kappa' (d . e) with kappa' = sqrt(1-th'^2)/th'.
-// Both u1 = kappa' d.e + d x e and u2 = kappa' d.e - d x e are affine in the hypothesis, so each
-// costs two FMAs against per-pixel constants; their own rounding is covered by E_h =
-// 2e-6 (|hx|+|hy|+W+H).  Accepted pair  =>  u1 >= -E_h and u2 >= -E_h.
+// Why the two cones are sound (DESIGN.md "vote filter"): the reference accepts a pair when fl(cos) > th
+// where fl(cos) carries at most 8 ulp(1) < 1e-6 of rounding.  So an accepted pair has true cos >= th' =
+// th - 1e-6, i.e. |s| <= kappa' t with kappa' = sqrt(1-th'^2)/th' ("maybe"), and a pair with true
+// cos >= th'' = th + 1e-6, i.e. |s| <= kappa'' t, is accepted for sure.  t and s are affine in the hypothesis
+// (two FMAs each against per-pixel constants); their own rounding is covered by E_h = 2e-6 (|hx|+|hy|+W+H):
+//     accepted  =>  |s| <= kappa' t + E_h        (computed values);   |s| <= kappa'' t - E_h  =>  accepted.
 //
 // One RANSAC round: the reference's rounds re-evaluate identical samples.
 #include "common.hpp"
@@ -91,19 +90,17 @@ constexpr int kTile = 256;         // pixels staged in LDS per step of the exact
 constexpr int kMeta = 8;           // i32 per instance: fg, tn, win_idx, win_cnt, inl
 constexpr int kT = 4;              // pixel tiles (of 64) held in registers per lane in k_count_hi
 constexpr int kBlkPx = 4 * 64 * kT;  // pixels per k_count_hi workgroup pass (4 waves)
-constexpr int kSelP = 16;          // workgroups per instance in k_select
-constexpr int kPartial = 8;        // doubles per k_select partial record
+constexpr int kSelP = 16;          // workgroups per instance in k_refine
+constexpr int kPartial = 8;        // doubles per k_refine partial record
 
 struct Ws {
-    int32_t* counts;      // [n, hn]  upper bounds (exact counts in exact mode); zeroed per call
-    int32_t* counts_ex;   // [n, hn]  exact counts, only when diagnostics are requested; zeroed
-    int32_t* tickets;     // [2, n]   zeroed (k_select, k_refine)
+    int32_t* counts;      // [n, hn]  exact inlier counts; zeroed per call
+    int32_t* tickets;     // [n]      zeroed (k_refine)
     int32_t* chunk_fg;    // [n, nch]
     int32_t* chunk_kept;  // [n, nch]
     int32_t* meta;        // [n, kMeta]
     float* hyp;           // [n, hn, 2]
     double* partial;      // [n, kSelP, kPartial]   k_refine partial sums
-    int32_t* partial_i;   // [n, kSelP, kCand]      k_select partial counts
     float4* px;           // [n, HW]  {x, y, dx, dy}
     size_t zero_bytes;    // leading bytes cleared per call
     size_t total;
@@ -116,15 +113,13 @@ static Ws carve(void* base, int n, int H, int W, int hn) {
     char* p = (char*)base;
     size_t off = 0;
     w.counts = (int32_t*)(p + off); off = align_up(off + sizeof(int32_t) * (size_t)n * hn, 256);
-    w.counts_ex = (int32_t*)(p + off); off = align_up(off + sizeof(int32_t) * (size_t)n * hn, 256);
-    w.tickets = (int32_t*)(p + off); off = align_up(off + sizeof(int32_t) * 2 * (size_t)n, 256);
+    w.tickets = (int32_t*)(p + off); off = align_up(off + sizeof(int32_t) * (size_t)n, 256);
     w.zero_bytes = off;
     w.chunk_fg = (int32_t*)(p + off); off = align_up(off + sizeof(int32_t) * (size_t)n * nch, 256);
     w.chunk_kept = (int32_t*)(p + off); off = align_up(off + sizeof(int32_t) * (size_t)n * nch, 256);
     w.meta = (int32_t*)(p + off); off = align_up(off + sizeof(int32_t) * (size_t)n * kMeta, 256);
     w.hyp = (float*)(p + off); off = align_up(off + sizeof(float) * (size_t)n * hn * 2, 256);
     w.partial = (double*)(p + off); off = align_up(off + sizeof(double) * (size_t)n * kSelP * kPartial, 256);
-    w.partial_i = (int32_t*)(p + off); off = align_up(off + sizeof(int32_t) * (size_t)n * kSelP * 16, 256);
     w.px = (float4*)(p + off); off = align_up(off + sizeof(float4) * (size_t)n * HW, 256);
     w.total = off;
     return w;
@@ -319,15 +314,14 @@ __global__ __launch_bounds__(256) void k_count_exact(const float4* __restrict__ 
     if (live && cnt) atomicAdd(&counts[(size_t)inst * hn + hi], cnt);
 }
 
-// Upper bound of every hypothesis' inlier count.  grid (ceil(hn/64), S, n), 256 threads.
-// Lane g of every wave owns hypothesis h0+g (generated in the prologue, RV/ransac_voting_gpu.py
-// :552,559) and pixel slots t*64+lane of the wave's T tiles (six affine constants each, in
-// registers).  For g = 0..63 the hypothesis is broadcast with v_readlane into SGPRs, so a
-// (tile, hypothesis) step is 4 FMA + 2 compares per lane, one s_and, one s_bcnt1, one s_add —
-// no LDS or memory traffic inside the loop.
+// Exact inlier count of every hypothesis.  grid (ceil(hn/64), S, n), 256 threads.
+// Lane g of every wave owns hypothesis h0+g and pixel slots t*64+lane of the wave's T tiles (six affine
+// constants + the raw vote, in registers).  For g = 0..63 the hypothesis is broadcast with v_readlane into
+// SGPRs, so a (tile, hypothesis) step is 6 FMA + 2 compares per lane, two ballots — no LDS or memory
+// traffic inside the loop; the exact test runs only for the lanes of a tile that fall between the cones.
 template <int T>
 __global__ __launch_bounds__(256) void k_count_hi(const float4* __restrict__ px, int HW, int hn, float wh,
-                                                  float kappa, const int32_t* __restrict__ idxs, uint64_t seed,
+                                                  float kappa1, float kappa2, float thresh,
                                                   const int32_t* __restrict__ meta, const float* __restrict__ hyp,
                                                   int32_t* __restrict__ counts, const int32_t* __restrict__ n_dev) {
     if (n_dev && (int)blockIdx.z >= *n_dev) return;
@@ -340,15 +334,16 @@ __global__ __launch_bounds__(256) void k_count_hi(const float4* __restrict__ px,
     const float4* P = px + (size_t)inst * HW;
     if (threadIdx.x < kWave) s_cnt[threadIdx.x] = 0;
 
-    // this lane's hypothesis (generated once by k_hypothesis): (hx, hy, -E_h); (0, 0, -inf) outside the
-    // filter's domain (every voting pixel then counts: still an upper bound), (0, 0, +inf) past hn
-    float hx = 0.f, hy = 0.f, ne = __builtin_huge_valf();
+    // this lane's hypothesis: the true point (hx, hy) for the exact test, (fx, fy, E_h) for the cones.
+    // Outside the filter's domain (huge / non-finite coordinates) E = +inf: every voting pixel is "maybe"
+    // and is decided by the exact test.  Past hn E = NaN: nothing ever counts.
+    float hx = 0.f, hy = 0.f, fx = 0.f, fy = 0.f, eh = __builtin_nanf("");
     int hi = h0 + lane;
     if (hi < hn) {
-        float x = hyp[((size_t)inst * hn + hi) * 2], y = hyp[((size_t)inst * hn + hi) * 2 + 1];
-        float s = fabsf(x) + fabsf(y);
-        if (s <= 1e18f) { hx = x; hy = y; ne = -2e-6f * (s + wh); }   // false for inf / NaN
-        else ne = -__builtin_huge_valf();
+        hx = hyp[((size_t)inst * hn + hi) * 2]; hy = hyp[((size_t)inst * hn + hi) * 2 + 1];
+        float s = fabsf(hx) + fabsf(hy);
+        if (s <= 1e18f) { fx = hx; fy = hy; eh = 2e-6f * (s + wh); }   // false for inf / NaN
+        else eh = __builtin_huge_valf();
     }
     if (tn == 0) return;   // uniform
     __syncthreads();
@@ -357,35 +352,46 @@ __global__ __launch_bounds__(256) void k_count_hi(const float4* __restrict__ px,
     int nblk = (tn + kBlk - 1) / kBlk;
     const float qnan = __builtin_nanf("");
     for (int blk = blockIdx.y; blk < nblk; blk += gridDim.y) {
-        float a1x[T], a1y[T], c1[T], a2x[T], a2y[T], c2[T];
+        float ex[T], ey[T], ct[T], cs[T], n1[T];
+        float4 q[T];
 #pragma unroll
         for (int t = 0; t < T; ++t) {
             int j = blk * kBlk + (w * T + t) * kWave + lane;
-            a1x[t] = a1y[t] = a2x[t] = a2y[t] = 0.f;
-            c1[t] = c2[t] = qnan;   // NaN >= x is false: empty slots and zero votes never count
+            ex[t] = ey[t] = 0.f;
+            ct[t] = cs[t] = qnan;   // NaN compares false: empty slots and zero votes are never "maybe"
+            n1[t] = 0.f;
+            q[t] = make_float4(0.f, 0.f, 0.f, 0.f);
             if (j < tn) {
-                float4 q = P[j];
-                float n1 = sqrtf(q.z * q.z + q.w * q.w);
-                if (!below_eps(n1) && n1 <= 3.0e38f) {
-                    float ex = q.z / n1, ey = q.w / n1;
-                    a1x[t] = kappa * ex + ey; a1y[t] = kappa * ey - ex;
-                    a2x[t] = kappa * ex - ey; a2y[t] = kappa * ey + ex;
-                    c1[t] = -(q.x * a1x[t] + q.y * a1y[t]);
-                    c2[t] = -(q.x * a2x[t] + q.y * a2y[t]);
+                q[t] = P[j];
+                n1[t] = sqrtf(q[t].z * q[t].z + q[t].w * q[t].w);
+                if (!below_eps(n1[t]) && n1[t] <= 3.0e38f) {
+                    ex[t] = q[t].z / n1[t]; ey[t] = q[t].w / n1[t];
+                    ct[t] = -(q[t].x * ex[t] + q[t].y * ey[t]);      // t = d . e  = ex gx + ey gy + ct
+                    cs[t] = -(q[t].x * ey[t] - q[t].y * ex[t]);      // s = d x e  = ey gx - ex gy + cs
                 }
             }
         }
-#pragma unroll 4
+#pragma unroll 2
         for (int g = 0; g < kWave; ++g) {
-            float gx = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, hx), g));
-            float gy = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, hy), g));
-            float ge = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, ne), g));
+            float gx = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, fx), g));
+            float gy = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, fy), g));
+            float ge = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, eh), g));
             int c = 0;
 #pragma unroll
             for (int t = 0; t < T; ++t) {
-                float u1 = __builtin_fmaf(a1x[t], gx, __builtin_fmaf(a1y[t], gy, c1[t]));
-                float u2 = __builtin_fmaf(a2x[t], gx, __builtin_fmaf(a2y[t], gy, c2[t]));
-                c += __popcll(__builtin_amdgcn_ballot_w64(u1 >= ge && u2 >= ge));
+                float tt = __builtin_fmaf(ex[t], gx, __builtin_fmaf(ey[t], gy, ct[t]));
+                float ss = fabsf(__builtin_fmaf(ey[t], gx, __builtin_fmaf(-ex[t], gy, cs[t])));
+                bool maybe = ss <= __builtin_fmaf(kappa1, tt, ge);
+                bool sure = ss <= __builtin_fmaf(kappa2, tt, -ge);
+                c += __popcll(__builtin_amdgcn_ballot_w64(sure));
+                unsigned long long band = __builtin_amdgcn_ballot_w64(maybe && !sure);
+                if (band) {      // wave-uniform, rare: the reference's arithmetic for the pairs between the cones
+                    float rx = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, hx), g));
+                    float ry = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, hy), g));
+                    bool in = maybe && !sure &&
+                              pair_is_inlier(q[t].x, q[t].y, q[t].z, q[t].w, n1[t], rx, ry, thresh);
+                    c += __popcll(__builtin_amdgcn_ballot_w64(in));
+                }
             }
             cnt_v += (lane == g) ? c : 0;
         }
@@ -398,18 +404,12 @@ __global__ __launch_bounds__(256) void k_count_hi(const float4* __restrict__ px,
     }
 }
 
-// ---- k_select / k_refine ------------------------------------------------------
+// ---- k_refine ------------------------------------------------------------------
 
-constexpr int kCand = 8;           // candidates re-counted exactly in the first, parallel pass
-constexpr int kSelLds = 4096;      // counts of up to this many hypotheses are staged in LDS for the arg-max rounds
-
-// (max count, lowest index) over counts[0..hn) skipping entries whose bit is set in `done`.
-// Result broadcast to the block through s_int[0..7].
-__device__ __forceinline__ void block_argmax(const int32_t* counts, int hn, const uint32_t* done,
-                                             int* s_int, int& bc, int& bi) {
+// (max count, lowest index) over counts[0..hn).  Result broadcast to the block through s_int[0..7].
+__device__ __forceinline__ void block_argmax(const int32_t* counts, int hn, int* s_int, int& bc, int& bi) {
     bc = -1; bi = 0x7fffffff;
     for (int h = threadIdx.x; h < hn; h += blockDim.x) {
-        if ((done[h >> 5] >> (h & 31)) & 1u) continue;
         int c = counts[h];
         if (c > bc) { bc = c; bi = h; }
     }
@@ -426,32 +426,6 @@ __device__ __forceinline__ void block_argmax(const int32_t* counts, int hn, cons
     for (int i = 1; i < 4; ++i)
         if (s_int[i] > bc || (s_int[i] == bc && s_int[4 + i] < bi)) { bc = s_int[i]; bi = s_int[4 + i]; }
     __syncthreads();
-}
-
-// Exact inlier count of ONE hypothesis over pixels first, first+stride, ...; block total in thread 0.
-__device__ __forceinline__ int exact_count(const float4* __restrict__ P, int tn, int first, int stride, float wx,
-                                           float wy, float thresh, int* s_int) {
-    int c = 0;
-    for (int j0 = first; j0 < tn; j0 += 4 * stride) {
-        float4 q[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            int j = j0 + u * stride;
-            q[u] = j < tn ? P[j] : make_float4(0.f, 0.f, 0.f, 0.f);   // zero vote: never an inlier
-        }
-#pragma unroll
-        for (int u = 0; u < 4; ++u)
-            c += pair_is_inlier(q[u].x, q[u].y, q[u].z, q[u].w, sqrtf(q[u].z * q[u].z + q[u].w * q[u].w), wx, wy,
-                                thresh);
-    }
-    c = wave_reduce_add(c);
-    int lane = threadIdx.x & (kWave - 1), w = threadIdx.x / kWave;
-    __syncthreads();
-    if (lane == 0) s_int[w] = c;
-    __syncthreads();
-    if (threadIdx.x == 0) c = s_int[0] + s_int[1] + s_int[2] + s_int[3];
-    __syncthreads();
-    return c;
 }
 
 // Publish this workgroup's partial record and learn whether it arrived last
@@ -476,107 +450,6 @@ __device__ __forceinline__ bool arrive_last(int32_t* ticket, int nwg, int* s_fla
     return last;
 }
 
-// grid (kSelP, n), 256 threads.  `counts` are upper bounds of the exact inlier counts (or the exact
-// counts themselves).  The kCand hypotheses with the largest bounds are re-counted exactly by all
-// workgroups together; the last arriver decides.  If a bound outside the candidate set can still
-// win, that workgroup keeps walking candidates in decreasing bound order on its own (rare).
-// Writes meta[2] = winner index (-1: no hypothesis has an inlier), meta[3] = its exact count.
-__global__ __launch_bounds__(256) void k_select(const float4* __restrict__ px, int HW, int hn, float thresh,
-                                                int32_t* __restrict__ meta, const float* __restrict__ hyp,
-                                                const int32_t* __restrict__ counts_all,
-                                                int32_t* __restrict__ partial_all, int32_t* __restrict__ tickets, const int32_t* __restrict__ n_dev) {
-    if (n_dev && (int)(blockIdx.y) >= *n_dev) return;   // capacity rows past the device-side instance count
-    __shared__ int s_int[8];
-    __shared__ int s_flag;
-    __shared__ int s_cidx[kCand], s_chi[kCand];
-    __shared__ int s_wc[4][kCand];
-    __shared__ uint32_t s_done[2048];
-    __shared__ int32_t s_counts[kSelLds];
-    int inst = blockIdx.y;
-    int tn = meta[inst * kMeta + 1];
-    if (tn == 0) {
-        if (blockIdx.x == 0 && threadIdx.x == 0) { meta[inst * kMeta + 2] = -1; meta[inst * kMeta + 3] = 0; }
-        return;
-    }
-    const float4* P = px + (size_t)inst * HW;
-    const int32_t* counts = counts_all + (size_t)inst * hn;
-    const float* H = hyp + (size_t)inst * hn * 2;
-    int32_t* partial = partial_all + (size_t)inst * kSelP * kCand;
-
-    for (int i = threadIdx.x; i < 2048; i += blockDim.x) s_done[i] = 0;
-    // arg-max rounds run on an LDS copy of the bounds (a global re-scan per round costs an L2 round trip each)
-    const bool in_lds = hn <= kSelLds;
-    if (in_lds)
-        for (int i = threadIdx.x; i < hn; i += blockDim.x) s_counts[i] = counts[i];
-    __syncthreads();
-    const int32_t* cnt_src = in_lds ? s_counts : counts;
-    // the same candidate list in every workgroup
-    int ncand = 0;
-    for (int k = 0; k < kCand; ++k) {
-        int c_hi, c_idx;
-        block_argmax(cnt_src, hn, s_done, s_int, c_hi, c_idx);
-        if (c_hi <= 0) break;
-        if (threadIdx.x == 0) { s_cidx[k] = c_idx; s_chi[k] = c_hi; s_done[c_idx >> 5] |= 1u << (c_idx & 31); }
-        __syncthreads();
-        ++ncand;
-    }
-    if (ncand == 0) {   // no hypothesis has even a possible inlier
-        if (blockIdx.x == 0 && threadIdx.x == 0) { meta[inst * kMeta + 2] = -1; meta[inst * kMeta + 3] = 0; }
-        return;
-    }
-    // exact counts of the candidates over this workgroup's slice of the pixels
-    float cx[kCand], cy[kCand];
-    int cc[kCand];
-#pragma unroll
-    for (int k = 0; k < kCand; ++k) {
-        int idx = s_cidx[k < ncand ? k : 0];
-        cx[k] = H[2 * idx]; cy[k] = H[2 * idx + 1]; cc[k] = 0;
-    }
-    for (int j = blockIdx.x * 256 + threadIdx.x; j < tn; j += kSelP * 256) {
-        float4 q = P[j];
-        float n1 = sqrtf(q.z * q.z + q.w * q.w);
-#pragma unroll
-        for (int k = 0; k < kCand; ++k) cc[k] += pair_is_inlier(q.x, q.y, q.z, q.w, n1, cx[k], cy[k], thresh);
-    }
-    int lane = threadIdx.x & (kWave - 1), w = threadIdx.x / kWave;
-#pragma unroll
-    for (int k = 0; k < kCand; ++k) {
-        int c = wave_reduce_add(cc[k]);
-        if (lane == 0) s_wc[w][k] = c;
-    }
-    __syncthreads();
-    if (threadIdx.x < kCand)
-        partial[blockIdx.x * kCand + threadIdx.x] =
-            s_wc[0][threadIdx.x] + s_wc[1][threadIdx.x] + s_wc[2][threadIdx.x] + s_wc[3][threadIdx.x];
-    __syncthreads();
-    if (!arrive_last(&tickets[inst], kSelP, &s_flag)) return;
-
-    // last arriver: exact totals, best = (largest count, lowest index)
-    int best_cnt = 0, best_idx = -1;
-    for (int k = 0; k < ncand; ++k) {
-        int tot = 0;
-        for (int i = 0; i < kSelP; ++i) tot += partial[i * kCand + k];
-        int idx = s_cidx[k];
-        if (tot > best_cnt || (tot == best_cnt && tot > 0 && idx < best_idx)) { best_cnt = tot; best_idx = idx; }
-    }
-    // anything outside the candidate set whose bound can still win (or tie with a lower index)?
-    while (true) {
-        int n_hi, n_idx;
-        block_argmax(cnt_src, hn, s_done, s_int, n_hi, n_idx);
-        if (n_hi <= 0 || n_hi < best_cnt || (n_hi == best_cnt && best_idx >= 0 && n_idx > best_idx)) break;
-        int qc = exact_count(P, tn, threadIdx.x, 256, H[2 * n_idx], H[2 * n_idx + 1], thresh, s_int);
-        if (threadIdx.x == 0) { s_done[n_idx >> 5] |= 1u << (n_idx & 31); s_int[0] = qc; }
-        __syncthreads();
-        qc = s_int[0];
-        __syncthreads();
-        if (qc > best_cnt || (qc == best_cnt && qc > 0 && n_idx < best_idx)) { best_cnt = qc; best_idx = n_idx; }
-    }
-    if (threadIdx.x == 0) {
-        meta[inst * kMeta + 2] = best_idx;
-        meta[inst * kMeta + 3] = best_idx >= 0 ? best_cnt : 0;
-    }
-}
-
 // b_inv (RV/ransac_voting_gpu.py:503-516): inverse when regular, pseudo-inverse when singular.
 __device__ __forceinline__ void solve2_sym(double a00, double a01, double a11, double b0, double b1, double& x0,
                                            double& x1) {
@@ -599,22 +472,30 @@ __device__ __forceinline__ void solve2_sym(double a00, double a01, double a11, d
 // workgroup order, so the result is bit-reproducible.
 __global__ __launch_bounds__(256) void k_refine(const float4* __restrict__ px, int HW, int hn, float thresh,
                                                 int32_t* __restrict__ meta, const float* __restrict__ hyp,
+                                                const int32_t* __restrict__ counts_all,
                                                 double* __restrict__ partial_all, int32_t* __restrict__ tickets,
                                                 float* __restrict__ out_xy, const int32_t* __restrict__ n_dev) {
     if (n_dev && (int)(blockIdx.y) >= *n_dev) return;   // capacity rows past the device-side instance count
     __shared__ double s_sum[4][6];
     __shared__ int s_flag;
+    __shared__ int s_int[8];
     int inst = blockIdx.y;
     int tn = meta[inst * kMeta + 1];
     if (tn == 0) {
         if (blockIdx.x == 0 && threadIdx.x == 0) {
-            out_xy[inst * 2] = 0.0f; out_xy[inst * 2 + 1] = 0.0f; meta[inst * kMeta + 4] = 0;
+            out_xy[inst * 2] = 0.0f; out_xy[inst * 2 + 1] = 0.0f;
+            meta[inst * kMeta + 2] = -1; meta[inst * kMeta + 3] = 0; meta[inst * kMeta + 4] = 0;
         }
         return;
     }
     const float4* P = px + (size_t)inst * HW;
     double* partial = partial_all + (size_t)inst * kSelP * kPartial;
-    int widx = meta[inst * kMeta + 2];
+    // winner = (largest exact count, lowest index) as torch.max (RV/ransac_voting_gpu.py:567); every workgroup
+    // finds it for itself.  No hypothesis with an inlier: all_win_pts stays (0,0) (:571-574).
+    int wcnt, widx;
+    block_argmax(counts_all + (size_t)inst * hn, hn, s_int, wcnt, widx);
+    if (wcnt <= 0) { widx = -1; wcnt = 0; }
+    if (blockIdx.x == 0 && threadIdx.x == 0) { meta[inst * kMeta + 2] = widx; meta[inst * kMeta + 3] = wcnt; }
     // all_win_pts stays (0,0) unless some hypothesis has an inlier (:571-574)
     float wx = 0.f, wy = 0.f;
     if (widx >= 0) { wx = hyp[((size_t)inst * hn + widx) * 2]; wy = hyp[((size_t)inst * hn + widx) * 2 + 1]; }
@@ -720,32 +601,27 @@ extern "C" int fpc_ransac_voting_v3(const float* mask, const float* vertex, int6
     hipLaunchKernelGGL(k_hypothesis, dim3(cdiv(hn, 256), n), dim3(256), 0, s, w.px, HW, hn, idxs, seed, w.meta, w.hyp,
                        n_dev);
 
-    // the filter needs th' = th - 1e-6 > 0; otherwise count exactly
+    // the cones need th' = th - 1e-6 > 0; otherwise every pair takes the reference's arithmetic
     bool fast = inlier_thresh > 2e-6f && inlier_thresh < 3.0e38f;
-    auto exact_counts = [&](int32_t* dst) {
+    if (fast) {
+        double th1 = (double)inlier_thresh - 1e-6, th2 = (double)inlier_thresh + 1e-6;
+        double k1 = 1.0 - th1 * th1, k2 = 1.0 - th2 * th2;
+        float kappa1 = (float)((k1 > 0.0 ? sqrt(k1) : 0.0) / th1) * (1.0f + 1e-6f);        // wider
+        float kappa2 = (th2 < 1.0 && k2 > 0.0) ? (float)(sqrt(k2) / th2) * (1.0f - 1e-6f) : 0.0f;   // narrower (0: no "sure")
+        float wh = (float)(W + H);
+        int split = cdiv(max_num < HW ? max_num + max_num / 8 + 64 : HW, kBlkPx);
+        split = split < 1 ? 1 : (split > 64 ? 64 : split);
+        hipLaunchKernelGGL(k_count_hi<kT>, dim3(cdiv(hn, kWave), split, n), dim3(256), 0, s, w.px, HW, hn, wh, kappa1,
+                           kappa2, inlier_thresh, w.meta, w.hyp, w.counts, n_dev);
+    } else {
         int hb = cdiv(hn, 256);
         int split = 2048 / (n * hb);
         split = split < 8 ? 8 : (split > 128 ? 128 : split);
         hipLaunchKernelGGL(k_count_exact, dim3(hb, split, n), dim3(256), 0, s, w.px, HW, hn, inlier_thresh, w.meta,
-                           w.hyp, dst, n_dev);
-    };
-    if (fast) {
-        double thp = (double)inlier_thresh - 1e-6;
-        double k2 = 1.0 - thp * thp;
-        float kappa = (float)((k2 > 0.0 ? sqrt(k2) : 0.0) / thp) * (1.0f + 1e-6f);
-        float wh = (float)(W + H);
-        int split = cdiv(max_num < HW ? max_num + max_num / 8 + 64 : HW, kBlkPx);
-        split = split < 1 ? 1 : (split > 64 ? 64 : split);
-        hipLaunchKernelGGL(k_count_hi<kT>, dim3(cdiv(hn, kWave), split, n), dim3(256), 0, s, w.px, HW, hn, wh, kappa,
-                           idxs, seed, w.meta, w.hyp, w.counts, n_dev);
-        if (out_counts) exact_counts(w.counts_ex);
-    } else {
-        exact_counts(w.counts);
+                           w.hyp, w.counts, n_dev);
     }
-    hipLaunchKernelGGL(k_select, dim3(kSelP, n), dim3(256), 0, s, w.px, HW, hn, inlier_thresh, w.meta, w.hyp,
-                       w.counts, w.partial_i, w.tickets, n_dev);
     hipLaunchKernelGGL(k_refine, dim3(kSelP, n), dim3(256), 0, s, w.px, HW, hn, inlier_thresh, w.meta, w.hyp,
-                       w.partial, w.tickets + n, out_xy, n_dev);
+                       w.counts, w.partial, w.tickets, out_xy, n_dev);
     if (out_tn || out_win_idx || out_win_count || out_inl_count)
         hipLaunchKernelGGL(k_export_meta, dim3(cdiv(n, 256)), dim3(256), 0, s, w.meta, n, out_tn, out_win_idx,
                            out_win_count, out_inl_count);
@@ -754,7 +630,7 @@ extern "C" int fpc_ransac_voting_v3(const float* mask, const float* vertex, int6
         if (e != hipSuccess) { set_hip_error(e); return FPC_ELAUNCH; }
     }
     if (out_counts) {
-        e = hipMemcpyAsync(out_counts, fast ? w.counts_ex : w.counts, sizeof(int32_t) * (size_t)n * hn,
+        e = hipMemcpyAsync(out_counts, w.counts, sizeof(int32_t) * (size_t)n * hn,
                            hipMemcpyDeviceToDevice, s);
         if (e != hipSuccess) { set_hip_error(e); return FPC_ELAUNCH; }
     }

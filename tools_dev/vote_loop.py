@@ -28,7 +28,7 @@ out = torch.empty((n, 2), device=dev)
 st = torch.cuda.current_stream().cuda_stream
 
 def vote(seed):
-    nat.check(lib.fpc_ransac_voting_v3(mask.data_ptr(), vertex.data_ptr(), sn, sh, sw, sc, n, H, W, a.hn, None, None,
+    nat.check(lib.fpc_ransac_voting_v3(mask.data_ptr(), vertex.data_ptr(), sn, sh, sw, sc, n, None, H, W, a.hn, None, None,
                                        seed, 0.999, 5, 30000, out.data_ptr(), None, None, None, None, None, None,
                                        ws.data_ptr(), ws.numel(), st), "vote")
 
