@@ -371,24 +371,30 @@ __global__ __launch_bounds__(256) void k_count_hi(const float4* __restrict__ px,
                 }
             }
         }
-#pragma unroll 2
+#pragma unroll 4
         for (int g = 0; g < kWave; ++g) {
             float gx = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, fx), g));
             float gy = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, fy), g));
             float ge = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, eh), g));
             int c = 0;
+            unsigned long long band[T], any = 0;
 #pragma unroll
-            for (int t = 0; t < T; ++t) {
+            for (int t = 0; t < T; ++t) {          // branch-free: 6 FMA + 2 compares per lane
                 float tt = __builtin_fmaf(ex[t], gx, __builtin_fmaf(ey[t], gy, ct[t]));
                 float ss = fabsf(__builtin_fmaf(ey[t], gx, __builtin_fmaf(-ex[t], gy, cs[t])));
                 bool maybe = ss <= __builtin_fmaf(kappa1, tt, ge);
                 bool sure = ss <= __builtin_fmaf(kappa2, tt, -ge);
                 c += __popcll(__builtin_amdgcn_ballot_w64(sure));
-                unsigned long long band = __builtin_amdgcn_ballot_w64(maybe && !sure);
-                if (band) {      // wave-uniform, rare: the reference's arithmetic for the pairs between the cones
-                    float rx = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, hx), g));
-                    float ry = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, hy), g));
-                    bool in = maybe && !sure &&
+                band[t] = __builtin_amdgcn_ballot_w64(maybe && !sure);
+                any |= band[t];
+            }
+            if (any) {      // wave-uniform, rare: the reference's arithmetic for the pairs between the cones
+                float rx = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, hx), g));
+                float ry = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, hy), g));
+#pragma unroll
+                for (int t = 0; t < T; ++t) {
+                    if (!band[t]) continue;
+                    bool in = ((band[t] >> lane) & 1ull) &&
                               pair_is_inlier(q[t].x, q[t].y, q[t].z, q[t].w, n1[t], rx, ry, thresh);
                     c += __popcll(__builtin_amdgcn_ballot_w64(in));
                 }
