@@ -60,6 +60,7 @@ def parse():
     ap.add_argument("--batch", type=int, default=1, help="frames per GPU per step (1 = BASELINE.json configs[1]; 32 = configs[2]/[3])")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--vote-only", action="store_true", help="time only the post-network stages (profiling aid)")
+    ap.add_argument("--tune-mode", type=int, default=0, help="conv autotune objective: 0 latency, 1 latency x sqrt(chip share)")
     ap.add_argument("--net-streams", type=int, default=2, help="network plans / HIP streams that alternate frames (1 or 2)")
     ap.add_argument("--no-pipeline", action="store_true", help="finish every frame before starting the next (latency mode)")
     return ap.parse_args()
@@ -114,6 +115,7 @@ def main():
     hp.RUNTIME_TIMING = False
     hp.HV_NUM_OF_HYPOTHESES = args.hn
     hp.ENCODER = args.encoder
+    hp.ENGINE_TUNE_MODE = args.tune_mode
     torch.manual_seed(0)
     model = L.pose_regressor.MODELS[hp.MODEL].load_from_ckpt(None, hp).eval()
     model_gpu = model.to(dev)

@@ -45,7 +45,7 @@ _SIGNATURES = {
     "fpc_net_workspace_bytes": (_sz, [_vp]),
     "fpc_net_load_params": (_i, [_vp, _vp, _i, _vp, _sz, _vp]),
     "fpc_net_forward": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
-    "fpc_net_autotune_next": (_i, [_vp]),
+    "fpc_net_autotune_next": (_i, [_vp, _i]),
     "fpc_net_conv_count": (_i, [_vp]),
     "fpc_net_conv_plan": (_i, [_vp, _i, ctypes.POINTER(_i)]),
     "fpc_net_tensor": (_i, [_vp, ctypes.c_char_p, ctypes.POINTER(_vp), ctypes.POINTER(_i), ctypes.POINTER(_i),

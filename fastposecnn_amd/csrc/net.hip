@@ -104,6 +104,7 @@ struct fpc_net {
     bool loaded = false;
     bool tuning = false;          // next forward times every candidate tiling per conv site and keeps the best
     bool tuned = false;
+    int tune_mode = 0;            // 0: minimise latency, 1: latency x sqrt(share of the chip occupied)
 
     // conv indices
     int c_stem = -1;
@@ -407,7 +408,19 @@ int run_conv(fpc_net* n, ConvArgs& a, int groups, int ci, hipStream_t s) {
                 hipEventElapsedTime(&t, e0, e1);
                 if (t < ms) ms = t;
             }
-            if (ms < best_ms) { best_ms = ms; best = q; }
+            // objective: latency, or (throughput mode) latency x the share of the chip the launch occupies —
+            // with several frames in flight a launch that leaves CUs free lets another stream's kernels run
+            float score = ms;
+            if (n->tune_mode == 1) {
+                double nblk = q.wino ? (double)cdiv(cdiv(a.Wo, 2), 8) * cdiv(cdiv(a.Ho, 2), q.wino == 2 ? 8 : 4) * a.B * (a.Cout / 64) * groups
+                                     : (double)q.mtiles * q.ntiles * q.nsplit * a.B * groups;
+                double slots = 256.0 * ((q.wino == 2) ? 1.0 : 2.0);
+                double share = nblk / slots;
+                if (share > 1.0) share = 1.0;
+                if (share < 0.125) share = 0.125;
+                score = ms * (float)sqrt(share);
+            }
+            if (score < best_ms) { best_ms = score; best = q; }
         }
         hipEventDestroy(e0);
         hipEventDestroy(e1);
@@ -587,9 +600,10 @@ extern "C" int fpc_net_forward(fpc_net_t* n, const float* x, float* logits_mask,
 
 // The NEXT fpc_net_forward times every candidate tiling of every convolution site on the device
 // (it synchronises the stream; not capturable) and keeps the fastest; later forwards reuse the plans.
-extern "C" int fpc_net_autotune_next(fpc_net_t* n) {
-    if (!n || !n->loaded) return FPC_EINVAL;
+extern "C" int fpc_net_autotune_next(fpc_net_t* n, int mode) {
+    if (!n || !n->loaded || mode < 0 || mode > 1) return FPC_EINVAL;
     n->tuning = true;
+    n->tune_mode = mode;
     return FPC_OK;
 }
 

@@ -14,7 +14,7 @@ from fastposecnn_amd import _native as nat
 
 class NetEngine:
 
-    def __init__(self, model, B, H, W, device, autotune=True):
+    def __init__(self, model, B, H, W, device, autotune=True, tune_mode=0):
         L = nat.lib()
         self._lib = L
         self.B, self.H, self.W, self.device = B, H, W, device
@@ -46,7 +46,7 @@ class NetEngine:
             nat.check(L.fpc_net_load_params(h, ptrs, n, self._ws.data_ptr(), nbytes, nat.stream()), "fpc_net_load_params")
         if autotune:
             # one (discarded) forward that times every candidate tiling per convolution on this device
-            nat.check(L.fpc_net_autotune_next(h), "fpc_net_autotune_next")
+            nat.check(L.fpc_net_autotune_next(h, int(tune_mode)), "fpc_net_autotune_next")
             self.forward(torch.zeros((B, 3, H, W), dtype=torch.float32, device=device), want_logits=False)
 
     def conv_plans(self):

@@ -167,7 +167,8 @@ int fpc_net_forward(fpc_net_t* net, const float* x, float* logits_mask, float* l
  * (block tile, split-K factor) of every convolution on the device, keeps the fastest, and is itself
  * a valid forward; it synchronises the stream, so it must not be captured into a graph.
  * fpc_net_conv_plan reports the tiling in use for convolution i: out5 = bm, bn, nsplit, Cout, K. */
-int fpc_net_autotune_next(fpc_net_t* net);
+int fpc_net_autotune_next(fpc_net_t* net, int mode /* 0: minimise each conv's latency; 1: latency x sqrt(share of
+                                                      the chip its grid occupies) — for several frames in flight */);
 int fpc_net_conv_count(const fpc_net_t* net);
 int fpc_net_conv_plan(const fpc_net_t* net, int i, int* out5);
 /* Intermediate activations (NHWC f32 inside the workspace) for tests: "stem", "pool", "c2".."c5",

@@ -406,3 +406,72 @@ def test_deferred_post_network_equals_staged(lib, oracle, dev):
             assert fused[k].shape == staged[k].shape and fused[k].dtype == staged[k].dtype, k
             assert torch.equal(fused[k], staged[k]), k
         assert fused["class_ids"].shape[0] == (0 if frames == [3] else 6 * len(frames))
+
+
+# ----------------------------------------------------------------------------- randomised whole-path parity
+
+@pytest.mark.parametrize("seed", [0, 1, 2, 3])
+def test_random_scenes_post_network_vs_oracle(lib, oracle, dev, seed):
+    """Random small scenes (ragged sizes, touching multi-class blobs, specks below min_num, empty images,
+    a blob above max_num) through compress -> CC -> aggregate -> vote -> RT: integer outputs bit-exact
+    against the oracle, floating point within 1e-4."""
+    import gpu_tensor_funcs as gtf
+    import aggregation_layer as al
+    import ransac_voting_gpu_layer.ransac_voting_gpu as rvg
+    rng = np.random.default_rng(seed)
+    B = int(rng.integers(1, 4))
+    H = int(rng.integers(17, 70)); W = int(rng.integers(19, 90))
+    C = 7
+    yy, xx = np.mgrid[0:H, 0:W].astype(np.float32)
+    mask_logits = rng.normal(0, 0.1, (B, C, H, W)).astype(np.float32)
+    mask_logits[:, 0] += 2.0                                               # background wins by default
+    xy = rng.normal(0, 1, (B, 12, H, W)).astype(np.float32)
+    for b in range(B):
+        if seed == 3 and b == 0:
+            continue                                                       # one empty image
+        for k in range(int(rng.integers(1, 5))):
+            cx, cy = rng.uniform(4, W - 4), rng.uniform(4, H - 4)
+            r = rng.uniform(1.0, min(H, W) / 3)
+            cls = int(rng.integers(1, C))
+            blob = ((xx - cx) ** 2 + (yy - cy) ** 2) <= r * r
+            mask_logits[b, cls][blob] += 6.0 + k                           # later blobs win overlaps: touching classes
+            d = np.stack([cx - xx, cy - yy]); d /= np.maximum(np.sqrt((d ** 2).sum(0)), 1e-6)
+            ang = rng.normal(0, 0.02, (H, W)).astype(np.float32)
+            vx = np.cos(ang) * d[0] - np.sin(ang) * d[1]; vy = np.sin(ang) * d[0] + np.cos(ang) * d[1]
+            xy[b, 2 * (cls - 1)][blob] = vx[blob] * 3.0                    # un-normalised: compression normalises
+            xy[b, 2 * (cls - 1) + 1][blob] = vy[blob] * 3.0
+    logits_np = {"mask": mask_logits, "quaternion": rng.normal(0, 1, (B, 24, H, W)).astype(np.float32),
+                 "scales": rng.normal(0, 1, (B, 18, H, W)).astype(np.float32), "xy": xy,
+                 "z": rng.normal(6, 0.2, (B, 6, H, W)).astype(np.float32)}
+    cat = gtf.class_compression_fused(C, {k: T(v, dev) for k, v in logits_np.items()})
+    wcat = oracle.class_compress(logits_np, C)
+    assert np.array_equal(cat["mask"].cpu().numpy(), wcat["mask"])
+    layer = al.AggregationLayer(None, C)
+    agg = layer.forward(cat)
+    want = oracle.aggregate(wcat)
+    n = want["class_ids"].shape[0]
+    assert agg["class_ids"].shape[0] == n
+    if n == 0:
+        return
+    assert np.array_equal(agg["class_ids"].cpu().numpy(), want["class_ids"])
+    assert np.array_equal(agg["sample_ids"].cpu().numpy(), want["sample_ids"])
+    assert np.array_equal(agg["instance_masks"].cpu().numpy(), want["instance_masks"])
+    for k in ("quaternion", "scales", "z"):
+        np.testing.assert_allclose(agg[k].cpu().numpy(), want[k], atol=1e-5, rtol=1e-5)
+    max_num = 60 if seed == 2 else 30000                                   # force the thinning path
+    vertex = agg["xy"].permute(0, 2, 3, 1).unsqueeze(3)
+    out, dbg = rvg.ransac_voting_layer_v3(agg["instance_masks"], vertex, 96, seed=seed + 5, max_num=max_num,
+                                          return_debug=True)
+    wxy, wdbg = oracle.ransac_voting_layer_v3(want["instance_masks"], want["xy"].transpose(0, 2, 3, 1)[:, :, :, None, :],
+                                              96, seed=seed + 5, max_num=max_num, return_debug=True)
+    d = {k: v.cpu().numpy() for k, v in dbg[0].items()}
+    for k in ("tn", "win_idx", "win_count", "inlier_count", "counts"):
+        assert np.array_equal(d[k], wdbg[0][k]), k
+    assert np.array_equal(d["hyp"], wdbg[0]["hyp"], equal_nan=True)
+    np.testing.assert_allclose(out.cpu().numpy(), wxy, atol=1e-4, rtol=1e-6)
+    agg.update({"xy": out.squeeze(1)})
+    kinv = np.linalg.inv(np.array([[577.5, 0, 319.5], [0, 577.5, 239.5], [0, 0, 1]], np.float32)).astype(np.float32)
+    agg = gtf.samplewise_get_RT(agg, T(kinv, dev))
+    R, Tt, RT = oracle.pose_rt(want["quaternion"], wxy[:, 0], want["z"], kinv)
+    np.testing.assert_allclose(agg["R"].cpu().numpy(), R, atol=1e-5)
+    np.testing.assert_allclose(agg["RT"].cpu().numpy(), RT, atol=1e-3, rtol=1e-4)
