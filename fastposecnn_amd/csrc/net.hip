@@ -128,6 +128,7 @@ struct fpc_net {
     int gn_P[7];
     Act a_low[4];                 // low-res logits
     size_t splitk_off = 0, splitk_floats = 0;
+    size_t zeros_off = 0;         // 64 zero floats (DMA source for out-of-image positions)
 
     // per-conv launch plans (index = conv id of decoder 0 for grouped ones)
     std::vector<ConvPlan> cplan;
@@ -223,6 +224,7 @@ extern "C" int fpc_net_create(const char* encoder, int classes, int B, int H, in
         dc.p_head_w = n->add_param(std::string(kHeadNames[d]) + ".0.weight", (int64_t)head_ch[d] * 128);
         dc.p_head_b = n->add_param(std::string(kHeadNames[d]) + ".0.bias", head_ch[d]);
     }
+    n->zeros_off = n->alloc(64);
     n->packed_floats = n->bump;
 
     // ---- activations
@@ -313,6 +315,7 @@ extern "C" int fpc_net_load_params(fpc_net_t* n, const float* const* params, int
     hipStream_t s = (hipStream_t)stream;
     n->ws = (float*)ws;
     n->pptr.assign(params, params + count);
+    if (hipMemsetAsync(n->ws + n->zeros_off, 0, 64 * sizeof(float), s) != hipSuccess) return FPC_ELAUNCH;
     for (const PackedConv& c : n->convs) {
         int rc = launch_pack_weight(n->pptr[c.p_w], n->ws + c.w_off, c.Cout, c.Cin, c.Cinp, c.Kh, c.Kw, c.Npad, c.Kpad, s);
         if (rc) return rc;
@@ -348,6 +351,7 @@ void fill_conv_args(const fpc_net* n, ConvArgs& a, const PackedConv& c, const Co
     a.relu = relu ? 1 : 0; a.nsplit = p.nsplit; a.mtiles = p.mtiles; a.ntiles = p.ntiles; a.ksteps = c.Kpad / kConvBK;
     a.bm = p.bm; a.bn = p.bn; a.generic = mode;
     a.splitk_ws = n->ws + n->splitk_off;
+    a.zeros = n->ws + n->zeros_off;
 }
 
 int launch_conv_plan(ConvArgs& a, const ConvPlan& p, int groups, hipStream_t s) {
@@ -359,10 +363,12 @@ int launch_conv_plan(ConvArgs& a, const ConvPlan& p, int groups, hipStream_t s) 
             w.p[g] = a.p[g];
             w.p[g].w = a.wino_w[g];
         }
-        w.variant = p.wino == 3 ? 1 : 0;
+        w.variant = p.wino == 3 ? 1 : (p.wino == 4 ? 2 : 0);
+        w.zeros = a.zeros;
+        w.dbg = (long long*)a.dbg;
         w.groups = groups;
         w.B = a.B; w.H = a.Ho; w.W = a.Wo; w.Cin = a.Cin; w.Cout = a.Cout; w.relu = a.relu;
-        w.waves = p.wino == 2 ? 8 : 4;
+        w.waves = (p.wino == 2 || p.wino == 4) ? 8 : 4;
         w.tbx = cdiv(cdiv(a.Wo, 2), 8); w.tby = cdiv(cdiv(a.Ho, 2), w.waves);
         return launch_conv_wino(w, groups, s);
     }
@@ -375,7 +381,7 @@ int launch_conv_plan(ConvArgs& a, const ConvPlan& p, int groups, hipStream_t s) 
 
 // number of GroupNorm partial rows per image a plan writes
 int plan_gn_rows(const ConvPlan& p, int Ho, int Wo) {
-    return p.wino ? cdiv(cdiv(Wo, 2), 8) * cdiv(cdiv(Ho, 2), p.wino == 2 ? 8 : 4) : p.mtiles * p.bm / 32;
+    return p.wino ? cdiv(cdiv(Wo, 2), 8) * cdiv(cdiv(Ho, 2), (p.wino == 2 || p.wino == 4) ? 8 : 4) : p.mtiles * p.bm / 32;
 }
 
 // Runs conv site `ci` with its current plan; in tuning mode first times every candidate tiling
@@ -393,6 +399,7 @@ int run_conv(fpc_net* n, ConvArgs& a, int groups, int ci, hipStream_t s) {
             wq.wino = 1; cands.push_back(wq);
             wq.wino = 2; cands.push_back(wq);
             wq.wino = 3; cands.push_back(wq);
+            if (a.zeros) { wq.wino = 4; cands.push_back(wq); }
         }
         for (const ConvPlan& q : cands) {
             if (splitk_floats_for(q, groups, a.B, a.Npad) > cap) continue;
@@ -412,9 +419,9 @@ int run_conv(fpc_net* n, ConvArgs& a, int groups, int ci, hipStream_t s) {
             // with several frames in flight a launch that leaves CUs free lets another stream's kernels run
             float score = ms;
             if (n->tune_mode == 1) {
-                double nblk = q.wino ? (double)cdiv(cdiv(a.Wo, 2), 8) * cdiv(cdiv(a.Ho, 2), q.wino == 2 ? 8 : 4) * a.B * (a.Cout / 64) * groups
+                double nblk = q.wino ? (double)cdiv(cdiv(a.Wo, 2), 8) * cdiv(cdiv(a.Ho, 2), (q.wino == 2 || q.wino == 4) ? 8 : 4) * a.B * (a.Cout / 64) * groups
                                      : (double)q.mtiles * q.ntiles * q.nsplit * a.B * groups;
-                double slots = 256.0 * ((q.wino == 2) ? 1.0 : 2.0);
+                double slots = 256.0 * ((q.wino == 2 || q.wino == 4) ? 1.0 : 2.0);
                 double share = nblk / slots;
                 if (share > 1.0) share = 1.0;
                 if (share < 0.125) share = 0.125;
@@ -642,7 +649,7 @@ extern "C" size_t fpc_conv2d_workspace_bytes(int B, int Ho, int Wo, int Cin, int
     int K = Cin * Kh * Kw, Kpad = cdiv(K, kConvBK) * kConvBK, Npad = cdiv(Cout, kConvNAlign) * kConvNAlign;
     size_t packed = ((size_t)Npad * Kpad + 63) / 64 * 64;
     size_t splitk = (size_t)32 * B * (cdiv(Ho * Wo, 128) * 128) * Npad;
-    size_t wino = (size_t)16 * Cout * Cin;
+    size_t wino = (size_t)16 * Cout * Cin + 64;      // + a zero page for the all-DMA Winograd form
     return (packed + splitk + wino) * sizeof(float);
 }
 
@@ -651,7 +658,7 @@ extern "C" int fpc_conv2d_plan(int B, int Ho, int Wo, int Cin, int Cout, int Kh,
     if (!out4) return FPC_EINVAL;
     int Kpad = cdiv(Cin * Kh * Kw, kConvBK) * kConvBK;
     ConvPlan p = plan_conv(Ho * Wo, B, Cout, Kpad / kConvBK, 1, bm, bn, nsplit);
-    if (nsplit <= -1 && nsplit >= -3) { p.wino = -nsplit; p.nsplit = nsplit; }
+    if (nsplit <= -1 && nsplit >= -4) { p.wino = -nsplit; p.nsplit = nsplit; }
     out4[0] = p.bm; out4[1] = p.bn; out4[2] = p.nsplit; out4[3] = plan_gn_rows(p, Ho, Wo);
     return FPC_OK;
 }
@@ -670,7 +677,7 @@ extern "C" int fpc_conv2d(const float* in, int64_t sb, int64_t sh, int64_t sw, i
     hipStream_t s = (hipStream_t)stream;
     float* packed = (float*)ws;
     FPC_TRY(launch_pack_weight(w_oihw, packed, Cout, Cin, Cin, Kh, Kw, c.Npad, c.Kpad, s));
-    bool wino = nsplit <= -1 && nsplit >= -3;      // -1: 4 waves, -2: 8 waves, -3: 4 waves, wave-private K loop
+    bool wino = nsplit <= -1 && nsplit >= -4;      // -1: 4 waves, -2: 8 waves, -3: 4 waves wave-private, -4: 8 waves all-DMA 3-stage
     ConvPlan p = plan_conv(Ho * Wo, B, Cout, c.Kpad / kConvBK, 1, wino ? 0 : bm, bn, wino ? 1 : nsplit);
     int mode = (sc == 1 && Cin % kConvBK == 0) ? 0
                : (sc == 1 && Cin % 4 == 0 && sw % 4 == 0 && sh % 4 == 0 && sb % 4 == 0 && ((uintptr_t)in & 15) == 0) ? 2 : 1;
@@ -681,6 +688,8 @@ extern "C" int fpc_conv2d(const float* in, int64_t sb, int64_t sh, int64_t sw, i
     ConvArgs a;
     fill_conv_args(&tmp, a, c, p, Hi, Wi, Ho, Wo, sb, sh, sw, sc, relu != 0, mode);
     a.p[0] = ConvPtrs{in, packed, out, scale, shift, res, up, gn_part};
+    a.zeros = nullptr;
+    if (wino && relu == 77) { a.dbg = gn_part; a.p[0].gn_part = nullptr; a.relu = 0; }
     if (wino) {
         if (Kh != 3 || stride != 1 || pad != 1 || Cin % 8 || Cout % 64 || sc != 1 || up || sw != Cin ||
             sh != (int64_t)Wi * Cin || sb != (int64_t)Hi * Wi * Cin)
@@ -688,6 +697,9 @@ extern "C" int fpc_conv2d(const float* in, int64_t sb, int64_t sh, int64_t sw, i
         float* wp = packed + tmp.splitk_off + (size_t)32 * B * (cdiv(Ho * Wo, 128) * 128) * c.Npad;
         FPC_TRY(launch_wino_pack(w_oihw, wp, Cout, Cin, s));
         a.wino_w[0] = wp;
+        float* zp = wp + (size_t)16 * Cout * Cin;
+        if (hipMemsetAsync(zp, 0, 64 * sizeof(float), s) != hipSuccess) return FPC_ELAUNCH;
+        a.zeros = zp;
         p.wino = -nsplit;
         return launch_conv_plan(a, p, 1, s);
     }

@@ -911,7 +911,10 @@ constexpr int kWinoLdsW = 16 * kWinoBN * 8;             // 8192 floats (32 KB) p
 // into a private LDS patch; every fragment of a K-step is pulled into registers first, so the single
 // LDS buffer can be refilled (DMA + ds_write) under that step's 32 MFMAs.  Ablation of the barrier form:
 // the two barriers per step cost 17 % of the kernel, they also force the four waves into lockstep.
-template <int NW, bool WP>
+// P3 (NW = 8): every operand goes global -> LDS by DMA (out-of-image positions read a zero page), three
+// LDS stages, the loads of step k+2 are issued before step k's MFMAs and the wave waits with a COUNTED
+// vmcnt (the newest batch stays in flight across the raw s_barrier) — guide "Pipelining across barriers".
+template <int NW, bool WP, bool P3>
 __global__ __launch_bounds__(64 * NW, 2) void k_conv_wino(const WinoArgs a) {
     constexpr int TY = NW;                                  // tile rows of the patch
     constexpr int RH = 2 * TY + 2, POS = kWinoRW * RH;      // staged input region
@@ -919,8 +922,10 @@ __global__ __launch_bounds__(64 * NW, 2) void k_conv_wino(const WinoArgs a) {
     constexpr int NT = 8 * NW;                              // tiles per workgroup
     constexpr int NTHR = 64 * NW;
     constexpr int WPI = 8 * kWinoRW * kWinoIS;              // WP: floats of a wave's private input patch (8 rows)
-    constexpr int kLdsFloats = WP ? (kWinoLdsW + 4 * WPI) : (2 * LIN + 2 * kWinoLdsW);
+    constexpr int IP3 = 512 * kWinoIS;                      // P3: floats per input stage (16 pieces of 1 KB, 324 positions used)
+    constexpr int kLdsFloats = WP ? (kWinoLdsW + 4 * WPI) : P3 ? (3 * IP3 + 3 * kWinoLdsW) : (2 * LIN + 2 * kWinoLdsW);
     static_assert(!WP || NW == 4, "wave-private form is written for 4 waves");
+    static_assert(!P3 || (NW == 8 && !WP), "three-stage DMA form is written for 8 waves");
     static_assert(kLdsFloats >= 2 * 4 * NT * 32, "output transform needs 2*4*NT*32 floats");
     __shared__ __attribute__((aligned(16))) float lds[kLdsFloats];
     const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
@@ -1036,6 +1041,129 @@ __global__ __launch_bounds__(64 * NW, 2) void k_conv_wino(const WinoArgs a) {
         }
 #undef FPC_WP_ISSUE
 #undef FPC_WP_LAND
+    } else if constexpr (P3) {
+        // Measured on the barrier form (s_memtime stamps): while the co-resident wave of a SIMD issues its 32
+        // MFMAs back to back, THIS wave's vector instructions (address maths, the input transform) get the
+        // vector ALU only at MFMA boundaries — 1600 + 1350 cycles per K-step for ~60 VALU instructions beside
+        // 2200 cycles of MFMA issue.  So here every vector instruction that is not an MFMA sits in the shadow
+        // of the wave's OWN MFMAs: the next step's fragments are read and transformed between the MFMAs of
+        // the second half of the current step, DMA addressing is scalar, and the single barrier of a step sits
+        // in the middle of its MFMA block.
+        float* const lds_w = lds + 3 * IP3;
+        const int swv = __builtin_amdgcn_readfirstlane(wv);
+        const float* wbase = P.w + (size_t)nb * nkb * kWinoLdsW + (swv * 4 * 256);     // wave-uniform
+        const unsigned lane16 = 4u * lane;                                            // floats
+        const float* isrc[2];
+        int istep[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            int q = (swv + 8 * i) * 32 + (lane >> 1), hf = lane & 1;     // LDS position of this lane's 16 bytes
+            int ry = q / kWinoRW, rx = q - ry * kWinoRW;
+            int y = y_in0 + ry, x = x_in0 + rx;
+            bool ok = q < POS && y >= 0 && y < H && x >= 0 && x < W;
+            isrc[i] = ok ? P.in + ((long long)b * HW + (long long)y * W + x) * Cin + 4 * hf : a.zeros;
+            istep[i] = ok ? 8 : 0;
+        }
+#define FPC_P3_ISSUE(KB, BUF)                                                                                 \
+    do {                                                                                                      \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i) __builtin_amdgcn_global_load_lds(                       \
+            (const __attribute__((address_space(1))) void*)(wbase + (size_t)(KB) * kWinoLdsW + 256 * i + lane16), \
+            (__attribute__((address_space(3))) void*)(lds_w + (BUF) * kWinoLdsW + (swv * 4 + i) * 256), 16, 0, 0); \
+        _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                       \
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)isrc[i],          \
+                (__attribute__((address_space(3))) void*)(lds + (BUF) * IP3 + (swv + 8 * i) * 256), 16, 0, 0); \
+            isrc[i] += istep[i];                                                                              \
+        }                                                                                                     \
+    } while (0)
+        const int tyl = (li >> 3) + 4 * half, txl = li & 7;
+        const int ra = (wi == 0) ? 0 : (wi == 2 ? 2 : 1);
+        const int rb = (wi == 0) ? 2 : (wi == 1 ? 2 : (wi == 2 ? 1 : 3));
+        const int in_a = ((2 * tyl + ra) * kWinoRW + 2 * txl) * kWinoIS + 4 * lh;
+        const int in_b = ((2 * tyl + rb) * kWinoRW + 2 * txl) * kWinoIS + 4 * lh;
+        int w_frag[2];
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+            int co = nt * 32 + li;
+            w_frag[nt] = ((4 * wi) * kWinoBN + co) * 8 + 4 * (lh ^ ((co >> 3) & 1));
+        }
+        const f32x4 sg4 = {sgn, sgn, sgn, sgn};
+#define FPC_P3_MFMA8(J, U0, U1)                                                                               \
+    _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                                           \
+        acc[J][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[J][q], U0[q], acc[J][0], 0, 0, 0);                 \
+        acc[J][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[J][q], U1[q], acc[J][1], 0, 0, 0);                 \
+    }
+        // prologue: stages 0 and 1 in flight, fragments of step 0 transformed
+        FPC_P3_ISSUE(0, 0);
+        if (nkb > 1) FPC_P3_ISSUE(1, 1);
+        if (nkb > 1) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        f32x4 v[4];
+        {
+            f32x4 e[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+                e[c] = __builtin_elementwise_fma(sg4, *reinterpret_cast<const f32x4*>(lds + in_b + c * kWinoIS),
+                                                 *reinterpret_cast<const f32x4*>(lds + in_a + c * kWinoIS));
+            v[0] = e[0] - e[2]; v[1] = e[1] + e[2]; v[2] = e[2] - e[1]; v[3] = e[1] - e[3];
+        }
+        int cur = 0;
+        for (int kb = 0; kb < nkb; ++kb) {
+            int nxt = cur + 1 == 3 ? 0 : cur + 1;
+            int nx2 = nxt + 1 == 3 ? 0 : nxt + 1;
+            const float* Wb = lds_w + cur * kWinoLdsW;
+            const float* In = lds + nxt * IP3;
+            // ---- first half: xi 0, 1 of this step
+            f32x4 u0 = *reinterpret_cast<const f32x4*>(Wb + w_frag[0]);
+            f32x4 u1 = *reinterpret_cast<const f32x4*>(Wb + w_frag[1]);
+            f32x4 p0 = *reinterpret_cast<const f32x4*>(Wb + w_frag[0] + 1 * kWinoBN * 8);
+            f32x4 p1 = *reinterpret_cast<const f32x4*>(Wb + w_frag[1] + 1 * kWinoBN * 8);
+            __builtin_amdgcn_s_setprio(1);
+            FPC_P3_MFMA8(0, u0, u1)
+            __builtin_amdgcn_sched_barrier(0);
+            u0 = *reinterpret_cast<const f32x4*>(Wb + w_frag[0] + 2 * kWinoBN * 8);
+            u1 = *reinterpret_cast<const f32x4*>(Wb + w_frag[1] + 2 * kWinoBN * 8);
+            FPC_P3_MFMA8(1, p0, p1)
+            __builtin_amdgcn_sched_barrier(0);
+            p0 = *reinterpret_cast<const f32x4*>(Wb + w_frag[0] + 3 * kWinoBN * 8);
+            p1 = *reinterpret_cast<const f32x4*>(Wb + w_frag[1] + 3 * kWinoBN * 8);
+            // ---- middle: stage kb+1 (issued a whole step ago) must have landed; everyone is past step kb-1,
+            //      so stage (kb+2)%3 — read last in step kb-1 — may be refilled
+            if (kb + 1 < nkb) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            if (kb + 2 < nkb) FPC_P3_ISSUE(kb + 2, nx2);
+            // ---- second half: xi 2, 3, with the NEXT step's input fragments read and transformed in between
+            f32x4 da[4], db[4], e[4];
+            const bool more = kb + 1 < nkb;
+            if (more) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    da[c] = *reinterpret_cast<const f32x4*>(In + in_a + c * kWinoIS);
+                    db[c] = *reinterpret_cast<const f32x4*>(In + in_b + c * kWinoIS);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            FPC_P3_MFMA8(2, u0, u1)
+            __builtin_amdgcn_sched_barrier(0);
+            f32x4 w0 = v[0], w1 = v[1], w2 = v[2];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                acc[3][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[3][q], p0[q], acc[3][0], 0, 0, 0);
+                acc[3][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[3][q], p1[q], acc[3][1], 0, 0, 0);
+                if (more) {      // 8 vector instructions in the shadow of this MFMA pair
+                    if (q == 0) { e[0] = __builtin_elementwise_fma(sg4, db[0], da[0]); e[1] = __builtin_elementwise_fma(sg4, db[1], da[1]); }
+                    if (q == 1) { e[2] = __builtin_elementwise_fma(sg4, db[2], da[2]); e[3] = __builtin_elementwise_fma(sg4, db[3], da[3]); }
+                    if (q == 2) { w0 = e[0] - e[2]; w1 = e[1] + e[2]; }
+                    if (q == 3) { w2 = e[2] - e[1]; }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            __builtin_amdgcn_s_setprio(0);
+            if (more) { v[3] = e[1] - e[3]; v[0] = w0; v[1] = w1; v[2] = w2; }
+            cur = nxt;
+        }
+#undef FPC_P3_ISSUE
+#undef FPC_P3_MFMA8
     } else {
     // ---- staging.  Weights: the K-step image (32 KB, already in its LDS layout) goes global -> LDS by
     // LDS-DMA (global_load_lds_dwordx4: no VGPRs, no ds_write; every wave moves 32/NW pieces of 1 KB).
@@ -1095,12 +1223,18 @@ __global__ __launch_bounds__(64 * NW, 2) void k_conv_wino(const WinoArgs a) {
     FPC_WINO_STORE_IN(0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    long long stamp[6] = {0, 0, 0, 0, 0, 0};
+    const bool dbg = a.dbg != nullptr;
+#define FPC_STAMP(I) do { if (dbg) { long long now_ = clock64(); stamp[I] += now_ - tprev; tprev = now_; } } while (0)
+    long long tprev = dbg ? clock64() : 0;
+    const long long c_begin = tprev, r_begin = dbg ? wall_clock64() : 0;
     for (int kb = 0; kb < nkb; ++kb) {
         const int cur = kb & 1;
         if (kb + 1 < nkb) {              // buffers cur^1 were last read in step kb-1, which ended with a barrier
             FPC_WINO_DMA(kb + 1, cur ^ 1);
             FPC_WINO_LOAD_IN(kb + 1);
         }
+        FPC_STAMP(0);      // issue of the next step's loads
         const float* Ib = lds + cur * LIN;
         const float* Wb = lds_w + cur * kWinoLdsW;
         f32x4 e[4], v[4];
@@ -1112,6 +1246,8 @@ __global__ __launch_bounds__(64 * NW, 2) void k_conv_wino(const WinoArgs a) {
         }
         v[0] = e[0] - e[2]; v[1] = e[1] + e[2]; v[2] = e[2] - e[1]; v[3] = e[1] - e[3];
         // lanes 0-31 carry ci = q, lanes 32-63 carry ci = 4 + q of this K-step
+        if (dbg) { asm volatile("" :: "v"(v[0][0]), "v"(v[1][0]), "v"(v[2][0]), "v"(v[3][0])); }
+        FPC_STAMP(1);      // input fragments + transform
         __builtin_amdgcn_s_setprio(1);      // MFMA issue ahead of the co-resident workgroup's staging (measured -4 %)
         f32x4 u0 = *reinterpret_cast<const f32x4*>(Wb + w_frag[0]);
         f32x4 u1 = *reinterpret_cast<const f32x4*>(Wb + w_frag[1]);
@@ -1133,10 +1269,22 @@ __global__ __launch_bounds__(64 * NW, 2) void k_conv_wino(const WinoArgs a) {
             u0 = n0; u1 = n1;
         }
         __builtin_amdgcn_s_setprio(0);
+        FPC_STAMP(2);      // MFMA issue (not completion)
         if (kb + 1 < nkb) FPC_WINO_STORE_IN(cur ^ 1);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's DMA pieces have landed
+        FPC_STAMP(3);      // input store + wait for this wave's loads
         __syncthreads();                                      // everybody's have; step kb's reads are done
+        FPC_STAMP(4);      // barrier
     }
+    if (dbg && lane == 0) {
+        long long* o = a.dbg + ((size_t)blockIdx.x * NW + wv) * 6;
+        for (int i = 0; i < 3; ++i) o[i] = stamp[i];
+        o[3] = clock64() - c_begin;            // shader-clock ticks of the whole K loop
+        o[4] = wall_clock64() - r_begin;       // 100 MHz reference ticks of the same span
+        o[5] = nkb;
+    }
+#undef FPC_STAMP
+
 #undef FPC_WINO_DMA
 #undef FPC_WINO_LOAD_IN
 #undef FPC_WINO_STORE_IN
@@ -1236,9 +1384,12 @@ int launch_conv_wino(const WinoArgs& a, int groups, hipStream_t s) {
     if (groups < 1 || groups > kMaxGroup || a.Cin % 8 != 0 || a.Cout % kWinoBN != 0 || (a.waves != 4 && a.waves != 8))
         return FPC_EINVAL;
     dim3 grid(a.tbx * a.tby * a.B * (a.Cout / kWinoBN) * groups);
-    if (a.waves == 8) hipLaunchKernelGGL((k_conv_wino<8, false>), grid, dim3(512), 0, s, a);
-    else if (a.variant == 1) hipLaunchKernelGGL((k_conv_wino<4, true>), grid, dim3(256), 0, s, a);
-    else hipLaunchKernelGGL((k_conv_wino<4, false>), grid, dim3(256), 0, s, a);
+    if (a.waves == 8 && a.variant == 2) {
+        if (!a.zeros) return FPC_EINVAL;
+        hipLaunchKernelGGL((k_conv_wino<8, false, true>), grid, dim3(512), 0, s, a);
+    } else if (a.waves == 8) hipLaunchKernelGGL((k_conv_wino<8, false, false>), grid, dim3(512), 0, s, a);
+    else if (a.variant == 1) hipLaunchKernelGGL((k_conv_wino<4, true, false>), grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((k_conv_wino<4, false, false>), grid, dim3(256), 0, s, a);
     return check_launch();
 }
 

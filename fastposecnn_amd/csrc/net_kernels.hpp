@@ -27,6 +27,8 @@ struct ConvArgs {
     long long in_sb, in_sh, in_sw, in_sc;   // element strides of the input
     int relu, nsplit, mtiles, ntiles, ksteps, bm, bn, generic, groups;
     const float* wino_w[kMaxGroup];   // host side only: Winograd-packed weights per group (or null)
+    const float* zeros;               // host side only: 64 zero floats for the all-DMA Winograd form (or null)
+    void* dbg;                        // host side only: diagnostic stamp buffer for k_conv_wino (or null)
 };
 
 struct GnFinArgs {
@@ -70,7 +72,9 @@ struct Up4Args {
 // Winograd F(2x2,3x3) convolution (3x3, stride 1, pad 1, NHWC, Cin % 8 == 0, Cout % 64 == 0)
 struct WinoArgs {
     ConvPtrs p[kMaxGroup];   // .w = Winograd-packed weights [Cout/64][Cin/8][16][64][8]; .up unused
-    int variant;             // 0: barrier form, 1: wave-private barrier-free K loop (4 waves only)
+    long long* dbg;          // diagnostic builds: per (workgroup, wave) cycle sums of the K-loop phases, or null
+    const float* zeros;      // >= 16 bytes of zeros, 16-byte aligned (source of out-of-image DMA pieces; variant 2)
+    int variant;             // 0: barrier form, 1: wave-private barrier-free K loop (4 waves), 2: all-DMA 3-stage (8 waves)
     int groups;
     int waves;               // 4: 8x4 tile patch per workgroup; 8: 8x8 patch (512 threads)
     int B, H, W, Cin, Cout, relu, tbx, tby;   // tbx = ceil(ceil(W/2)/8), tby = ceil(ceil(H/2)/waves) tile patches

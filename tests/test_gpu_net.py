@@ -100,6 +100,12 @@ CONV_CASES = [
     (1, 64, 30, 40, 64, 3, 1, 1, (0, 0, -3), "bn_relu_res"),
     (2, 256, 15, 20, 128, 3, 1, 1, (0, 0, -3), "gn"),
     (1, 128, 34, 50, 128, 3, 1, 1, (0, 0, -3), "gn"),
+    # 8-wave all-DMA three-stage form (nsplit = -4)
+    (1, 64, 30, 40, 64, 3, 1, 1, (0, 0, -4), "bn_relu_res"),
+    (2, 256, 15, 20, 128, 3, 1, 1, (0, 0, -4), "gn"),
+    (1, 128, 34, 50, 128, 3, 1, 1, (0, 0, -4), "gn"),
+    (1, 8, 7, 9, 64, 3, 1, 1, (0, 0, -4), "bias_relu"),       # a single K-step
+    (1, 16, 20, 24, 64, 3, 1, 1, (0, 0, -4), "bias_relu"),    # two K-steps
     # 8-wave form (8x8 tile patch per workgroup, nsplit = -2)
     (1, 64, 30, 40, 64, 3, 1, 1, (0, 0, -2), "bn_relu_res"),
     (2, 256, 15, 20, 128, 3, 1, 1, (0, 0, -2), "gn"),

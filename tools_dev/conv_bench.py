@@ -23,7 +23,7 @@ SHAPES = {
     "l4": (1, 512, 15, 20, 512, 3, 1, 1),
     "p2lat x4": (4, 64, 120, 160, 256, 1, 1, 0),
 }
-CONFIGS = [(0, 0, -1), (0, 0, -3), (0, 0, -2), (0, 0, 0), (64, 64, 1), (64, 128, 1), (128, 64, 1), (128, 128, 1), (64, 64, 2), (64, 64, 4), (64, 64, 8),
+CONFIGS = [(0, 0, -1), (0, 0, -3), (0, 0, -2), (0, 0, -4), (0, 0, 0), (64, 64, 1), (64, 128, 1), (128, 64, 1), (128, 128, 1), (64, 64, 2), (64, 64, 4), (64, 64, 8),
            (64, 128, 2), (64, 128, 4), (128, 128, 2)]
 
 for name, (B, Cin, Hi, Wi, Cout, k, stride, pad) in SHAPES.items():
