@@ -144,9 +144,10 @@ class Model(object):
             classes=len(HPARAM.SELECTED_CLASSES),
         )
         model.TIMERS = [MODEL_TIMER, AGG_TIMER, HV_TIMER, RT_CAL_TIMER, CLASS_COMPRESS_TIMER, FORWARD_TIMER]
-        if HPARAM.RUNTIME_TIMING:
-            for timer in model.TIMERS:
-                timer.enabled = True
+        # the timers are module-level objects (as in the reference): set them from THIS model's flag so that a
+        # model built with RUNTIME_TIMING=False is not timed because an earlier one asked for it
+        for timer in model.TIMERS:
+            timer.enabled = bool(HPARAM.RUNTIME_TIMING)
         return model
 
     def report_runtime(self):

@@ -25,7 +25,7 @@ class TimerDecorator(object):
 
         @functools.wraps(function)
         def wrapper(*args, **kwargs):
-            if not self.enabled:
+            if not self.enabled or not torch.cuda.is_available():
                 return function(*args, **kwargs)
             if self.start is None:
                 self.start = torch.cuda.Event(enable_timing=True)
