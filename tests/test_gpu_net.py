@@ -292,3 +292,37 @@ def test_frame_streamer_matches_forward(lib, dev):
         for k, v in ref[i][2].items():
             assert torch.equal(out["aggregated"][k], v), (i, k)
         assert out["aggregated"]["class_ids"].shape[0] == 3
+
+
+def test_forward_with_runtime_timing_and_report(lib, dev, capsys):
+    """config.INFERENCE defaults (RUNTIME_TIMING=True): the stage-by-stage path with the reference's six
+    timers; whole forward() on a small frame with random weights (many tiny instances), schema check."""
+    from fastposecnn_amd import config, synth
+    hp = config.INFERENCE()
+    hp.HV_NUM_OF_HYPOTHESES = 32
+    torch.manual_seed(0)
+    m = lib.pose_regressor.MODELS['PoseRegressor'].load_from_ckpt(None, hp).to(dev).eval()
+    x = torch.stack([synth.make_image(i, 64, 96) for i in range(2)]).to(dev)
+    with torch.no_grad():
+        out = m(x)
+        out2 = m(x)
+    agg = out["aggregated"]
+    n = agg["class_ids"].shape[0]
+    assert n == out2["aggregated"]["class_ids"].shape[0]
+    for k, shp in (("instance_masks", (n, 64, 96)), ("quaternion", (n, 4)), ("scales", (n, 3)), ("xy", (n, 2)),
+                   ("z", (n, 1)), ("R", (n, 3, 3)), ("T", (n, 3)), ("RT", (n, 4, 4)), ("hypothesis", (n, 1, 2)),
+                   ("xy_mask", (n, 2, 64, 96)), ("sample_ids", (n,))):
+        assert tuple(agg[k].shape) == shp, k
+    if n:
+        assert int(agg["sample_ids"].max()) <= 1 and int(agg["class_ids"].min()) >= 1
+        # the instance masks partition the foreground of their images
+        fg = (out["categorical"]["mask"] != 0).float()
+        cover = torch.zeros_like(fg).index_add_(0, agg["sample_ids"], agg["instance_masks"])
+        assert torch.equal(cover, fg)
+    m.report_runtime()
+    printed = capsys.readouterr().out
+    for name in ("forward", "model", "Aggregation", "Hough Voting", "RT Calculation", "Class Compression"):
+        assert name + ":" in printed
+    hp.RUNTIME_TIMING = False
+    m2 = lib.pose_regressor.MODELS['PoseRegressor'].construct_model(hp)       # resets the module-level timers
+    assert not any(t.enabled for t in m2.TIMERS)
