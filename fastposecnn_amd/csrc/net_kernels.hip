@@ -914,7 +914,8 @@ constexpr int kWinoLdsW = 16 * kWinoBN * 8;             // 8192 floats (32 KB) p
 // P3 (NW = 8): every operand goes global -> LDS by DMA (out-of-image positions read a zero page), three
 // LDS stages, the loads of step k+2 are issued before step k's MFMAs and the wave waits with a COUNTED
 // vmcnt (the newest batch stays in flight across the raw s_barrier) — guide "Pipelining across barriers".
-template <int NW, bool WP, bool P3>
+// DBG: diagnostic instantiations that stamp the K-loop phases with s_memtime (tools_dev/wino_stamps.py).
+template <int NW, bool WP, bool P3, bool DBG = false>
 __global__ __launch_bounds__(64 * NW, 2) void k_conv_wino(const WinoArgs a) {
     constexpr int TY = NW;                                  // tile rows of the patch
     constexpr int RH = 2 * TY + 2, POS = kWinoRW * RH;      // staged input region
@@ -1107,6 +1108,11 @@ __global__ __launch_bounds__(64 * NW, 2) void k_conv_wino(const WinoArgs a) {
                                                  *reinterpret_cast<const f32x4*>(lds + in_a + c * kWinoIS));
             v[0] = e[0] - e[2]; v[1] = e[1] + e[2]; v[2] = e[2] - e[1]; v[3] = e[1] - e[3];
         }
+        long long stamp[6] = {0, 0, 0, 0, 0, 0};
+        const bool dbg = DBG && a.dbg != nullptr;
+#define FPC_STAMP(I) do { if (DBG && dbg) { long long now_ = clock64(); stamp[I] += now_ - tprev; tprev = now_; } } while (0)
+        long long tprev = dbg ? clock64() : 0;
+        const long long c_begin = tprev, r_begin = dbg ? wall_clock64() : 0;
         int cur = 0;
         for (int kb = 0; kb < nkb; ++kb) {
             int nxt = cur + 1 == 3 ? 0 : cur + 1;
@@ -1127,10 +1133,13 @@ __global__ __launch_bounds__(64 * NW, 2) void k_conv_wino(const WinoArgs a) {
             __builtin_amdgcn_sched_barrier(0);
             p0 = *reinterpret_cast<const f32x4*>(Wb + w_frag[0] + 3 * kWinoBN * 8);
             p1 = *reinterpret_cast<const f32x4*>(Wb + w_frag[1] + 3 * kWinoBN * 8);
+            FPC_STAMP(0);      // first half: 16 MFMA issued
             // ---- middle: stage kb+1 (issued a whole step ago) must have landed; everyone is past step kb-1,
             //      so stage (kb+2)%3 — read last in step kb-1 — may be refilled
             if (kb + 1 < nkb) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            FPC_STAMP(1);      // wait for this wave's DMA pieces
             __builtin_amdgcn_s_barrier();
+            FPC_STAMP(2);      // barrier
             if (kb + 2 < nkb) FPC_P3_ISSUE(kb + 2, nx2);
             // ---- second half: xi 2, 3, with the NEXT step's input fragments read and transformed in between
             f32x4 da[4], db[4], e[4];
@@ -1160,8 +1169,15 @@ __global__ __launch_bounds__(64 * NW, 2) void k_conv_wino(const WinoArgs a) {
             }
             __builtin_amdgcn_s_setprio(0);
             if (more) { v[3] = e[1] - e[3]; v[0] = w0; v[1] = w1; v[2] = w2; }
+            FPC_STAMP(3);      // DMA issue + second half (16 MFMA + next step's fragments)
             cur = nxt;
         }
+        if (dbg && lane == 0) {
+            long long* o = a.dbg + ((size_t)blockIdx.x * NW + wv) * 6;
+            o[0] = stamp[0]; o[1] = stamp[1] + stamp[2]; o[2] = stamp[3];
+            o[3] = clock64() - c_begin; o[4] = wall_clock64() - r_begin; o[5] = nkb;
+        }
+#undef FPC_STAMP
 #undef FPC_P3_ISSUE
 #undef FPC_P3_MFMA8
     } else {
@@ -1224,8 +1240,8 @@ __global__ __launch_bounds__(64 * NW, 2) void k_conv_wino(const WinoArgs a) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     long long stamp[6] = {0, 0, 0, 0, 0, 0};
-    const bool dbg = a.dbg != nullptr;
-#define FPC_STAMP(I) do { if (dbg) { long long now_ = clock64(); stamp[I] += now_ - tprev; tprev = now_; } } while (0)
+    const bool dbg = DBG && a.dbg != nullptr;
+#define FPC_STAMP(I) do { if (DBG && dbg) { long long now_ = clock64(); stamp[I] += now_ - tprev; tprev = now_; } } while (0)
     long long tprev = dbg ? clock64() : 0;
     const long long c_begin = tprev, r_begin = dbg ? wall_clock64() : 0;
     for (int kb = 0; kb < nkb; ++kb) {
@@ -1246,7 +1262,7 @@ __global__ __launch_bounds__(64 * NW, 2) void k_conv_wino(const WinoArgs a) {
         }
         v[0] = e[0] - e[2]; v[1] = e[1] + e[2]; v[2] = e[2] - e[1]; v[3] = e[1] - e[3];
         // lanes 0-31 carry ci = q, lanes 32-63 carry ci = 4 + q of this K-step
-        if (dbg) { asm volatile("" :: "v"(v[0][0]), "v"(v[1][0]), "v"(v[2][0]), "v"(v[3][0])); }
+        if (DBG && dbg) { asm volatile("" :: "v"(v[0][0]), "v"(v[1][0]), "v"(v[2][0]), "v"(v[3][0])); }
         FPC_STAMP(1);      // input fragments + transform
         __builtin_amdgcn_s_setprio(1);      // MFMA issue ahead of the co-resident workgroup's staging (measured -4 %)
         f32x4 u0 = *reinterpret_cast<const f32x4*>(Wb + w_frag[0]);
@@ -1386,9 +1402,11 @@ int launch_conv_wino(const WinoArgs& a, int groups, hipStream_t s) {
     dim3 grid(a.tbx * a.tby * a.B * (a.Cout / kWinoBN) * groups);
     if (a.waves == 8 && a.variant == 2) {
         if (!a.zeros) return FPC_EINVAL;
-        hipLaunchKernelGGL((k_conv_wino<8, false, true>), grid, dim3(512), 0, s, a);
+        if (a.dbg) hipLaunchKernelGGL((k_conv_wino<8, false, true, true>), grid, dim3(512), 0, s, a);
+        else hipLaunchKernelGGL((k_conv_wino<8, false, true>), grid, dim3(512), 0, s, a);
     } else if (a.waves == 8) hipLaunchKernelGGL((k_conv_wino<8, false, false>), grid, dim3(512), 0, s, a);
     else if (a.variant == 1) hipLaunchKernelGGL((k_conv_wino<4, true, false>), grid, dim3(256), 0, s, a);
+    else if (a.dbg) hipLaunchKernelGGL((k_conv_wino<4, false, false, true>), grid, dim3(256), 0, s, a);
     else hipLaunchKernelGGL((k_conv_wino<4, false, false>), grid, dim3(256), 0, s, a);
     return check_launch();
 }
