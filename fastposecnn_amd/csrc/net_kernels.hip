@@ -23,6 +23,18 @@ namespace fpc {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));   // native vector: stays in registers (HIP's float4 struct copies can land in scratch)
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// a - b as two v_pk_add_f32 with negated second operand (the compiler splits a vector subtraction into four
+// v_sub_f32).  Same IEEE result as the scalar subtraction.
+__device__ __forceinline__ f32x4 sub_pk(f32x4 a, f32x4 b) {
+    f32x2 al = __builtin_shufflevector(a, a, 0, 1), ah = __builtin_shufflevector(a, a, 2, 3);
+    f32x2 bl = __builtin_shufflevector(b, b, 0, 1), bh = __builtin_shufflevector(b, b, 2, 3);
+    f32x2 rl, rh;
+    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(rl) : "v"(al), "v"(bl));
+    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(rh) : "v"(ah), "v"(bh));
+    return __builtin_shufflevector(rl, rh, 0, 1, 2, 3);
+}
 
 constexpr int kLdsRow = kConvBK + 4;   // 36 floats: 16 distinct 16-byte slots for 16 consecutive rows
 
@@ -919,12 +931,11 @@ template <int NW, bool WP, bool P3, bool DBG = false>
 __global__ __launch_bounds__(64 * NW, 2) void k_conv_wino(const WinoArgs a) {
     constexpr int TY = NW;                                  // tile rows of the patch
     constexpr int RH = 2 * TY + 2, POS = kWinoRW * RH;      // staged input region
-    constexpr int LIN = POS * kWinoIS;                      // floats per input buffer
     constexpr int NT = 8 * NW;                              // tiles per workgroup
-    constexpr int NTHR = 64 * NW;
     constexpr int WPI = 8 * kWinoRW * kWinoIS;              // WP: floats of a wave's private input patch (8 rows)
     constexpr int IP3 = 512 * kWinoIS;                      // P3: floats per input stage (16 pieces of 1 KB, 324 positions used)
-    constexpr int kLdsFloats = WP ? (kWinoLdsW + 4 * WPI) : P3 ? (3 * IP3 + 3 * kWinoLdsW) : (2 * LIN + 2 * kWinoLdsW);
+    constexpr int NPI = (POS + 31) / 32, LINP = NPI * 256;   // barrier form: 1 KB input pieces per stage, floats per input buffer
+    constexpr int kLdsFloats = WP ? (kWinoLdsW + 4 * WPI) : P3 ? (3 * IP3 + 3 * kWinoLdsW) : (2 * LINP + 2 * kWinoLdsW);
     static_assert(!WP || NW == 4, "wave-private form is written for 4 waves");
     static_assert(!P3 || (NW == 8 && !WP), "three-stage DMA form is written for 8 waves");
     static_assert(kLdsFloats >= 2 * 4 * NT * 32, "output transform needs 2*4*NT*32 floats");
@@ -1025,7 +1036,7 @@ __global__ __launch_bounds__(64 * NW, 2) void k_conv_wino(const WinoArgs a) {
                 u[j][0] = *reinterpret_cast<const f32x4*>(Wp + j * 512 + w_frag[0]);
                 u[j][1] = *reinterpret_cast<const f32x4*>(Wp + j * 512 + w_frag[1]);
             }
-            v[0] = e[0] - e[2]; v[1] = e[1] + e[2]; v[2] = e[2] - e[1]; v[3] = e[1] - e[3];
+            v[0] = sub_pk(e[0], e[2]); v[1] = e[1] + e[2]; v[2] = sub_pk(e[2], e[1]); v[3] = sub_pk(e[1], e[3]);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    // LDS reads complete: the patch may be refilled
             __builtin_amdgcn_sched_barrier(0);
             if (kb + 1 < nkb) FPC_WP_ISSUE(kb + 1);
@@ -1106,7 +1117,7 @@ __global__ __launch_bounds__(64 * NW, 2) void k_conv_wino(const WinoArgs a) {
             for (int c = 0; c < 4; ++c)
                 e[c] = __builtin_elementwise_fma(sg4, *reinterpret_cast<const f32x4*>(lds + in_b + c * kWinoIS),
                                                  *reinterpret_cast<const f32x4*>(lds + in_a + c * kWinoIS));
-            v[0] = e[0] - e[2]; v[1] = e[1] + e[2]; v[2] = e[2] - e[1]; v[3] = e[1] - e[3];
+            v[0] = sub_pk(e[0], e[2]); v[1] = e[1] + e[2]; v[2] = sub_pk(e[2], e[1]); v[3] = sub_pk(e[1], e[3]);
         }
         long long stamp[6] = {0, 0, 0, 0, 0, 0};
         const bool dbg = DBG && a.dbg != nullptr;
@@ -1162,13 +1173,13 @@ __global__ __launch_bounds__(64 * NW, 2) void k_conv_wino(const WinoArgs a) {
                 if (more) {      // 8 vector instructions in the shadow of this MFMA pair
                     if (q == 0) { e[0] = __builtin_elementwise_fma(sg4, db[0], da[0]); e[1] = __builtin_elementwise_fma(sg4, db[1], da[1]); }
                     if (q == 1) { e[2] = __builtin_elementwise_fma(sg4, db[2], da[2]); e[3] = __builtin_elementwise_fma(sg4, db[3], da[3]); }
-                    if (q == 2) { w0 = e[0] - e[2]; w1 = e[1] + e[2]; }
-                    if (q == 3) { w2 = e[2] - e[1]; }
+                    if (q == 2) { w0 = sub_pk(e[0], e[2]); w1 = e[1] + e[2]; }
+                    if (q == 3) { w2 = sub_pk(e[2], e[1]); }
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
             __builtin_amdgcn_s_setprio(0);
-            if (more) { v[3] = e[1] - e[3]; v[0] = w0; v[1] = w1; v[2] = w2; }
+            if (more) { v[3] = sub_pk(e[1], e[3]); v[0] = w0; v[1] = w1; v[2] = w2; }
             FPC_STAMP(3);      // DMA issue + second half (16 MFMA + next step's fragments)
             cur = nxt;
         }
@@ -1181,42 +1192,50 @@ __global__ __launch_bounds__(64 * NW, 2) void k_conv_wino(const WinoArgs a) {
 #undef FPC_P3_ISSUE
 #undef FPC_P3_MFMA8
     } else {
-    // ---- staging.  Weights: the K-step image (32 KB, already in its LDS layout) goes global -> LDS by
-    // LDS-DMA (global_load_lds_dwordx4: no VGPRs, no ds_write; every wave moves 32/NW pieces of 1 KB).
-    // Input: 2 float4 per thread through registers (zero fill at the image border).
-    constexpr int NPIECE = 32 / NW;
-    const float* wsrc = P.w + (size_t)nb * nkb * kWinoLdsW + (wv * NPIECE * 256) + 4 * lane;
-    long long i_src[2];
-    int i_dst[2];
-    bool i_ok[2], i_use[2];
+    // ---- barrier form.  Both operands go global -> LDS by LDS-DMA (global_load_lds_dwordx4: no VGPRs, no
+    // ds_write).  Weights: the K-step image (32 KB, already in its LDS layout), every wave moves 32/NW
+    // pieces of 1 KB; the four pieces of a group share ONE address register pair and ONE M0 value and differ
+    // in the instruction's immediate offset, which the hardware adds to the global AND to the LDS address
+    // (measured: tools_dev/glds_offset.hip).  Input: the staged region as 1 KB pieces of 32 positions,
+    // out-of-image positions read the zero page.  The K loop is unrolled by two so that every LDS address
+    // of a step is register + immediate.  Per K-step this leaves ~8 address instructions beside the
+    // transform's 16 packed ones (the register-staged form had ~60, and a wave's vector instructions crawl
+    // while its SIMD partner issues MFMAs — see the P3 comment above).
+    constexpr int NPIECE = 32 / NW, NG = NPIECE / 4;
+    const int swv = __builtin_amdgcn_readfirstlane(wv);
+    float* const lds_w = lds + 2 * LINP;
+    const float* wp[NG];
+#pragma unroll
+    for (int g = 0; g < NG; ++g) wp[g] = P.w + (size_t)nb * nkb * kWinoLdsW + (swv * NPIECE + 4 * g) * 256 + 4 * lane;
+    const float* isrc[2];
+    int istep[2];
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-        int f = t + NTHR * i;
-        int q = f >> 1, hf = f & 1;
-        i_use[i] = q < POS;
+        int q = (swv + NW * i) * 32 + (lane >> 1), hf = lane & 1;     // LDS position of this lane's 16 bytes
         int ry = q / kWinoRW, rx = q - ry * kWinoRW;
         int y = y_in0 + ry, x = x_in0 + rx;
-        i_ok[i] = i_use[i] && y >= 0 && y < H && x >= 0 && x < W;
-        i_src[i] = ((long long)b * HW + (long long)y * W + x) * Cin + 4 * hf;
-        i_dst[i] = q * kWinoIS + 4 * hf;
+        bool ok = q < POS && y >= 0 && y < H && x >= 0 && x < W;
+        isrc[i] = ok ? P.in + ((long long)b * HW + (long long)y * W + x) * Cin + 4 * hf : a.zeros;
+        istep[i] = ok ? 8 : 0;
     }
-    f32x4 ri[2];
-    float* const lds_w = lds + 2 * LIN;
-#define FPC_WINO_DMA(KB, BUF)                                                                                 \
+    const bool second_piece = swv + NW < NPI;       // wave-uniform
+#define FPC_WB_DMA4(G, BUF, OFF)                                                                              \
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)wp[G],                    \
+        (__attribute__((address_space(3))) void*)(lds_w + (BUF) * kWinoLdsW + (swv * NPIECE + 4 * (G)) * 256), 16, OFF, 0)
+#define FPC_WB_ISSUE(BUF)                                                                                     \
     do {                                                                                                      \
-        _Pragma("unroll") for (int i = 0; i < NPIECE; ++i) __builtin_amdgcn_global_load_lds(                  \
-            (const __attribute__((address_space(1))) void*)(wsrc + (size_t)(KB) * kWinoLdsW + 256 * i),      \
-            (__attribute__((address_space(3))) void*)(lds_w + (BUF) * kWinoLdsW + (wv * NPIECE + i) * 256), 16, 0, 0); \
-    } while (0)
-#define FPC_WINO_LOAD_IN(KB)                                                                                  \
-    do {                                                                                                      \
-        _Pragma("unroll") for (int i = 0; i < 2; ++i) ri[i] =                                                 \
-            i_ok[i] ? *reinterpret_cast<const f32x4*>(P.in + i_src[i] + 8 * (KB)) : f32x4{0.f, 0.f, 0.f, 0.f}; \
-    } while (0)
-#define FPC_WINO_STORE_IN(BUF)                                                                                \
-    do {                                                                                                      \
-        _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                         \
-            if (i_use[i]) *reinterpret_cast<f32x4*>(lds + (BUF) * LIN + i_dst[i]) = ri[i];                    \
+        _Pragma("unroll") for (int g = 0; g < NG; ++g) {                                                      \
+            FPC_WB_DMA4(g, BUF, 0); FPC_WB_DMA4(g, BUF, 1024); FPC_WB_DMA4(g, BUF, 2048); FPC_WB_DMA4(g, BUF, 3072); \
+            wp[g] += kWinoLdsW;                                                                               \
+        }                                                                                                     \
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)isrc[0],              \
+            (__attribute__((address_space(3))) void*)(lds + (BUF) * LINP + swv * 256), 16, 0, 0);             \
+        isrc[0] += istep[0];                                                                                  \
+        if (second_piece) {                                                                                   \
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)isrc[1],          \
+                (__attribute__((address_space(3))) void*)(lds + (BUF) * LINP + (swv + NW) * 256), 16, 0, 0);  \
+            isrc[1] += istep[1];                                                                              \
+        }                                                                                                     \
     } while (0)
 
     // ---- fragment addressing
@@ -1232,11 +1251,10 @@ __global__ __launch_bounds__(64 * NW, 2) void k_conv_wino(const WinoArgs a) {
         int co = nt * 32 + li;
         w_frag[nt] = ((4 * wi) * kWinoBN + co) * 8 + 4 * (lh ^ ((co >> 3) & 1));   // halves swapped on odd 8-channel groups (k_wino_pack)
     }
+    const f32x4 sg4 = {sgn, sgn, sgn, sgn};
 
     // prologue: step 0 operands
-    FPC_WINO_DMA(0, 0);
-    FPC_WINO_LOAD_IN(0);
-    FPC_WINO_STORE_IN(0);
+    FPC_WB_ISSUE(0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     long long stamp[6] = {0, 0, 0, 0, 0, 0};
@@ -1244,54 +1262,53 @@ __global__ __launch_bounds__(64 * NW, 2) void k_conv_wino(const WinoArgs a) {
 #define FPC_STAMP(I) do { if (DBG && dbg) { long long now_ = clock64(); stamp[I] += now_ - tprev; tprev = now_; } } while (0)
     long long tprev = dbg ? clock64() : 0;
     const long long c_begin = tprev, r_begin = dbg ? wall_clock64() : 0;
-    for (int kb = 0; kb < nkb; ++kb) {
-        const int cur = kb & 1;
-        if (kb + 1 < nkb) {              // buffers cur^1 were last read in step kb-1, which ended with a barrier
-            FPC_WINO_DMA(kb + 1, cur ^ 1);
-            FPC_WINO_LOAD_IN(kb + 1);
-        }
-        FPC_STAMP(0);      // issue of the next step's loads
-        const float* Ib = lds + cur * LIN;
-        const float* Wb = lds_w + cur * kWinoLdsW;
-        f32x4 e[4], v[4];
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            f32x4 da = *reinterpret_cast<const f32x4*>(Ib + in_a + c * kWinoIS);
-            f32x4 db = *reinterpret_cast<const f32x4*>(Ib + in_b + c * kWinoIS);
-            e[c] = da + sgn * db;
-        }
-        v[0] = e[0] - e[2]; v[1] = e[1] + e[2]; v[2] = e[2] - e[1]; v[3] = e[1] - e[3];
-        // lanes 0-31 carry ci = q, lanes 32-63 carry ci = 4 + q of this K-step
-        if (DBG && dbg) { asm volatile("" :: "v"(v[0][0]), "v"(v[1][0]), "v"(v[2][0]), "v"(v[3][0])); }
-        FPC_STAMP(1);      // input fragments + transform
-        __builtin_amdgcn_s_setprio(1);      // MFMA issue ahead of the co-resident workgroup's staging (measured -4 %)
-        f32x4 u0 = *reinterpret_cast<const f32x4*>(Wb + w_frag[0]);
-        f32x4 u1 = *reinterpret_cast<const f32x4*>(Wb + w_frag[1]);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            // weight fragments of xi j+1 are requested before xi j's MFMAs (LDS latency behind 8 MFMAs)
-            f32x4 n0 = u0, n1 = u1;
-            if (j < 3) {
-                n0 = *reinterpret_cast<const f32x4*>(Wb + w_frag[0] + (j + 1) * kWinoBN * 8);
-                n1 = *reinterpret_cast<const f32x4*>(Wb + w_frag[1] + (j + 1) * kWinoBN * 8);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                acc[j][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[j][q], u0[q], acc[j][0], 0, 0, 0);
-                acc[j][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[j][q], u1[q], acc[j][1], 0, 0, 0);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            u0 = n0; u1 = n1;
-        }
-        __builtin_amdgcn_s_setprio(0);
-        FPC_STAMP(2);      // MFMA issue (not completion)
-        if (kb + 1 < nkb) FPC_WINO_STORE_IN(cur ^ 1);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's DMA pieces have landed
-        FPC_STAMP(3);      // input store + wait for this wave's loads
-        __syncthreads();                                      // everybody's have; step kb's reads are done
-        FPC_STAMP(4);      // barrier
+    // one K-step on the buffers CUR (a literal); buffers CUR^1 were last read in the step before, which
+    // ended with a barrier
+#define FPC_WB_STEP(CUR, KBV)                                                                                 \
+    do {                                                                                                      \
+        if ((KBV) + 1 < nkb) FPC_WB_ISSUE((CUR) ^ 1);                                                         \
+        FPC_STAMP(0);      /* issue of the next step's loads */                                               \
+        const float* Ib = lds + (CUR) * LINP;                                                                 \
+        const float* Wb = lds_w + (CUR) * kWinoLdsW;                                                          \
+        f32x4 e[4], v[4];                                                                                     \
+        _Pragma("unroll") for (int c = 0; c < 4; ++c)                                                         \
+            e[c] = __builtin_elementwise_fma(sg4, *reinterpret_cast<const f32x4*>(Ib + in_b + c * kWinoIS),   \
+                                             *reinterpret_cast<const f32x4*>(Ib + in_a + c * kWinoIS));       \
+        v[0] = sub_pk(e[0], e[2]); v[1] = e[1] + e[2]; v[2] = sub_pk(e[2], e[1]); v[3] = sub_pk(e[1], e[3]);  \
+        /* lanes 0-31 carry ci = q, lanes 32-63 carry ci = 4 + q of this K-step */                            \
+        if (DBG && dbg) { asm volatile("" :: "v"(v[0][0]), "v"(v[1][0]), "v"(v[2][0]), "v"(v[3][0])); }       \
+        FPC_STAMP(1);      /* input fragments + transform */                                                  \
+        __builtin_amdgcn_s_setprio(1);      /* MFMA issue ahead of the co-resident workgroup's staging */     \
+        f32x4 u0 = *reinterpret_cast<const f32x4*>(Wb + w_frag[0]);                                           \
+        f32x4 u1 = *reinterpret_cast<const f32x4*>(Wb + w_frag[1]);                                           \
+        _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                       \
+            /* weight fragments of xi j+1 are requested before xi j's MFMAs (LDS latency behind 8 MFMAs) */   \
+            f32x4 n0 = u0, n1 = u1;                                                                           \
+            if (j < 3) {                                                                                      \
+                n0 = *reinterpret_cast<const f32x4*>(Wb + w_frag[0] + (j + 1) * kWinoBN * 8);                 \
+                n1 = *reinterpret_cast<const f32x4*>(Wb + w_frag[1] + (j + 1) * kWinoBN * 8);                 \
+            }                                                                                                 \
+            __builtin_amdgcn_sched_barrier(0);                                                                \
+            _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                                   \
+                acc[j][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[j][q], u0[q], acc[j][0], 0, 0, 0);         \
+                acc[j][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[j][q], u1[q], acc[j][1], 0, 0, 0);         \
+            }                                                                                                 \
+            __builtin_amdgcn_sched_barrier(0);                                                                \
+            u0 = n0; u1 = n1;                                                                                 \
+        }                                                                                                     \
+        __builtin_amdgcn_s_setprio(0);                                                                        \
+        FPC_STAMP(2);      /* MFMA issue (not completion) */                                                  \
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      /* this wave's DMA pieces have landed */        \
+        FPC_STAMP(3);                                                                                         \
+        __syncthreads();                                      /* everybody's have; this step's reads are done */ \
+        FPC_STAMP(4);      /* barrier */                                                                      \
+    } while (0)
+    int kb = 0;
+    for (; kb + 1 < nkb; kb += 2) {
+        FPC_WB_STEP(0, kb);
+        FPC_WB_STEP(1, kb + 1);
     }
+    if (kb < nkb) FPC_WB_STEP(0, kb);
     if (dbg && lane == 0) {
         long long* o = a.dbg + ((size_t)blockIdx.x * NW + wv) * 6;
         for (int i = 0; i < 3; ++i) o[i] = stamp[i];
@@ -1300,10 +1317,9 @@ __global__ __launch_bounds__(64 * NW, 2) void k_conv_wino(const WinoArgs a) {
         o[5] = nkb;
     }
 #undef FPC_STAMP
-
-#undef FPC_WINO_DMA
-#undef FPC_WINO_LOAD_IN
-#undef FPC_WINO_STORE_IN
+#undef FPC_WB_STEP
+#undef FPC_WB_ISSUE
+#undef FPC_WB_DMA4
 
     }
 
@@ -1400,8 +1416,8 @@ int launch_conv_wino(const WinoArgs& a, int groups, hipStream_t s) {
     if (groups < 1 || groups > kMaxGroup || a.Cin % 8 != 0 || a.Cout % kWinoBN != 0 || (a.waves != 4 && a.waves != 8))
         return FPC_EINVAL;
     dim3 grid(a.tbx * a.tby * a.B * (a.Cout / kWinoBN) * groups);
+    if (a.variant != 1 && !a.zeros) return FPC_EINVAL;
     if (a.waves == 8 && a.variant == 2) {
-        if (!a.zeros) return FPC_EINVAL;
         if (a.dbg) hipLaunchKernelGGL((k_conv_wino<8, false, true, true>), grid, dim3(512), 0, s, a);
         else hipLaunchKernelGGL((k_conv_wino<8, false, true>), grid, dim3(512), 0, s, a);
     } else if (a.waves == 8) hipLaunchKernelGGL((k_conv_wino<8, false, false>), grid, dim3(512), 0, s, a);
