@@ -16,11 +16,11 @@ one frame:
              usable instances)
           -> [N > 1] RCCL all-gather of the per-instance pose records
 
-All inputs are resident in HBM before the timed region.  Frames are streamed with three in flight
-(fastposecnn_amd/streaming.py: consecutive frames alternate between two native plans on their own
-HIP streams, the post-network stages of finished networks run on a third; every frame completes all of
-its work, it is only collected two submissions later) — `--no-pipeline` finishes each frame before starting the next and
-`config.ms_per_frame_one_in_flight` reports that latency.  Weak scaling: every rank runs its own
+All inputs are resident in HBM before the timed region.  Frames are streamed with five in flight
+(fastposecnn_amd/streaming.py: consecutive frames go round-robin to four native plans on their own HIP
+streams — one per hardware compute pipe — each frame's post-network stages follow on the same stream;
+every frame completes all of its work, it is only collected four submissions later) — `--no-pipeline`
+finishes each frame before starting the next and `config.ms_per_frame_one_in_flight` reports that latency.  Weak scaling: every rank runs its own
 frame per step; `value` = N * K / max-over-ranks(time).
 
 Extra objects on the JSON line:
@@ -37,6 +37,8 @@ import json
 import os
 import sys
 import time
+
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")   # 4 frame streams + null stream, before HIP initialises (streaming.py)
 
 import torch
 
@@ -61,7 +63,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--vote-only", action="store_true", help="time only the post-network stages (profiling aid)")
     ap.add_argument("--tune-mode", type=int, default=0, help="conv autotune objective: 0 latency, 1 latency x sqrt(chip share)")
-    ap.add_argument("--net-streams", type=int, default=2, help="network plans / HIP streams that alternate frames (1 or 2)")
+    ap.add_argument("--net-streams", type=int, default=4, help="frame streams: native plans on their own HIP streams that take consecutive frames")
+    ap.add_argument("--post-stream", action="store_true", help="run the post-network stages of all frames on one extra stream instead of the frame's own")
     ap.add_argument("--no-pipeline", action="store_true", help="finish every frame before starting the next (latency mode)")
     return ap.parse_args()
 
@@ -130,19 +133,19 @@ def main():
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
     vote_ms = []
 
-    # Frame-streaming runtime (fastposecnn_amd/streaming.py): consecutive frames alternate between
-    # `--net-streams` native plans on their own HIP streams, the post-network stages run on one more stream.
+    # Frame-streaming runtime (fastposecnn_amd/streaming.py): consecutive frames go round-robin to
+    # `--net-streams` native plans on their own HIP streams (network + post-network stages of a frame in order).
     # Every frame does all of its work and is complete (instance count read back, tensors trimmed) when it
     # is collected, `depth` submissions later.
     from fastposecnn_amd.streaming import FrameStreamer
-    streamer = FrameStreamer(model_gpu, net_streams=1 if args.no_pipeline else args.net_streams)
+    streamer = FrameStreamer(model_gpu, net_streams=1 if args.no_pipeline else args.net_streams,
+                             post_inline=not args.post_stream)
     s_net = streamer.net_streams[0]
     depth = 0 if args.no_pipeline else len(streamer.models)
     pending = []
 
     def finish(ticket):
-        out = streamer.collect(ticket) if isinstance(ticket, dict) and "model" in ticket else \
-            {"aggregated": model_gpu.post_network_finish(ticket)}
+        out = {"aggregated": model_gpu.post_network_finish(ticket)} if args.vote_only else streamer.collect(ticket)
         if world > 1:
             parallel.all_gather_pose_records(out["aggregated"], rank * Bq, cap)
         return out

@@ -253,7 +253,8 @@ def test_engine_invalidation(lib, dev):
     assert not m._engines and out["logits"]["mask"].requires_grad
 
 
-def test_frame_streamer_matches_forward(lib, dev):
+@pytest.mark.parametrize("kw", [dict(), dict(net_streams=2, post_inline=False)], ids=["4-streams-inline", "2-streams+post-stream"])
+def test_frame_streamer_matches_forward(lib, dev, kw):
     """Three frames in flight on the streaming runtime give, frame by frame, what forward() gives."""
     from fastposecnn_amd import config, synth
     from fastposecnn_amd.streaming import FrameStreamer
@@ -275,7 +276,7 @@ def test_frame_streamer_matches_forward(lib, dev):
             cat = m.class_compression(logits)
             torch.manual_seed(100 + i)
             ref.append((logits, cat, m.agg_hough_and_generate_RT(cats[i])))
-    st = FrameStreamer(m, net_streams=2)
+    st = FrameStreamer(m, **kw)
     tickets = []
     for i in range(5):
         torch.manual_seed(100 + i)                     # the vote's sampler seed is drawn at submit time
