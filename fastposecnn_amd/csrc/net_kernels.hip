@@ -940,6 +940,7 @@ __global__ __launch_bounds__(64 * NW, 2) void k_conv_wino(const WinoArgs a) {
     static_assert(!P3 || (NW == 8 && !WP), "three-stage DMA form is written for 8 waves");
     static_assert(kLdsFloats >= 2 * 4 * NT * 32, "output transform needs 2*4*NT*32 floats");
     __shared__ __attribute__((aligned(16))) float lds[kLdsFloats];
+    const long long t_entry = DBG ? clock64() : 0;
     const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
     const int wi = wv & 3, half = wv >> 2;                  // transform row of this wave, tile-row group
     const int li = lane & 31, lh = lane >> 5;
@@ -1184,9 +1185,9 @@ __global__ __launch_bounds__(64 * NW, 2) void k_conv_wino(const WinoArgs a) {
             cur = nxt;
         }
         if (dbg && lane == 0) {
-            long long* o = a.dbg + ((size_t)blockIdx.x * NW + wv) * 6;
+            long long* o = a.dbg + ((size_t)blockIdx.x * NW + wv) * 8;
             o[0] = stamp[0]; o[1] = stamp[1] + stamp[2]; o[2] = stamp[3];
-            o[3] = clock64() - c_begin; o[4] = wall_clock64() - r_begin; o[5] = nkb;
+            o[3] = clock64() - c_begin; o[4] = wall_clock64() - r_begin; o[5] = nkb; o[6] = c_begin - t_entry;
         }
 #undef FPC_STAMP
 #undef FPC_P3_ISSUE
@@ -1204,38 +1205,48 @@ __global__ __launch_bounds__(64 * NW, 2) void k_conv_wino(const WinoArgs a) {
     constexpr int NPIECE = 32 / NW, NG = NPIECE / 4;
     const int swv = __builtin_amdgcn_readfirstlane(wv);
     float* const lds_w = lds + 2 * LINP;
-    const float* wp[NG];
-#pragma unroll
-    for (int g = 0; g < NG; ++g) wp[g] = P.w + (size_t)nb * nkb * kWinoLdsW + (swv * NPIECE + 4 * g) * 256 + 4 * lane;
-    const float* isrc[2];
-    int istep[2];
+    // Staging addresses are SGPR base + 32-bit VGPR offset: beside a SIMD partner that issues MFMAs back to
+    // back, a global_load* with a 64-bit VGPR address waits like a vector-ALU instruction (one per MFMA; a pure
+    // MFMA partner starves it: 1550 cycles against 12 for the SGPR-base form — tools_dev/dma_vs_mfma.hip).
+    // The bases advance on the scalar unit, the lane offsets never change: no vector instruction per K-step.
+    const float* wsb = P.w + (size_t)nb * nkb * kWinoLdsW + swv * NPIECE * 256;     // wave-uniform: this wave's pieces of step 0
+    const float* isb = P.in + (size_t)b * HW * Cin;                                // image base, + 8 floats per step
+    const unsigned wvo = 16u * lane;                                               // bytes
+    unsigned ivo[2];
+    bool iok[2];
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         int q = (swv + NW * i) * 32 + (lane >> 1), hf = lane & 1;     // LDS position of this lane's 16 bytes
         int ry = q / kWinoRW, rx = q - ry * kWinoRW;
         int y = y_in0 + ry, x = x_in0 + rx;
-        bool ok = q < POS && y >= 0 && y < H && x >= 0 && x < W;
-        isrc[i] = ok ? P.in + ((long long)b * HW + (long long)y * W + x) * Cin + 4 * hf : a.zeros;
-        istep[i] = ok ? 8 : 0;
+        iok[i] = q < POS && y >= 0 && y < H && x >= 0 && x < W && (i == 0 || swv + NW < NPI);
+        ivo[i] = iok[i] ? (unsigned)((((size_t)y * W + x) * Cin + 4 * hf) * sizeof(float)) : 0u;
     }
-    const bool second_piece = swv + NW < NPI;       // wave-uniform
-#define FPC_WB_DMA4(G, BUF, OFF)                                                                              \
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)wp[G],                    \
-        (__attribute__((address_space(3))) void*)(lds_w + (BUF) * kWinoLdsW + (swv * NPIECE + 4 * (G)) * 256), 16, OFF, 0)
-#define FPC_WB_ISSUE(BUF)                                                                                     \
+    // out-of-image positions are never written by the DMA (inactive lanes): zero both input buffers once
+    for (int i = t; i < 2 * LINP / 4; i += 64 * NW) reinterpret_cast<f32x4*>(lds)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __syncthreads();
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"
+#define FPC_LDS_ADDR(PTR) ((unsigned)(size_t)(__attribute__((address_space(3))) void*)(PTR))
+    // weights of one K-step -> weight buffer BUF: four 1 KB pieces per group share base, offset register and M0
+    // (the immediate offset moves the global AND the LDS address, tools_dev/glds_offset.hip)
+#define FPC_WB_ISSUE_W(BUF)                                                                                   \
     do {                                                                                                      \
-        _Pragma("unroll") for (int g = 0; g < NG; ++g) {                                                      \
-            FPC_WB_DMA4(g, BUF, 0); FPC_WB_DMA4(g, BUF, 1024); FPC_WB_DMA4(g, BUF, 2048); FPC_WB_DMA4(g, BUF, 3072); \
-            wp[g] += kWinoLdsW;                                                                               \
-        }                                                                                                     \
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)isrc[0],              \
-            (__attribute__((address_space(3))) void*)(lds + (BUF) * LINP + swv * 256), 16, 0, 0);             \
-        isrc[0] += istep[0];                                                                                  \
-        if (second_piece) {                                                                                   \
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)isrc[1],          \
-                (__attribute__((address_space(3))) void*)(lds + (BUF) * LINP + (swv + NW) * 256), 16, 0, 0);  \
-            isrc[1] += istep[1];                                                                              \
-        }                                                                                                     \
+        _Pragma("unroll") for (int g = 0; g < NG; ++g)                                                        \
+            asm volatile("s_mov_b32 m0, %0\n s_nop 0\n"                                                       \
+                         "global_load_lds_dwordx4 %1, %2\n global_load_lds_dwordx4 %1, %2 offset:1024\n"      \
+                         "global_load_lds_dwordx4 %1, %2 offset:2048\n global_load_lds_dwordx4 %1, %2 offset:3072\n" \
+                         :: "s"(FPC_LDS_ADDR(lds_w + (BUF) * kWinoLdsW + (swv * NPIECE + 4 * g) * 256)), "v"(wvo), \
+                            "s"(wsb + 1024 * g) : "memory", "m0");                                            \
+    } while (0)
+    // input region of one K-step -> input buffer BUF (in-image lanes only)
+#define FPC_WB_ISSUE_IN(BUF)                                                                                  \
+    do {                                                                                                      \
+        if (iok[0]) asm volatile("s_mov_b32 m0, %0\n s_nop 0\n global_load_lds_dwordx4 %1, %2\n"              \
+                                 :: "s"(FPC_LDS_ADDR(lds + (BUF) * LINP + swv * 256)), "v"(ivo[0]), "s"(isb) : "memory", "m0"); \
+        if (iok[1]) asm volatile("s_mov_b32 m0, %0\n s_nop 0\n global_load_lds_dwordx4 %1, %2\n"              \
+                                 :: "s"(FPC_LDS_ADDR(lds + (BUF) * LINP + (swv + NW) * 256)), "v"(ivo[1]), "s"(isb) : "memory", "m0"); \
     } while (0)
 
     // ---- fragment addressing
@@ -1253,76 +1264,111 @@ __global__ __launch_bounds__(64 * NW, 2) void k_conv_wino(const WinoArgs a) {
     }
     const f32x4 sg4 = {sgn, sgn, sgn, sgn};
 
-    // prologue: step 0 operands
-    FPC_WB_ISSUE(0);
+    // Software pipeline (measured on this kernel with s_memtime stamps, tools_dev/wino_stamps.py):
+    //  * a burst of LDS-DMA issues holds a wave ~1500 cycles per K-step (the CU's L2 -> LDS path moves ~62 B/clk
+    //    whatever the instruction form, tools_dev/dma_rate.hip) and costs as much when the instructions are
+    //    spread between the wave's MFMAs (~100 cycles each there) — so the burst stays a phase of its own,
+    //    beside the SIMD partner's MFMA phase;
+    //  * vector ALU instructions of a wave whose partner issues MFMAs back to back advance one per MFMA
+    //    (~64 cycles each), but cost 2-4 cycles between the wave's OWN MFMAs — so the input transform of step
+    //    k+1 (8 LDS reads, 16 packed instructions) runs inside step k's MFMA block.
+    // Step k therefore: [DMA: weights k+1 -> W[cur^1], input k+2 -> I[cur]] [32 MFMAs of step k on v and
+    // W[cur], with the fragments of step k+1 read from I[cur^1] and transformed in between] [wait, barrier].
+    // Input k+2 may overwrite I[cur]: step k's fragments were read from it during step k-1.  The body has no
+    // branch: past the last step the sources stop advancing, so the final steps stage (and transform) the
+    // last step's operands once more into buffers nobody reads.
+    FPC_WB_ISSUE_W(0);
+    FPC_WB_ISSUE_IN(0);
+    if (nkb > 1) { wsb += kWinoLdsW; isb += 8; }
+    FPC_WB_ISSUE_IN(1);
+    if (nkb > 2) isb += 8;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    f32x4 v[4];      // transformed input fragments of the current step: lanes 0-31 carry ci = q, lanes 32-63 ci = 4 + q
+    {
+        f32x4 e[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+            e[c] = __builtin_elementwise_fma(sg4, *reinterpret_cast<const f32x4*>(lds + in_b + c * kWinoIS),
+                                             *reinterpret_cast<const f32x4*>(lds + in_a + c * kWinoIS));
+        v[0] = sub_pk(e[0], e[2]); v[1] = e[1] + e[2]; v[2] = sub_pk(e[2], e[1]); v[3] = sub_pk(e[1], e[3]);
+    }
+    __syncthreads();       // I[0] is refilled by step 0's DMA
     long long stamp[6] = {0, 0, 0, 0, 0, 0};
     const bool dbg = DBG && a.dbg != nullptr;
 #define FPC_STAMP(I) do { if (DBG && dbg) { long long now_ = clock64(); stamp[I] += now_ - tprev; tprev = now_; } } while (0)
     long long tprev = dbg ? clock64() : 0;
     const long long c_begin = tprev, r_begin = dbg ? wall_clock64() : 0;
-    // one K-step on the buffers CUR (a literal); buffers CUR^1 were last read in the step before, which
-    // ended with a barrier
-#define FPC_WB_STEP(CUR, KBV)                                                                                 \
-    do {                                                                                                      \
-        if ((KBV) + 1 < nkb) FPC_WB_ISSUE((CUR) ^ 1);                                                         \
-        FPC_STAMP(0);      /* issue of the next step's loads */                                               \
-        const float* Ib = lds + (CUR) * LINP;                                                                 \
-        const float* Wb = lds_w + (CUR) * kWinoLdsW;                                                          \
-        f32x4 e[4], v[4];                                                                                     \
-        _Pragma("unroll") for (int c = 0; c < 4; ++c)                                                         \
-            e[c] = __builtin_elementwise_fma(sg4, *reinterpret_cast<const f32x4*>(Ib + in_b + c * kWinoIS),   \
-                                             *reinterpret_cast<const f32x4*>(Ib + in_a + c * kWinoIS));       \
-        v[0] = sub_pk(e[0], e[2]); v[1] = e[1] + e[2]; v[2] = sub_pk(e[2], e[1]); v[3] = sub_pk(e[1], e[3]);  \
-        /* lanes 0-31 carry ci = q, lanes 32-63 carry ci = 4 + q of this K-step */                            \
-        if (DBG && dbg) { asm volatile("" :: "v"(v[0][0]), "v"(v[1][0]), "v"(v[2][0]), "v"(v[3][0])); }       \
-        FPC_STAMP(1);      /* input fragments + transform */                                                  \
-        __builtin_amdgcn_s_setprio(1);      /* MFMA issue ahead of the co-resident workgroup's staging */     \
-        f32x4 u0 = *reinterpret_cast<const f32x4*>(Wb + w_frag[0]);                                           \
-        f32x4 u1 = *reinterpret_cast<const f32x4*>(Wb + w_frag[1]);                                           \
-        _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                       \
-            /* weight fragments of xi j+1 are requested before xi j's MFMAs (LDS latency behind 8 MFMAs) */   \
-            f32x4 n0 = u0, n1 = u1;                                                                           \
-            if (j < 3) {                                                                                      \
-                n0 = *reinterpret_cast<const f32x4*>(Wb + w_frag[0] + (j + 1) * kWinoBN * 8);                 \
-                n1 = *reinterpret_cast<const f32x4*>(Wb + w_frag[1] + (j + 1) * kWinoBN * 8);                 \
-            }                                                                                                 \
-            __builtin_amdgcn_sched_barrier(0);                                                                \
-            _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                                   \
-                acc[j][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[j][q], u0[q], acc[j][0], 0, 0, 0);         \
-                acc[j][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[j][q], u1[q], acc[j][1], 0, 0, 0);         \
-            }                                                                                                 \
-            __builtin_amdgcn_sched_barrier(0);                                                                \
-            u0 = n0; u1 = n1;                                                                                 \
-        }                                                                                                     \
-        __builtin_amdgcn_s_setprio(0);                                                                        \
-        FPC_STAMP(2);      /* MFMA issue (not completion) */                                                  \
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      /* this wave's DMA pieces have landed */        \
-        FPC_STAMP(3);                                                                                         \
-        __syncthreads();                                      /* everybody's have; this step's reads are done */ \
-        FPC_STAMP(4);      /* barrier */                                                                      \
-    } while (0)
-    int kb = 0;
-    for (; kb + 1 < nkb; kb += 2) {
-        FPC_WB_STEP(0, kb);
-        FPC_WB_STEP(1, kb + 1);
+    int cur = 0;
+#pragma unroll 1
+    for (int kb = 0; kb < nkb; ++kb) {
+        FPC_WB_ISSUE_W(cur ^ 1);
+        FPC_WB_ISSUE_IN(cur);
+        wsb += kb + 2 < nkb ? kWinoLdsW : 0;
+        isb += kb + 3 < nkb ? 8 : 0;
+        FPC_STAMP(0);      // issue of the staging loads
+        const float* In = lds + (cur ^ 1) * LINP;
+        const float* Wb = lds_w + cur * kWinoLdsW;
+        f32x4 da[4], db[4], e[4], vn[4];
+        __builtin_amdgcn_s_setprio(1);      // MFMA issue ahead of the co-resident workgroup's staging
+        f32x4 u0 = *reinterpret_cast<const f32x4*>(Wb + w_frag[0]);
+        f32x4 u1 = *reinterpret_cast<const f32x4*>(Wb + w_frag[1]);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            // weight fragments of xi j+1 are requested before xi j's MFMAs (LDS latency behind 8 MFMAs)
+            f32x4 n0 = u0, n1 = u1;
+            if (j < 3) {
+                n0 = *reinterpret_cast<const f32x4*>(Wb + w_frag[0] + (j + 1) * kWinoBN * 8);
+                n1 = *reinterpret_cast<const f32x4*>(Wb + w_frag[1] + (j + 1) * kWinoBN * 8);
+            }
+            if (j < 2) {                    // raw fragments of the next step, two channel pairs per xi block
+#pragma unroll
+                for (int c = 2 * j; c < 2 * j + 2; ++c) {
+                    da[c] = *reinterpret_cast<const f32x4*>(In + in_a + c * kWinoIS);
+                    db[c] = *reinterpret_cast<const f32x4*>(In + in_b + c * kWinoIS);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                acc[j][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[j][q], u0[q], acc[j][0], 0, 0, 0);
+                acc[j][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[j][q], u1[q], acc[j][1], 0, 0, 0);
+                // 2 packed instructions in the shadow of this MFMA pair
+                if (j < 2 && q >= 2) e[2 * j + q - 2] = __builtin_elementwise_fma(sg4, db[2 * j + q - 2], da[2 * j + q - 2]);
+                if (j == 2 && q == 0) vn[0] = sub_pk(e[0], e[2]);
+                if (j == 2 && q == 1) vn[1] = e[1] + e[2];
+                if (j == 2 && q == 2) vn[2] = sub_pk(e[2], e[1]);
+                if (j == 2 && q == 3) vn[3] = sub_pk(e[1], e[3]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            u0 = n0; u1 = n1;
+        }
+        __builtin_amdgcn_s_setprio(0);
+        v[0] = vn[0]; v[1] = vn[1]; v[2] = vn[2]; v[3] = vn[3];
+        FPC_STAMP(2);      // MFMA issue + the next step's fragments (not completion)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's DMA pieces have landed
+        FPC_STAMP(3);
+        __syncthreads();                                      // everybody's have; this step's reads are done
+        FPC_STAMP(4);      // barrier
+        cur ^= 1;
     }
-    if (kb < nkb) FPC_WB_STEP(0, kb);
     if (dbg && lane == 0) {
-        long long* o = a.dbg + ((size_t)blockIdx.x * NW + wv) * 6;
+        long long* o = a.dbg + ((size_t)blockIdx.x * NW + wv) * 8;
         for (int i = 0; i < 3; ++i) o[i] = stamp[i];
         o[3] = clock64() - c_begin;            // shader-clock ticks of the whole K loop
+        o[6] = c_begin - t_entry;              // kernel entry -> K loop
         o[4] = wall_clock64() - r_begin;       // 100 MHz reference ticks of the same span
         o[5] = nkb;
     }
 #undef FPC_STAMP
-#undef FPC_WB_STEP
-#undef FPC_WB_ISSUE
-#undef FPC_WB_DMA4
+#undef FPC_WB_ISSUE_W
+#undef FPC_WB_ISSUE_IN
+#undef FPC_LDS_ADDR
+#pragma clang diagnostic pop
 
     }
 
+    const long long t_kend = DBG ? clock64() : 0;
     // ---- output transform.  Column part inside the wave: z0 = m0 + m1 + m2, z1 = m1 - m2 - m3;
     // row part across the four transform-row waves through LDS: y0 = z[0] + z[1] + z[2], y1 = z[1] - z[2] - z[3].
     // LDS image Z[row i][cc][tile NT][co 32], one 32-channel half (nt) at a time.
@@ -1380,6 +1426,10 @@ __global__ __launch_bounds__(64 * NW, 2) void k_conv_wino(const WinoArgs a) {
             }
         }
     }
+    if (DBG && a.dbg != nullptr && lane == 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        a.dbg[((size_t)blockIdx.x * NW + wv) * 8 + 7] = clock64() - t_kend;      // K loop end -> last store acknowledged
+    }
 }
 
 // OIHW 3x3 weights -> U = G g G^T, packed [Cout/64][Cin/8][16 xi][64 co][8 ci] (one K-step image = 32 KB)
@@ -1417,6 +1467,7 @@ int launch_conv_wino(const WinoArgs& a, int groups, hipStream_t s) {
         return FPC_EINVAL;
     dim3 grid(a.tbx * a.tby * a.B * (a.Cout / kWinoBN) * groups);
     if (a.variant != 1 && !a.zeros) return FPC_EINVAL;
+    if ((long long)a.H * a.W * a.Cin * (long long)sizeof(float) >= (1LL << 32)) return FPC_EINVAL;   // 32-bit lane offsets inside one image
     if (a.waves == 8 && a.variant == 2) {
         if (a.dbg) hipLaunchKernelGGL((k_conv_wino<8, false, true, true>), grid, dim3(512), 0, s, a);
         else hipLaunchKernelGGL((k_conv_wino<8, false, true>), grid, dim3(512), 0, s, a);

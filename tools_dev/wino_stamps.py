@@ -11,7 +11,7 @@ x = torch.randn((B, Hi, Wi, Cin), device=dev); w = torch.randn((Cout, Cin, k, k)
 out = torch.empty((B, Hi, Wi, Cout), device=dev)
 ws = torch.empty(L.fpc_conv2d_workspace_bytes(B, Hi, Wi, Cin, Cout, k, k), dtype=torch.uint8, device=dev)
 nblk = (10 * 8 if VAR == -4 else 10 * 15) * B * 2
-dbg = torch.zeros((nblk, NWAVE, 6), dtype=torch.int64, device=dev)
+dbg = torch.zeros((nblk, NWAVE, 8), dtype=torch.int64, device=dev)
 sb, sh, sw, sc = x.stride(); st = torch.cuda.current_stream().cuda_stream
 for _ in range(200):
     nat.check(L.fpc_conv2d(x.data_ptr(), sb, sh, sw, sc, w.data_ptr(), None, None, None, None, out.data_ptr(), dbg.data_ptr(), B, Hi, Wi,
@@ -29,3 +29,5 @@ for i, n in enumerate(names):
     print(f"  {n:16s} {v.mean():8.0f} {v.median():8.0f} {v.quantile(0.9):8.0f}")
 print("  total            %8.0f" % per.sum(-1).mean())
 print("  whole K loop per step: %.0f" % (d[:, :, 3] / d[:, :, 5]).mean())
+print("kernel entry -> K loop: %.0f ticks; K loop end -> last store acknowledged: %.0f ticks (mean over waves; p90 %.0f)" %
+      (d[:, :, 6].mean(), d[:, :, 7].mean(), d[:, :, 7].flatten().quantile(0.9)))
