@@ -679,7 +679,7 @@ extern "C" int fpc_conv2d(const float* in, int64_t sb, int64_t sh, int64_t sw, i
     FPC_TRY(launch_pack_weight(w_oihw, packed, Cout, Cin, Cin, Kh, Kw, c.Npad, c.Kpad, s));
     bool wino = nsplit <= -1 && nsplit >= -4;      // -1: 4 waves, -2: 8 waves, -3: 4 waves wave-private, -4: 8 waves all-DMA 3-stage
     ConvPlan p = plan_conv(Ho * Wo, B, Cout, c.Kpad / kConvBK, 1, wino ? 0 : bm, bn, wino ? 1 : nsplit);
-    int mode = (sc == 1 && Cin % kConvBK == 0) ? 0
+    int mode = (sc == 1 && Cin % kConvBK == 0 && Kh * Kw <= 32 && ((int64_t)Hi + 2 * pad) * sh * 4 < ((int64_t)1 << 31)) ? 0
                : (sc == 1 && Cin % 4 == 0 && sw % 4 == 0 && sh % 4 == 0 && sb % 4 == 0 && ((uintptr_t)in & 15) == 0) ? 2 : 1;
     fpc_net tmp;
     tmp.B = B;

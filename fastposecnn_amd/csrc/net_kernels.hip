@@ -24,6 +24,16 @@ namespace fpc {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));   // native vector: stays in registers (HIP's float4 struct copies can land in scratch)
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+// raw buffer descriptor over [base, base + 2 GB): offsets are 32-bit, an offset >= 2^31 reads zeros without
+// touching memory (measured, tools_dev/dma_vs_mfma.hip) — the zero fill of the convolution padding
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, 0x7FFFFFFF, 0x00020000);
+}
+__device__ __forceinline__ f32x4 buf_load4(__amdgpu_buffer_rsrc_t r, unsigned voff, int soff) {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, soff, 0));
+}
 
 // a - b as two v_pk_add_f32 with negated second operand (the compiler splits a vector subtraction into four
 // v_sub_f32).  Same IEEE result as the scalar subtraction.
@@ -45,21 +55,27 @@ constexpr int kLdsRow = kConvBK + 4;   // 36 floats: 16 distinct 16-byte slots f
 // One K-step of operands, global -> registers.  Thread (sr, sq) owns rows sr + 32*i and the float4 at
 // column 4*sq of the 32-wide K-step.  (Macros, not functions: hipcc keeps by-reference register
 // arrays in scratch.)
+//
+// Every load is a buffer_load (descriptor + 32-bit lane offset + scalar offset): beside a SIMD partner that
+// issues MFMAs back to back a global_load with a 64-bit VGPR address waits like a vector-ALU instruction — one
+// slot per MFMA, starved by a pure MFMA loop — while the buffer form issues in 9 cycles
+// (tools_dev/dma_vs_mfma.hip).  MODE 0 (Cin % 32 == 0: a K-step is 32 channels of ONE tap) keeps the whole
+// address generation on the scalar unit: per row a constant lane offset and an inverted validity mask over the
+// taps (bit t = 1: tap t of this row is padding), so the zero fill is  offset | ((mask >> tap) << 31)  — two
+// vector instructions per row and K-step; the tap walk (c0, kw, kh) advances with scalar compares.  MODE 0
+// loads must be issued in K-step order (they are: ks0, ks0+1, ...).
 #define FPC_CONV_LOAD(KS, ra, rb)                                                                                     \
     do {                                                                                                      \
         const int ks_ = (KS);                                                                                 \
-        _Pragma("unroll") for (int i = 0; i < BR; ++i) rb[i] =                                                \
-            *reinterpret_cast<const f32x4*>(wrow[i] + ks_ * kConvBK);                                        \
+        _Pragma("unroll") for (int i = 0; i < BR; ++i) rb[i] = buf_load4(rs_w, wvo[i], ks_ * (kConvBK * 4)); \
         if (MODE == 0) {                                                                                      \
-            int k0 = ks_ * kConvBK;                                                                           \
-            int tap = k0 / Cin, c0 = k0 - tap * Cin;                                                          \
-            int kh = tap / Kw, kw = tap - kh * Kw;                                                            \
-            long long koff = (long long)kh * in_sh + (long long)kw * in_sw + c0 + 4 * sq;                     \
-            _Pragma("unroll") for (int i = 0; i < AR; ++i) {                                                  \
-                int hi = a_hi0[i] + kh, wi = a_wi0[i] + kw;                                                   \
-                bool ok = hi >= 0 && hi < Hi && wi >= 0 && wi < Wi;                                           \
-                ra[i] = ok ? *reinterpret_cast<const f32x4*>(P.in + a_off[i] + koff)                         \
-                           : f32x4{0.f, 0.f, 0.f, 0.f};                                                 \
+            _Pragma("unroll") for (int i = 0; i < AR; ++i)                                                    \
+                ra[i] = buf_load4(rs_in, ((anm[i] >> ld_tap) << 31) | avo[i], ld_soff);                       \
+            ld_c0 += kConvBK; ld_soff += kConvBK * 4;                                                         \
+            if (ld_c0 >= Cin) {                                                                               \
+                ld_c0 = 0; ++ld_tap; ++ld_kw;                                                                 \
+                if (ld_kw == Kw) { ld_kw = 0; ++ld_kh; }                                                      \
+                ld_soff = (ld_kh * ish + ld_kw * isw) * 4;                                                    \
             }                                                                                                 \
         } else if (MODE == 2) {                                                                               \
             /* Cin % 4 == 0, channel-last: this lane's float4 is 4 channels of ONE tap (the 7x7 stem on */   \
@@ -147,8 +163,10 @@ __global__ __launch_bounds__(256, (BM * BN >= 128 * 128) ? 1 : 2) void k_conv_ig
     }
 
     const int sr = t >> 3, sq = t & 7;
-    long long a_off[AR];     // element offset of (b, hi0, wi0, 0)
+    long long a_off[AR];     // MODE 1, 2: element offset of (b, hi0, wi0, 0)
     int a_hi0[AR], a_wi0[AR];
+    unsigned avo[AR], anm[AR];   // MODE 0: byte offset of (ho*stride, wo*stride, 4*sq) from the shifted base; padding mask
+    const int ish = (int)in_sh, isw = (int)in_sw;
 #pragma unroll
     for (int i = 0; i < AR; ++i) {
         int p = m0 + sr + 32 * i;
@@ -157,10 +175,29 @@ __global__ __launch_bounds__(256, (BM * BN >= 128 * 128) ? 1 : 2) void k_conv_ig
         a_hi0[i] = ok ? ho * stride - pad : -0x40000000;   // rows past the image: always out of bounds
         a_wi0[i] = wo * stride - pad;
         a_off[i] = (long long)b * in_sb + (long long)a_hi0[i] * in_sh + (long long)a_wi0[i] * in_sw;
+        if (MODE == 0) {
+            avo[i] = (unsigned)((ho * stride * ish + wo * stride * isw + 4 * sq) * 4);
+            unsigned vw = 0, m = 0;                        // valid columns (bit kw), valid taps (bit kh*Kw + kw)
+            for (int kw = 0; kw < Kw; ++kw) vw |= (unsigned)(a_wi0[i] + kw >= 0 && a_wi0[i] + kw < Wi) << kw;
+            for (int kh = 0; kh < a.Kh; ++kh)
+                if (ok && a_hi0[i] + kh >= 0 && a_hi0[i] + kh < Hi) m |= vw << (kh * Kw);
+            anm[i] = ~m;
+        }
     }
-    const float* wrow[BR];
+    // MODE 0: the descriptor starts `pad` rows and columns before the image (valid taps never reach below P.in)
+    const __amdgpu_buffer_rsrc_t rs_in = make_rsrc(P.in + (long long)b * in_sb - ((long long)pad * in_sh + (long long)pad * in_sw));
+    const __amdgpu_buffer_rsrc_t rs_w = make_rsrc(P.w);
+    unsigned wvo[BR];
 #pragma unroll
-    for (int i = 0; i < BR; ++i) wrow[i] = P.w + (size_t)(n0 + sr + 32 * i) * Kpad + 4 * sq;
+    for (int i = 0; i < BR; ++i) wvo[i] = (unsigned)(((n0 + sr + 32 * i) * Kpad + 4 * sq) * 4);
+    // tap walk of the NEXT K-step to load (scalar): channel offset, tap index and coordinates, byte offset of the tap
+    int ld_c0, ld_tap, ld_kh, ld_kw, ld_soff;
+    {
+        int k0 = ks0 * kConvBK;
+        ld_tap = k0 / Cin; ld_c0 = k0 - ld_tap * Cin;
+        ld_kh = ld_tap / Kw; ld_kw = ld_tap - ld_kh * Kw;
+        ld_soff = (ld_kh * ish + ld_kw * isw + ld_c0) * 4;
+    }
 
     // two register sets: the loads of K-step k+2 are issued while step k is computed and step k+1
     // waits in registers, so every global load has two compute phases to land (HBM / L2 latency
@@ -833,7 +870,10 @@ static void launch_conv_t(const ConvArgs& a, int groups, hipStream_t s) {
 //            1 = anything (scalar gathers)
 int launch_conv(const ConvArgs& a, int groups, hipStream_t s) {
     if (groups < 1 || groups > kMaxGroup || a.Npad % a.bn != 0 || a.Kpad % kConvBK != 0) return FPC_EINVAL;
-    if (a.generic == 0 && (a.Cin % kConvBK != 0 || a.in_sc != 1)) return FPC_EINVAL;
+    if (a.generic == 0 && (a.Cin % kConvBK != 0 || a.in_sc != 1 || a.Kh * a.Kw > 32 ||
+                           ((long long)a.Hi + 2 * a.pad) * a.in_sh * 4 >= (1LL << 31)))
+        return FPC_EINVAL;      // tap mask is 32 bits, lane offsets are 31 bits
+    if ((long long)a.Npad * a.Kpad * 4 >= (1LL << 31)) return FPC_EINVAL;
     if (a.generic == 2 && (a.Cin % 4 != 0 || a.in_sc != 1 || a.in_sw % 4 != 0 || a.in_sh % 4 != 0 || a.in_sb % 4 != 0))
         return FPC_EINVAL;
     if (a.bm == 128 && a.bn == 128) launch_conv_t<128, 128>(a, groups, s);
