@@ -25,13 +25,34 @@ def rows_from_csv(path):
     return sorted(out, key=lambda r: -r["TotalDurationNs"])
 
 
+def rows_from_trace(path, last_frames, skip_last=0):
+    """Steady state only: the dispatches of the last `last_frames` frames of a `*_kernel_trace.csv`
+    (a frame starts with k_nchw3_to_nhwc4) before the final `skip_last` ones, i.e. without the plans' autotuning passes."""
+    ev = sorted(((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]) for r in csv.DictReader(open(path))))
+    starts = [i for i, e in enumerate(ev) if "nchw3_to_nhwc4" in e[2]]
+    ev = ev[starts[-last_frames - skip_last - 1]:starts[-skip_last - 1]]
+    agg = {}
+    for s, e, n in ev:
+        a = agg.setdefault(n, [0, 0.0, 1e30, 0.0])
+        d = float(e - s)
+        a[0] += 1; a[1] += d; a[2] = min(a[2], d); a[3] = max(a[3], d)
+    out = [dict(Name=n, Calls=a[0], TotalDurationNs=a[1], AverageNs=a[1] / a[0], MinNs=a[2], MaxNs=a[3]) for n, a in agg.items()]
+    return sorted(out, key=lambda r: -r["TotalDurationNs"]), last_frames
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("path")
     ap.add_argument("--out")
     ap.add_argument("--top", type=int, default=40)
+    ap.add_argument("--last-frames", type=int, default=0, help="with a *_kernel_trace.csv: only the last N frames")
+    ap.add_argument("--skip-last", type=int, default=0, help="... ending this many frames before the end of the trace")
     a = ap.parse_args()
-    rows = rows_from_db(a.path) if a.path.endswith(".db") else rows_from_csv(a.path)
+    if a.last_frames:
+        rows, nf = rows_from_trace(a.path, a.last_frames, a.skip_last)
+        print(f"steady state: {nf} frames of the trace, ending {a.skip_last} frames before its end")
+    else:
+        rows = rows_from_db(a.path) if a.path.endswith(".db") else rows_from_csv(a.path)
     tot = sum(r["TotalDurationNs"] for r in rows) or 1.0
     for r in rows:
         r["Percentage"] = 100.0 * r["TotalDurationNs"] / tot
