@@ -37,6 +37,8 @@ _SIGNATURES = {
     "fpc_aggregate": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz,
                            _vp]),
     "fpc_pose_rt": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp]),
+    "fpc_mask_iou_workspace_bytes": (_sz, [_i, _i, _i64]),
+    "fpc_mask_iou": (_i, [_vp, _i, _vp, _i, _i64, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
     "fpc_net_create": (_i, [ctypes.c_char_p, _i, _i, _i, _i, ctypes.POINTER(_vp)]),
     "fpc_net_destroy": (None, [_vp]),
     "fpc_net_param_count": (_i, [_vp]),
@@ -72,7 +74,7 @@ def lib():
             fn = getattr(L, name)
             fn.restype = res
             fn.argtypes = args
-        if L.fpc_abi_version() != 2:
+        if L.fpc_abi_version() != 3:
             raise RuntimeError("fastposecnn_amd: libfpc_hip.so ABI version mismatch")
         _lib = L
     return _lib

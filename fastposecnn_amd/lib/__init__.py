@@ -4,7 +4,8 @@ Like the reference, the directory itself is put on sys.path and the modules are 
 under their bare names (`gpu_tensor_funcs`, `aggregation_layer`, `hough_voting`,
 `pose_regressor`, `ransac_voting_gpu_layer.*`), so `train.py` / `evaluate.py` /
 `inference.py` keep working with `import lib` pointed at this directory.
-loss / matching / metrics are outside the hot path and are not shipped.
+`matching.batchwise_find_matches` is shipped; loss / metrics and the rest of
+matching.py are outside the hot path and are not.
 """
 import os
 import sys
@@ -20,3 +21,4 @@ import gpu_tensor_funcs as gtf  # noqa: E402
 import aggregation_layer  # noqa: E402
 import hough_voting  # noqa: E402
 import pose_regressor  # noqa: E402
+import matching  # noqa: E402

@@ -134,3 +134,39 @@ def samplewise_get_RT(agg_data, inv_intrinsics):
     agg_data['T'] = T_data
     agg_data['RT'] = RT_data
     return agg_data
+
+
+def batchwise_get_2d_iou(batch_masks1, batch_masks2):
+    """Reference signature (gpu_tensor_funcs.py:386-409): masks [n1,H,W], [n2,H,W] (any dtype, non-zero = set)
+    -> IoU f32 [n1,n2].  One native call (fpc_mask_iou): every mask is read once and packed into a bitset;
+    the reference's [n1,n2,H,W] logical_and / logical_or expansions are never built.  GPU tensors only."""
+    if not (batch_masks1.is_cuda and batch_masks2.is_cuda):
+        raise RuntimeError("batchwise_get_2d_iou: the native path needs GPU tensors (there is no CPU fallback)")
+    n1, n2 = batch_masks1.shape[0], batch_masks2.shape[0]
+    dev = batch_masks1.device
+    iou = torch.empty((n1, n2), dtype=torch.float32, device=dev)
+    if n1 == 0 or n2 == 0:
+        return iou
+    if batch_masks1.shape[1:] != batch_masks2.shape[1:]:
+        raise RuntimeError("batchwise_get_2d_iou: mask shapes differ")
+
+    def prep(m):
+        if m.dtype == torch.float32:
+            return m.contiguous(), 4
+        if m.dtype in (torch.bool, torch.uint8):
+            return m.contiguous().view(torch.uint8), 1
+        return (m != 0).contiguous().view(torch.uint8), 1
+
+    a, ea = prep(batch_masks1)
+    b, eb = prep(batch_masks2)
+    if ea != eb:                      # mixed stacks: bring both to bytes
+        a = (a != 0).view(torch.uint8) if ea == 4 else a
+        b = (b != 0).view(torch.uint8) if eb == 4 else b
+        ea = 1
+    hw = a[0].numel()
+    L = nat.lib()
+    ws = torch.empty(L.fpc_mask_iou_workspace_bytes(n1, n2, hw), dtype=torch.uint8, device=dev)
+    with torch.cuda.device(dev):
+        nat.check(L.fpc_mask_iou(nat.ptr(a), n1, nat.ptr(b), n2, hw, ea, nat.ptr(iou), None, None, nat.ptr(ws), ws.numel(),
+                                 nat.stream()), "fpc_mask_iou")
+    return iou

@@ -19,6 +19,7 @@
  *   fpc_cc_label                 lib/aggregation_layer.py:160-183 (cupyx / scipy ndimage.label)
  *   fpc_aggregate                lib/aggregation_layer.py:61-158
  *   fpc_pose_rt                  lib/gpu_tensor_funcs.py:204-253, 306-326
+ *   fpc_mask_iou                 lib/gpu_tensor_funcs.py:386-409 (batchwise_get_2d_iou), called by lib/matching.py:264-267
  *   fpc_net_*                    lib/pose_regressor.py:709-743 (+ segmentation_models_pytorch encoder/decoder/head)
  * The Python-side bindings a maintainer would add are shown in INTEGRATION.md.
  */
@@ -32,7 +33,7 @@
 extern "C" {
 #endif
 
-#define FPC_ABI_VERSION 2
+#define FPC_ABI_VERSION 3
 
 #define FPC_OK 0
 #define FPC_EINVAL (-1)      /* bad argument (shape, null pointer, ...) */
@@ -127,6 +128,15 @@ int fpc_aggregate(const int32_t* labels, const int64_t* cat_mask,
  * -> R [n,9], T [n,3], RT [n,16]. */
 int fpc_pose_rt(const float* q, const float* xy, const float* z, const float* kinv, int n,
                 float* R, float* T, float* RT, fpc_stream_t stream);
+
+/* ---- matching: 2D IoU of every (mask1, mask2) pair ----------------------------
+ * lib/gpu_tensor_funcs.py:386-409 batchwise_get_2d_iou (the [n1,n2,H,W] logical_and / logical_or expansion
+ * of lib/matching.py:264-267).  masks1 [n1,hw], masks2 [n2,hw]: contiguous, elem_size 4 (f32: non-zero
+ * incl. NaN = set, -0.0 = clear) or 1 (u8 / bool).  iou f32 [n1,n2] = (float)|a & b| / (float)|a | b|
+ * (NaN for two empty masks, as torch's 0/0); inter / uni i32 [n1,n2] optional (NULL).  n1 == 0 or n2 == 0: no-op. */
+size_t fpc_mask_iou_workspace_bytes(int n1, int n2, int64_t hw);
+int fpc_mask_iou(const void* masks1, int n1, const void* masks2, int n2, int64_t hw, int elem_size,
+                 float* iou, int32_t* inter, int32_t* uni, void* ws, size_t ws_bytes, fpc_stream_t stream);
 
 /* ---- backbone engine ----------------------------------------------------------
  * PoseRegressor.pure_model_forward + Model.class_compression for inference

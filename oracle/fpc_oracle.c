@@ -452,3 +452,29 @@ int fpco_pose_rt(const float* q, const float* xy, const float* z, const float* k
     }
     return FPCO_OK;
 }
+
+/* ---- matching: 2D IoU of every (mask1, mask2) pair ------------------------------------------
+ * F/lib/gpu_tensor_funcs.py:386-409 (batchwise_get_2d_iou), the [n1,n2,H,W] expansion that
+ * F/lib/matching.py:264-267 (batchwise_find_matches) calls per class.  logical_and / logical_or
+ * treat every non-zero element (NaN included, -0.0 not) as true; the sums are int64 and
+ * `intersection / union` is torch's true division of two int64 tensors: both converted to
+ * float32, one IEEE division (0/0 = NaN for two empty masks).  inter / uni may be NULL. */
+int fpco_mask_iou(const float* m1, int n1, const float* m2, int n2, int64_t hw, float* iou, int64_t* inter,
+                  int64_t* uni) {
+    if (n1 < 0 || n2 < 0 || hw < 0) return FPCO_EINVAL;
+    for (int i = 0; i < n1; ++i)
+        for (int j = 0; j < n2; ++j) {
+            const float* a = m1 + (size_t)i * hw;
+            const float* b = m2 + (size_t)j * hw;
+            int64_t in = 0, un = 0;
+            for (int64_t p = 0; p < hw; ++p) {
+                int ta = a[p] != 0.0f, tb = b[p] != 0.0f;   /* NaN != 0 is true */
+                in += ta & tb;
+                un += ta | tb;
+            }
+            if (inter) inter[(size_t)i * n2 + j] = in;
+            if (uni) uni[(size_t)i * n2 + j] = un;
+            iou[(size_t)i * n2 + j] = (float)in / (float)un;
+        }
+    return FPCO_OK;
+}

@@ -8,7 +8,8 @@ What is reference code here and what is not:
   gpu_tensor_funcs (normalize, class_compress, samplewise_get_RT, batchwise_get_RT,
   quats_2_rotation_matrix), aggregation_layer.AggregationLayer (scipy CPU branch),
   hough_voting.HoughVotingLayer, ransac_voting_gpu.ransac_voting_layer_v3 / b_inv,
-  pose_regressor.Model.class_compression.
+  pose_regressor.Model.class_compression; matching.batchwise_find_matches and
+  gpu_tensor_funcs.batchwise_get_2d_iou.
 * NOT available: the CUDA extension `ransac_voting` (no NVIDIA toolchain, no GPU).  Its two
   live kernels are stood in for by oracle/fpc_oracle.c's line-by-line restatement
   (fpco_generate_hypothesis / fpco_voting_for_hypothesis).  So the voting goldens pin the
@@ -375,6 +376,59 @@ def gen_pipeline(ref, rng):
     print("pipeline n =", n, "xy", agg["xy"].numpy(), "classes", agg["class_ids"].numpy())
 
 
+def gen_matching(ref, rng):
+    """matching.batchwise_find_matches + gpu_tensor_funcs.batchwise_get_2d_iou on two AggData dicts:
+    ground truth (7 instances, 3 classes, 2 samples) against predictions (8 instances; perturbed masks, one of a
+    class the ground truth lacks, one empty mask, one ground-truth instance left without any overlapping
+    prediction).  A second case pins the 0/0 = NaN row (empty gt mask vs empty prediction)."""
+    torch = ref.torch
+    import matching as mg
+    H, W = 40, 56
+    yy, xx = np.mgrid[0:H, 0:W]
+
+    def disc(cx, cy, r):
+        return (((xx - cx) ** 2 + (yy - cy) ** 2) <= r * r).astype(np.float32)
+
+    def agg(masks, cls, sid, seed):
+        r = np.random.default_rng(seed)
+        n = len(masks)
+        q = r.normal(size=(n, 4)).astype(np.float32); q /= np.linalg.norm(q, axis=1, keepdims=True)
+        d = {"class_ids": np.asarray(cls, np.int64), "sample_ids": np.asarray(sid, np.int64),
+             "instance_masks": np.stack(masks).astype(np.float32), "quaternion": q,
+             "scales": r.uniform(0.1, 1, (n, 3)).astype(np.float32), "xy": r.uniform(0, 50, (n, 2)).astype(np.float32),
+             "z": r.uniform(500, 1500, (n, 1)).astype(np.float32), "R": r.normal(size=(n, 3, 3)).astype(np.float32),
+             "T": r.normal(size=(n, 3)).astype(np.float32), "RT": r.normal(size=(n, 4, 4)).astype(np.float32)}
+        return d
+
+    g_masks = [disc(10, 10, 6), disc(30, 12, 7), disc(45, 30, 6), disc(12, 30, 5), disc(28, 28, 6), disc(48, 8, 4), disc(20, 20, 3)]
+    gts = agg(g_masks, [1, 1, 2, 2, 3, 3, 1], [0, 0, 0, 1, 1, 1, 1], 1)
+    gts["symmetric_ids"] = np.asarray([0, 1, 0, 2, 0, 1, 0], np.int64)
+    p_masks = [disc(11, 10, 6), disc(31, 13, 6), disc(44, 31, 7), disc(29, 27, 6), disc(13, 31, 5), disc(5, 35, 3),
+               np.zeros((H, W), np.float32), disc(10, 11, 5)]
+    preds = agg(p_masks, [1, 1, 2, 3, 2, 4, 3, 1], [0, 0, 0, 1, 1, 1, 1, 0], 2)
+    t = lambda d: {k: torch.from_numpy(v) for k, v in d.items()}
+    out = mg.batchwise_find_matches(t(preds), t(gts))
+    iou_all = ref.gtf.batchwise_get_2d_iou(torch.from_numpy(gts["instance_masks"]), torch.from_numpy(preds["instance_masks"]))
+    # NaN case: an empty ground-truth mask and an empty prediction of the same class
+    g2 = agg([disc(10, 10, 6), np.zeros((H, W), np.float32), disc(40, 20, 5)], [1, 1, 2], [0, 0, 0], 3)
+    g2["symmetric_ids"] = np.asarray([0, 0, 1], np.int64)
+    p2 = agg([np.zeros((H, W), np.float32), disc(10, 11, 6), disc(41, 20, 5)], [1, 1, 2], [0, 0, 0], 4)
+    out2 = mg.batchwise_find_matches(t(p2), t(g2))
+    iou2 = ref.gtf.batchwise_get_2d_iou(torch.from_numpy(g2["instance_masks"]), torch.from_numpy(p2["instance_masks"]))
+    # no prediction at all -> None; predictions of foreign classes only -> None
+    none1 = mg.batchwise_find_matches({k: v[:0] for k, v in t(preds).items()}, t(gts))
+    p3 = {k: v[5:6] for k, v in t(preds).items()}
+    none2 = mg.batchwise_find_matches(p3, t(gts))
+    assert none1 is None and none2 is None
+    sv = {}
+    for tag, d in (("gts", gts), ("preds", preds), ("gts2", g2), ("preds2", p2)):
+        sv.update({f"{tag}_{k}": v for k, v in d.items()})
+    sv.update({f"out_{k}": v.numpy() for k, v in out.items()})
+    sv.update({f"out2_{k}": v.numpy() for k, v in out2.items()})
+    np.savez_compressed(os.path.join(OUT, "matching.npz"), iou_all=iou_all.numpy(), iou2=iou2.numpy(), **sv)
+    print("matching:", {k: tuple(v.shape) for k, v in out.items()}, "| nan case rows:", out2["class_ids"].tolist())
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     ref = import_reference()
@@ -385,6 +439,7 @@ def main():
     gen_aggregate(ref, rng)
     gen_pose_rt(ref, rng)
     gen_pipeline(ref, rng)
+    gen_matching(ref, rng)
     import torch, scipy
     with open(os.path.join(OUT, "PROVENANCE.txt"), "w") as f:
         f.write("generated by oracle/gen_golden.py from /root/reference (FastPoseCNN @ v0)\n"

@@ -41,8 +41,7 @@ def build(force=False):
 def lib():
     global _lib
     if _lib is None:
-        if not os.path.exists(_LIB_PATH):
-            build()
+        build()          # no-op when the library is newer than its sources
         _lib = ctypes.CDLL(_LIB_PATH)
         for name in ("fpco_generate_hypothesis", "fpco_voting_for_hypothesis", "fpco_ransac_voting_v3",
                      "fpco_class_compress", "fpco_cc_label", "fpco_aggregate", "fpco_pose_rt"):
@@ -175,3 +174,60 @@ def pose_rt(q, xy, z, inv_intrinsics):
     _check(lib().fpco_pose_rt(_p(q, c_f32p), _p(xy, c_f32p), _p(z, c_f32p), _p(k, c_f32p), n,
                               _p(R, c_f32p), _p(T, c_f32p), _p(RT, c_f32p)), "pose_rt")
     return R, T, RT
+
+
+def mask_iou(m1, m2, return_counts=False):
+    """gpu_tensor_funcs.py:386-409 batchwise_get_2d_iou: m1 [n1,H,W], m2 [n2,H,W] (non-zero = set) -> f32 [n1,n2]."""
+    a = _f32(np.asarray(m1, dtype=np.float32)); b = _f32(np.asarray(m2, dtype=np.float32))
+    n1, n2 = a.shape[0], b.shape[0]
+    hw = int(np.prod(a.shape[1:])) if n1 else int(np.prod(b.shape[1:]))
+    iou = np.zeros((n1, n2), np.float32); inter = np.zeros((n1, n2), np.int64); uni = np.zeros((n1, n2), np.int64)
+    c_i64p_ = ctypes.POINTER(ctypes.c_int64)
+    f = lib().fpco_mask_iou
+    f.restype = ctypes.c_int
+    f.argtypes = [c_f32p, ctypes.c_int, c_f32p, ctypes.c_int, ctypes.c_int64, c_f32p, c_i64p_, c_i64p_]
+    _check(f(_p(a, c_f32p), n1, _p(b, c_f32p), n2, hw, _p(iou, c_f32p), _p(inter, c_i64p_), _p(uni, c_i64p_)), "mask_iou")
+    return (iou, inter, uni) if return_counts else iou
+
+
+KEYS_TO_STACK = ['instance_masks', 'quaternion', 'R', 'scales', 'xy', 'z', 'T', 'RT']     # matching.py:29-35
+
+
+def find_matches(preds, gts):
+    """matching.py:226-325 batchwise_find_matches on numpy dicts: per ground-truth class (ascending,
+    torch.unique), IoU of that class's gt masks against that class's predicted masks (ANY sample of the
+    batch — the reference does not compare sample ids), row arg-max (first maximum; a NaN in the row wins,
+    as torch.max propagates it), rows whose maximum is not > 0 dropped; matched gt / pred tensors stacked
+    as [2, m, ...].  Returns None where the reference does."""
+    if not preds or not gts:
+        return None
+    if preds['class_ids'].shape[0] == 0:
+        return None
+    out = {'sample_ids': [], 'class_ids': [], 'symmetric_ids': []}
+    for cid in np.unique(gts['class_ids']):
+        gi = np.where(gts['class_ids'] == cid)[0]
+        pi = np.where(preds['class_ids'] == cid)[0]
+        if gi.size == 0 or pi.size == 0:
+            continue
+        iou = mask_iou(gts['instance_masks'][gi], preds['instance_masks'][pi])
+        max_pred = np.zeros(gi.size, np.int64); max_v = np.zeros(gi.size, np.float32)
+        for r in range(gi.size):
+            row = iou[r]
+            nan = np.isnan(row)
+            k = int(np.argmax(nan)) if nan.any() else int(np.argmax(row))     # torch.max: first NaN, else first maximum
+            max_pred[r] = k; max_v[r] = row[k]
+        valid = max_v > 0
+        if not valid.any():
+            continue
+        g_sel = gi[valid]; p_sel = pi[max_pred[valid]]
+        out['sample_ids'].append(gts['sample_ids'][g_sel])
+        out['symmetric_ids'].append(gts['symmetric_ids'][g_sel])
+        out['class_ids'].append(np.full(g_sel.size, cid, dtype=gts['class_ids'].dtype))
+        for k in gts.keys():
+            if k in KEYS_TO_STACK:
+                out.setdefault(k, []).append(np.stack((gts[k][g_sel], preds[k][p_sel])))
+    for k in list(out.keys()):
+        if len(out[k]) == 0:
+            return None
+        out[k] = np.concatenate(out[k], axis=0 if k in ('sample_ids', 'class_ids', 'symmetric_ids') else 1)
+    return out

@@ -475,3 +475,114 @@ def test_random_scenes_post_network_vs_oracle(lib, oracle, dev, seed):
     R, Tt, RT = oracle.pose_rt(want["quaternion"], wxy[:, 0], want["z"], kinv)
     np.testing.assert_allclose(agg["R"].cpu().numpy(), R, atol=1e-5)
     np.testing.assert_allclose(agg["RT"].cpu().numpy(), RT, atol=1e-3, rtol=1e-4)
+
+
+# ----------------------------------------------------------------------------- matching
+
+def _dicts(g, tag):
+    return {k[len(tag) + 1:]: g[k] for k in list(g.keys()) if k.startswith(tag + "_")}
+
+
+def test_mask_iou_golden_and_oracle(lib, oracle, dev):
+    """gtf.batchwise_get_2d_iou through the C ABI: the reference's own output (golden) and the oracle on seeded
+    stacks — ragged sizes (pixel count not a multiple of 64 / 256), f32 / bool / uint8 / int64 masks, NaN and
+    -0.0 elements, empty masks (0/0 = NaN), n1 or n2 = 0.  Bit-exact: integer counts and one f32 division."""
+    gtf = lib.gtf
+    g = load_golden("matching.npz")
+    got = gtf.batchwise_get_2d_iou(T(g["gts_instance_masks"], dev), T(g["preds_instance_masks"], dev))
+    assert np.array_equal(got.cpu().numpy(), g["iou_all"], equal_nan=True)
+    got2 = gtf.batchwise_get_2d_iou(T(g["gts2_instance_masks"], dev), T(g["preds2_instance_masks"], dev))
+    assert np.array_equal(got2.cpu().numpy(), g["iou2"], equal_nan=True)
+    rng = np.random.default_rng(5)
+    for (n1, n2, H, W) in [(3, 5, 17, 23), (1, 1, 1, 1), (4, 2, 16, 16), (6, 7, 48, 64), (2, 9, 31, 64)]:
+        a = (rng.random((n1, H, W)) < 0.4).astype(np.float32) * rng.normal(size=(n1, H, W)).astype(np.float32)
+        b = (rng.random((n2, H, W)) < 0.3).astype(np.float32)
+        a[0].flat[::7] = np.nan            # NaN counts as set
+        b[-1][:] = 0; b[-1].flat[::5] = -0.0   # -0.0 does not
+        want = oracle.mask_iou(a, b)
+        assert np.array_equal(gtf.batchwise_get_2d_iou(T(a, dev), T(b, dev)).cpu().numpy(), want, equal_nan=True)
+        ab, bb = (a != 0) | np.isnan(a), b != 0
+        wantb = oracle.mask_iou(ab.astype(np.float32), bb.astype(np.float32))
+        for cast in (lambda x: T(x, dev), lambda x: T(x.astype(np.uint8), dev), lambda x: T(x.astype(np.int64), dev)):
+            assert np.array_equal(gtf.batchwise_get_2d_iou(cast(ab), cast(bb)).cpu().numpy(), wantb, equal_nan=True)
+        assert np.array_equal(gtf.batchwise_get_2d_iou(T(a, dev), T(bb, dev)).cpu().numpy(), want, equal_nan=True)   # mixed dtypes
+    e = gtf.batchwise_get_2d_iou(torch.zeros((0, 8, 8), device=dev), torch.zeros((3, 8, 8), device=dev))
+    assert e.shape == (0, 3)
+    e = gtf.batchwise_get_2d_iou(torch.zeros((2, 8, 8), device=dev), torch.zeros((0, 8, 8), device=dev))
+    assert e.shape == (2, 0)
+    with pytest.raises(RuntimeError):
+        gtf.batchwise_get_2d_iou(torch.zeros((2, 8, 8)), torch.zeros((2, 8, 8)))        # CPU tensors: no fallback
+
+
+def test_mask_iou_full_size_properties(lib, dev):
+    """640x480, 24 x 24 masks (the size the oracle would need ~10 s for): IoU(a, a) = 1, symmetry,
+    disjoint -> 0, nested -> |inner| / |outer|, and the optional count outputs against torch sums."""
+    from fastposecnn_amd import _native as nat
+    H, W, n = 480, 640, 24
+    g = torch.Generator(device="cpu").manual_seed(3)
+    yy, xx = torch.meshgrid(torch.arange(H), torch.arange(W), indexing="ij")
+    ms = []
+    for i in range(n):
+        cx, cy, r = torch.randint(60, 580, (1,), generator=g), torch.randint(60, 420, (1,), generator=g), torch.randint(20, 120, (1,), generator=g)
+        ms.append((((xx - cx) ** 2 + (yy - cy) ** 2) <= r * r).float())
+    m = torch.stack(ms).to(dev)
+    iou = lib.gtf.batchwise_get_2d_iou(m, m)
+    assert torch.equal(torch.diagonal(iou), torch.ones(n, device=dev))
+    assert torch.equal(iou, iou.t())
+    mb = m.bool()
+    inter = (mb[:, None] & mb[None]).flatten(2).sum(2)
+    uni = (mb[:, None] | mb[None]).flatten(2).sum(2)
+    assert torch.equal(iou, inter.float() / uni.float())
+    L = nat.lib()
+    o_i = torch.empty((n, n), dtype=torch.int32, device=dev); o_u = torch.empty_like(o_i); o = torch.empty((n, n), device=dev)
+    ws = torch.empty(L.fpc_mask_iou_workspace_bytes(n, n, H * W), dtype=torch.uint8, device=dev)
+    nat.check(L.fpc_mask_iou(nat.ptr(m), n, nat.ptr(m), n, H * W, 4, nat.ptr(o), nat.ptr(o_i), nat.ptr(o_u), nat.ptr(ws),
+                             ws.numel(), nat.stream()), "fpc_mask_iou")
+    assert torch.equal(o_i.long(), inter) and torch.equal(o_u.long(), uni) and torch.equal(o, iou)
+    inner = torch.zeros((1, H, W), device=dev); inner[0, 100:200, 100:300] = 1
+    outer = torch.zeros((1, H, W), device=dev); outer[0, 50:250, 50:350] = 1
+    far = torch.zeros((1, H, W), device=dev); far[0, 300:400, 400:600] = 1
+    assert lib.gtf.batchwise_get_2d_iou(inner, outer).item() == np.float32(100 * 200) / np.float32(200 * 300)
+    assert lib.gtf.batchwise_get_2d_iou(inner, far).item() == 0.0
+
+
+def test_find_matches_golden_and_oracle(lib, oracle, dev):
+    """mg.batchwise_find_matches: the reference's outputs (golden, incl. the NaN row and the None cases) and
+    the oracle on randomized AggData pairs — every key bit for bit (pure selection, no arithmetic)."""
+    import matching as mg
+    g = load_golden("matching.npz")
+    td = lambda d: {k: T(v, dev) for k, v in d.items()}
+    gts, preds, g2, p2 = (_dicts(g, t) for t in ("gts", "preds", "gts2", "preds2"))
+    for (p, t, tag) in ((preds, gts, "out"), (p2, g2, "out2")):
+        want = _dicts(g, tag)
+        got = mg.batchwise_find_matches(td(p), td(t))
+        assert sorted(got) == sorted(want)
+        for k in want:
+            assert got[k].dtype == torch.from_numpy(want[k]).dtype, k
+            assert np.array_equal(got[k].cpu().numpy(), want[k]), k
+    assert mg.batchwise_find_matches({k: v[:0] for k, v in td(preds).items()}, td(gts)) is None
+    assert mg.batchwise_find_matches({k: v[5:6] for k, v in td(preds).items()}, td(gts)) is None
+    assert mg.batchwise_find_matches(None, td(gts)) is None and mg.batchwise_find_matches(td(preds), {}) is None
+    assert mg.batchwise_find_matches(td(preds), {k: v[:0] for k, v in td(gts).items()}) is None
+    rng = np.random.default_rng(11)
+    H, W = 60, 80
+    yy, xx = np.mgrid[0:H, 0:W]
+    for trial in range(6):
+        def scene(n, seed):
+            r = np.random.default_rng(seed)
+            masks = np.stack([(((xx - r.integers(5, W - 5)) ** 2 + (yy - r.integers(5, H - 5)) ** 2) <= r.integers(3, 15) ** 2)
+                              .astype(np.float32) for _ in range(n)]) if n else np.zeros((0, H, W), np.float32)
+            return {"class_ids": r.integers(1, 4, n).astype(np.int64), "sample_ids": r.integers(0, 3, n).astype(np.int64),
+                    "symmetric_ids": r.integers(0, 3, n).astype(np.int64), "instance_masks": masks,
+                    "quaternion": r.normal(size=(n, 4)).astype(np.float32), "scales": r.random((n, 3)).astype(np.float32),
+                    "xy": r.random((n, 2)).astype(np.float32), "z": r.random((n, 1)).astype(np.float32),
+                    "R": r.normal(size=(n, 3, 3)).astype(np.float32), "T": r.normal(size=(n, 3)).astype(np.float32),
+                    "RT": r.normal(size=(n, 4, 4)).astype(np.float32)}
+        t_, p_ = scene(int(rng.integers(1, 12)), 100 + trial), scene(int(rng.integers(1, 12)), 200 + trial)
+        want = oracle.find_matches(p_, t_)
+        got = mg.batchwise_find_matches(td(p_), td(t_))
+        assert (want is None) == (got is None)
+        if want is not None:
+            assert sorted(got) == sorted(want)
+            for k in want:
+                assert np.array_equal(got[k].cpu().numpy(), want[k]), (trial, k)

@@ -126,3 +126,28 @@ def test_pipeline_chain(oracle):
     np.testing.assert_allclose(RT, g["agg_RT"], atol=1e-4)
     for k in ("quaternion", "scales", "z"):
         np.testing.assert_allclose(agg[k], g["agg_" + k], atol=1e-4, rtol=1e-5)
+
+
+def _dicts(g, tag):
+    return {k[len(tag) + 1:]: g[k] for k in list(g.keys()) if k.startswith(tag + "_")}
+
+
+def test_matching_iou_and_find_matches(oracle):
+    """gtf.batchwise_get_2d_iou and mg.batchwise_find_matches of the reference (golden) vs the
+    oracle's restatement: IoU matrix bit for bit (integer counts, one f32 division, NaN for 0/0), matches identical."""
+    g = load_golden("matching.npz")
+    gts, preds, g2, p2 = (_dicts(g, t) for t in ("gts", "preds", "gts2", "preds2"))
+    iou, inter, uni = oracle.mask_iou(gts["instance_masks"], preds["instance_masks"], return_counts=True)
+    assert np.array_equal(iou, g["iou_all"], equal_nan=True)
+    assert (inter <= uni).all() and inter.dtype == np.int64
+    assert np.array_equal(oracle.mask_iou(g2["instance_masks"], p2["instance_masks"]), g["iou2"], equal_nan=True)
+    assert np.isnan(g["iou2"][1, 0])                                   # empty ground truth vs empty prediction
+    for (p, t, tag) in ((preds, gts, "out"), (p2, g2, "out2")):
+        want = _dicts(g, tag)
+        got = oracle.find_matches(p, t)
+        assert sorted(got) == sorted(want)
+        for k in want:
+            assert np.array_equal(got[k], want[k]), k
+    assert oracle.find_matches({k: v[:0] for k, v in preds.items()}, gts) is None       # no prediction
+    assert oracle.find_matches({k: v[5:6] for k, v in preds.items()}, gts) is None      # foreign class only
+    assert oracle.find_matches(None, gts) is None and oracle.find_matches(preds, {}) is None
