@@ -143,11 +143,12 @@ def main():
     s_net = streamer.net_streams[0]
     depth = 0 if args.no_pipeline else len(streamer.models)
     pending = []
+    gather_buf = [None]
 
     def finish(ticket):
         out = {"aggregated": model_gpu.post_network_finish(ticket)} if args.vote_only else streamer.collect(ticket)
-        if world > 1:
-            parallel.all_gather_pose_records(out["aggregated"], rank * Bq, cap)
+        if world > 1:      # ONE fixed-capacity RCCL all-gather of pose records per step: pack = one native launch
+            gather_buf[0] = parallel.all_gather_pose_records(out["aggregated"], rank * Bq, cap, out=gather_buf[0])
         return out
 
     def step(pipelined=True):

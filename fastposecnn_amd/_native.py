@@ -37,6 +37,7 @@ _SIGNATURES = {
     "fpc_aggregate": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz,
                            _vp]),
     "fpc_pose_rt": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp]),
+    "fpc_pack_pose_records": (_i, [_vp] * 9 + [_i, _i, _i, _vp, _vp]),
     "fpc_mask_iou_workspace_bytes": (_sz, [_i, _i, _i64]),
     "fpc_mask_iou": (_i, [_vp, _i, _vp, _i, _i64, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
     "fpc_net_create": (_i, [ctypes.c_char_p, _i, _i, _i, _i, ctypes.POINTER(_vp)]),

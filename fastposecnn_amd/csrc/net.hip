@@ -690,6 +690,9 @@ extern "C" int fpc_conv2d(const float* in, int64_t sb, int64_t sh, int64_t sw, i
     a.p[0] = ConvPtrs{in, packed, out, scale, shift, res, up, gn_part};
     a.zeros = nullptr;
     if (wino && relu == 77) { a.dbg = gn_part; a.p[0].gn_part = nullptr; a.relu = 0; }
+#ifdef FPC_STAMP_IGEMM
+    if (!wino && relu == 77) { a.dbg = gn_part; a.p[0].gn_part = nullptr; a.relu = 0; }
+#endif
     if (wino) {
         if (Kh != 3 || stride != 1 || pad != 1 || Cin % 8 || Cout % 64 || sc != 1 || up || sw != Cin ||
             sh != (int64_t)Wi * Cin || sb != (int64_t)Hi * Wi * Cin)

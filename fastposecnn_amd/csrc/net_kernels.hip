@@ -129,6 +129,9 @@ __global__ __launch_bounds__(256, (BM * BN >= 128 * 128) ? 1 : 2) void k_conv_ig
     constexpr int TM = BM / 64, TN = BN / 64;     // 32x32 tiles per wave
     constexpr int AR = BM / 32, BR = BN / 32;     // float4 rows staged per thread
     __shared__ __attribute__((aligned(16))) float lds[2 * (BM + BN) * kLdsRow];
+#ifdef FPC_STAMP_IGEMM      // diagnostic build (tools_dev/igemm_stamps.py): phase stamps per wave into a.dbg
+    const long long st0 = clock64();
+#endif
 
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int wm = wave >> 1, wn = wave & 1;
@@ -258,6 +261,9 @@ __global__ __launch_bounds__(256, (BM * BN >= 128 * 128) ? 1 : 2) void k_conv_ig
     }
     if (ks0 + 1 < ks1) FPC_CONV_LOAD(ks0 + 1, ra0, rb0);
     __syncthreads();
+#ifdef FPC_STAMP_IGEMM
+    const long long st1 = clock64();
+#endif
     for (int ks = ks0; ks < ks1; ks += 2) {
         // even phase: LDS buffer 0 holds step ks, set 0 holds ks+1
         if (ks + 2 < ks1) FPC_CONV_LOAD(ks + 2, ra1, rb1);
@@ -272,6 +278,9 @@ __global__ __launch_bounds__(256, (BM * BN >= 128 * 128) ? 1 : 2) void k_conv_ig
         __syncthreads();
     }
 
+#ifdef FPC_STAMP_IGEMM
+    const long long st2 = clock64();
+#endif
     // C/D layout of the 32x32 tile: column = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5),
     // i.e. a lane holds 16 rows of ONE channel.  Each wave transposes its tile through a private LDS
     // patch (the operand buffers are free after the last barrier) so that a lane owns 4 consecutive
@@ -372,6 +381,13 @@ __global__ __launch_bounds__(256, (BM * BN >= 128 * 128) ? 1 : 2) void k_conv_ig
                 }
             }
         }
+#ifdef FPC_STAMP_IGEMM
+    if (a.dbg && lane == 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        long long* o = (long long*)a.dbg + ((size_t)blockIdx.x * 4 + wave) * 4;
+        o[0] = st1 - st0; o[1] = st2 - st1; o[2] = clock64() - st2; o[3] = ks1 - ks0;
+    }
+#endif
 }
 
 // Sums the split-K partials in split order and applies the epilogue.

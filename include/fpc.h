@@ -19,6 +19,7 @@
  *   fpc_cc_label                 lib/aggregation_layer.py:160-183 (cupyx / scipy ndimage.label)
  *   fpc_aggregate                lib/aggregation_layer.py:61-158
  *   fpc_pose_rt                  lib/gpu_tensor_funcs.py:204-253, 306-326
+ *   fpc_pack_pose_records        (none: multi-GPU gather record)
  *   fpc_mask_iou                 lib/gpu_tensor_funcs.py:386-409 (batchwise_get_2d_iou), called by lib/matching.py:264-267
  *   fpc_net_*                    lib/pose_regressor.py:709-743 (+ segmentation_models_pytorch encoder/decoder/head)
  * The Python-side bindings a maintainer would add are shown in INTEGRATION.md.
@@ -128,6 +129,15 @@ int fpc_aggregate(const int32_t* labels, const int64_t* cat_mask,
  * -> R [n,9], T [n,3], RT [n,16]. */
 int fpc_pose_rt(const float* q, const float* xy, const float* z, const float* kinv, int n,
                 float* R, float* T, float* RT, fpc_stream_t stream);
+
+/* ---- multi-GPU pose records ---------------------------------------------------
+ * No reference counterpart (its evaluate / inference scripts are single-GPU, evaluate.py:90,127): one rank's
+ * per-instance results as fixed-width records for ONE all-gather (fastposecnn_amd/parallel.py).
+ * out f32 [capacity+1][40]: row 0 = {n as int32 bits, 0...}; row 1+i = {sample_id + sample_offset, class_id (int32
+ * bits), quaternion[4], scales[3], xy[2], z[1], R[9], T[3], RT[16]}; rows past n are zero.  n <= capacity. */
+int fpc_pack_pose_records(const int64_t* sample_ids, const int64_t* class_ids, const float* q, const float* scales,
+                          const float* xy, const float* z, const float* R, const float* T, const float* RT, int n,
+                          int sample_offset, int capacity, float* out, fpc_stream_t stream);
 
 /* ---- matching: 2D IoU of every (mask1, mask2) pair ----------------------------
  * lib/gpu_tensor_funcs.py:386-409 batchwise_get_2d_iou (the [n1,n2,H,W] logical_and / logical_or expansion

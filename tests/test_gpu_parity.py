@@ -586,3 +586,23 @@ def test_find_matches_golden_and_oracle(lib, oracle, dev):
             assert sorted(got) == sorted(want)
             for k in want:
                 assert np.array_equal(got[k].cpu().numpy(), want[k]), (trial, k)
+
+
+def test_pack_pose_records_native_equals_host_logic(lib, dev):
+    """fpc_pack_pose_records (one launch) against parallel.pack_pose_records' torch path on CPU tensors (the path the
+    world-size-2 gloo test covers): bit-identical buffer, incl. n = 0 and n = capacity; unpack round trip."""
+    from fastposecnn_amd import parallel
+    rng = np.random.default_rng(2)
+    for n, cap in ((5, 8), (0, 4), (4, 4)):
+        agg = {"sample_ids": torch.from_numpy(rng.integers(0, 3, n)), "class_ids": torch.from_numpy(rng.integers(1, 7, n)),
+               "quaternion": torch.from_numpy(rng.normal(size=(n, 4)).astype(np.float32)),
+               "scales": torch.from_numpy(rng.random((n, 3)).astype(np.float32)), "xy": torch.from_numpy(rng.random((n, 2)).astype(np.float32)),
+               "z": torch.from_numpy(rng.random((n, 1)).astype(np.float32)), "R": torch.from_numpy(rng.normal(size=(n, 3, 3)).astype(np.float32)),
+               "T": torch.from_numpy(rng.normal(size=(n, 3)).astype(np.float32)), "RT": torch.from_numpy(rng.normal(size=(n, 4, 4)).astype(np.float32))}
+        want = parallel.pack_pose_records(agg, sample_offset=32, capacity=cap)
+        got = parallel.pack_pose_records({k: v.to(dev) for k, v in agg.items()}, sample_offset=32, capacity=cap)
+        assert got.is_cuda and torch.equal(got.cpu().view(torch.int32), want.view(torch.int32))
+        out = parallel.unpack_pose_records(got[None].cpu())
+        assert torch.equal(out["sample_ids"], agg["sample_ids"] + 32) and torch.equal(out["RT"], agg["RT"])
+    with pytest.raises(RuntimeError):
+        parallel.pack_pose_records({k: v.to(dev) for k, v in agg.items()}, 0, capacity=2)
