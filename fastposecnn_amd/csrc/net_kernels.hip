@@ -535,6 +535,17 @@ __device__ __forceinline__ Lerp lerp_coord(int dst, int in, int out) {
     return L;
 }
 
+// lerp_coord with the scale (in - 1) / (out - 1) computed by the caller once
+__device__ __forceinline__ Lerp lerp_scaled(int dst, int in, float scale) {
+    float src = scale * (float)dst;
+    Lerp L;
+    L.i0 = (int)src;
+    L.i1 = L.i0 + (L.i0 < in - 1 ? 1 : 0);
+    L.l1 = src - (float)L.i0;
+    L.l0 = 1.f - L.l1;
+    return L;
+}
+
 __device__ __forceinline__ float4 gn_relu4(const float* p, float4 sa, float4 sb) {
     float4 v = *reinterpret_cast<const float4*>(p);
     v.x = fmaxf(v.x * sa.x + sb.x, 0.f); v.y = fmaxf(v.y * sa.y + sb.y, 0.f);
@@ -595,16 +606,29 @@ constexpr int kMhPx = 32;
 constexpr int kMhMaxC = 128;
 constexpr int kMhMaxCh = 32;
 
+#ifdef FPC_STAMP_MH      // diagnostic build: summed phase ticks of lane 0 / wave 0 of every workgroup
+__device__ unsigned long long g_mh[6];
+#define FPC_MH_STAMP(I) do { if (threadIdx.x == 0) { long long n_ = clock64(); atomicAdd(&g_mh[I], (unsigned long long)(n_ - mh_t)); mh_t = n_; } } while (0)
+#else
+#define FPC_MH_STAMP(I) do { } while (0)
+#endif
+
 __global__ __launch_bounds__(256) void k_merge_head(const MergeHeadArgs a) {
+#ifdef FPC_STAMP_MH
+    long long mh_t = clock64();
+#endif
     __shared__ __attribute__((aligned(16))) float s_m[kMhPx][kMhMaxC + 4];
     __shared__ __attribute__((aligned(16))) float s_w[kMhMaxCh][kMhMaxC + 4];
     const int z = blockIdx.z, b = blockIdx.y;
     const int H2 = 2 * a.h, W2 = 2 * a.w, C = a.C, C4 = C >> 2;
     const int ch = a.ch[z], chp = a.chp[z];
-    for (int i = threadIdx.x; i < ch * C; i += 256) s_w[i / C][i % C] = a.hw[z][i];
+    // C4 divides 256 (C = 128): a thread's channel quad is fixed — no division inside the loops
+    const int c4f = threadIdx.x % C4, prow = threadIdx.x / C4, pstep = 256 / C4;
+    for (int r = prow; r < kMhMaxCh; r += pstep)            // rows past ch: zero (the MFMA tile is 32 wide)
+        *reinterpret_cast<f32x4*>(&s_w[r][4 * c4f]) =
+            r < ch ? *reinterpret_cast<const f32x4*>(a.hw[z] + (size_t)r * C + 4 * c4f) : f32x4{0.f, 0.f, 0.f, 0.f};
     const int p0 = blockIdx.x * kMhPx;
-    // C4 divides 256 (C = 128): a thread's channel quad is fixed, its GroupNorm affines are loaded once
-    const int c4f = threadIdx.x % C4;
+    // the thread's GroupNorm affines are loaded once
     f32x4 la[3], lb[3], ha, hb;
     {
         float4 sa, sb;
@@ -616,19 +640,24 @@ __global__ __launch_bounds__(256) void k_merge_head(const MergeHeadArgs a) {
         load_affine4(a.a_hi[z] + ((size_t)b * C + 4 * c4f) * 2, sa, sb);
         ha = f32x4{sa.x, sa.y, sa.z, sa.w}; hb = f32x4{sb.x, sb.y, sb.z, sb.w};
     }
+    FPC_MH_STAMP(0);      // head weights -> LDS, affines
     auto gnr = [](const float* ptr, f32x4 sa, f32x4 sb) {
         f32x4 v = *reinterpret_cast<const f32x4*>(ptr) * sa + sb;
         v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f);
         return v;
     };
+    // bilinear source scales (align_corners): computed once, same arithmetic as lerp_coord
+    const float sy = H2 > 1 ? (float)(a.h - 1) / (float)(H2 - 1) : 0.f, sx = W2 > 1 ? (float)(a.w - 1) / (float)(W2 - 1) : 0.f;
+    const int y0 = p0 / W2, x0 = p0 - y0 * W2;               // workgroup-uniform
 #pragma unroll 2
-    for (int e = threadIdx.x; e < kMhPx * C4; e += 256) {
-        int c4 = e % C4, pl = e / C4;
+    for (int pl = prow; pl < kMhPx; pl += pstep) {
+        const int c4 = c4f;
         int p = p0 + pl;
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
         if (p < H2 * W2) {
-            int y = p / W2, x = p - y * W2;
-            Lerp ly = lerp_coord(y, a.h, H2), lx = lerp_coord(x, a.w, W2);
+            int y = y0, x = x0 + pl;
+            while (x >= W2) { x -= W2; ++y; }
+            Lerp ly = lerp_scaled(y, a.h, sy), lx = lerp_scaled(x, a.w, sx);
 #pragma unroll
             for (int k = 0; k < 3; ++k) {
                 const float* base = a.t_lo[z][k] + (size_t)b * a.h * a.w * C + 4 * c4;
@@ -642,24 +671,59 @@ __global__ __launch_bounds__(256) void k_merge_head(const MergeHeadArgs a) {
         }
         *reinterpret_cast<f32x4*>(&s_m[pl][4 * c4]) = acc;
     }
+    FPC_MH_STAMP(1);      // gather + GroupNorm + ReLU + bilinear merge
     __syncthreads();
-    // head: lanes along the pixel axis read LDS rows at stride C+4 (conflict-free), weights broadcast
-    for (int e = threadIdx.x; e < kMhPx * chp; e += 256) {
-        int pl = e % kMhPx, k = e / kMhPx;
-        int p = p0 + pl;
-        if (p >= H2 * W2) continue;
-        float v = 0.f;
-        if (k < ch) {
-            v = a.hb[z][k];
-            for (int c = 0; c < C; c += 4) {
-                float4 m = *reinterpret_cast<const float4*>(&s_m[pl][c]);
-                float4 w = *reinterpret_cast<const float4*>(&s_w[k][c]);
-                v += m.x * w.x; v += m.y * w.y; v += m.z * w.z; v += m.w * w.w;
-            }
-        }
-        a.out[z][((size_t)b * H2 * W2 + p) * chp + k] = v;
+    FPC_MH_STAMP(2);      // barrier
+    // head (1x1 conv, C -> ch <= 32) on the matrix cores: the 32 px x 32 ch tile, K = C split over the four waves
+    // (wave w owns channels [w C/4, (w+1) C/4)); A = merged activations, B = head weights, both read from LDS as
+    // 16-byte fragments (2 x C/32 ds_read_b128 per wave — the scalar-FMA form needed ~900 wave-level LDS reads
+    // per workgroup and was LDS-bound: 40 us for the four decoders).  Partials are summed in wave order.
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, li = lane & 31, lh = lane >> 5;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    const int kq = C >> 2;                                   // K range of a wave (C % 32 == 0, checked by the launcher)
+    for (int k0 = wv * kq; k0 < (wv + 1) * kq; k0 += 8) {
+        f32x4 fa = *reinterpret_cast<const f32x4*>(&s_m[li][k0 + 4 * lh]);
+        f32x4 fb = *reinterpret_cast<const f32x4*>(&s_w[li][k0 + 4 * lh]);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[e], fb[e], acc, 0, 0, 0);
     }
+    FPC_MH_STAMP(3);      // MFMA head
+    __syncthreads();                                         // all fragments read: s_m becomes the partial buffer
+    float* part = &s_m[0][0];                                // [4 waves][32 px][33]: 4224 floats = sizeof(s_m)
+    static_assert(kMhPx * (kMhMaxC + 4) >= 4 * 32 * 33, "partial buffer");
+#pragma unroll
+    for (int r = 0; r < 16; ++r) part[(wv * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * 33 + li] = acc[r];
+    __syncthreads();
+    // the 32 pixels' outputs are one contiguous block of 32 * chp floats; 32 lanes per pixel (k < chp active)
+    const int nvalid = min(kMhPx, H2 * W2 - p0);
+    float* ob = a.out[z] + ((size_t)b * H2 * W2 + p0) * chp;
+    const int ok = threadIdx.x & 31;
+    const float bias = ok < ch ? a.hb[z][ok] : 0.f;
+    for (int pl = threadIdx.x >> 5; pl < nvalid; pl += 8) {
+        if (ok >= chp) continue;
+        float v = 0.f;
+        if (ok < ch) {
+            v = bias;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) v += part[(w * 32 + pl) * 33 + ok];
+        }
+        ob[pl * chp + ok] = v;
+    }
+    FPC_MH_STAMP(4);      // partial exchange + stores
+#ifdef FPC_STAMP_MH
+    if (threadIdx.x == 0) atomicAdd(&g_mh[5], 1ull);
+#endif
 }
+
+#ifdef FPC_STAMP_MH
+extern "C" int fpc_dbg_merge_head_stamps(unsigned long long* out6) {
+    unsigned long long z[6] = {0, 0, 0, 0, 0, 0};
+    if (hipMemcpyFromSymbol(out6, HIP_SYMBOL(g_mh), sizeof(z)) != hipSuccess) return -1;
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_mh), z, sizeof(z)) == hipSuccess ? 0 : -1;
+}
+#endif
 
 // ------------------------------------------------------------------------------------------
 // x4 bilinear upsample (UpsamplingBilinear2d, align_corners=True) of the four heads' low-res
@@ -933,7 +997,7 @@ int launch_gn_relu_up2(const GnUpArgs& a, int groups, hipStream_t s) {
 }
 
 int launch_merge_head(const MergeHeadArgs& a, int groups, hipStream_t s) {
-    if (a.C > kMhMaxC || a.C % 4 != 0 || 256 % (a.C / 4) != 0) return FPC_EINVAL;
+    if (a.C > kMhMaxC || a.C % 32 != 0 || 256 % (a.C / 4) != 0) return FPC_EINVAL;      // the head splits C over 4 waves in 8-channel steps
     for (int z = 0; z < groups; ++z)
         if (a.ch[z] > kMhMaxCh || a.chp[z] > kMhMaxCh || a.chp[z] < a.ch[z]) return FPC_EINVAL;
     hipLaunchKernelGGL(k_merge_head, dim3(cdiv(4 * a.h * a.w, kMhPx), a.B, groups), dim3(256), 0, s, a);

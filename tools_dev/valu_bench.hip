@@ -27,6 +27,18 @@ __global__ __launch_bounds__(256) void probe(float* out, int iters, float s0, fl
             a0 = __builtin_fmaf(a0, s0, a2); a1 = __builtin_fmaf(a1, s1, a3); a2 = __builtin_fmaf(a2, s0, a4); a3 = __builtin_fmaf(a3, s1, a5);
             cnt += __popcll(__builtin_amdgcn_ballot_w64(a0 >= s0)); cnt += __popcll(__builtin_amdgcn_ballot_w64(a1 >= s0));
             cnt += __popcll(__builtin_amdgcn_ballot_w64(a2 >= s1)); cnt += __popcll(__builtin_amdgcn_ballot_w64(a3 >= s1));
+        } else if (KIND == 6) {   // 4 fma + 4 v_cmp -> sgpr pairs, OR-combined (no s_bcnt1 / s_add chain)
+            a0 = __builtin_fmaf(a0, s0, a2); a1 = __builtin_fmaf(a1, s1, a3); a2 = __builtin_fmaf(a2, s0, a4); a3 = __builtin_fmaf(a3, s1, a5);
+            unsigned long long m = __builtin_amdgcn_ballot_w64(a0 >= s0) | __builtin_amdgcn_ballot_w64(a1 >= s0) |
+                                   __builtin_amdgcn_ballot_w64(a2 >= s1) | __builtin_amdgcn_ballot_w64(a3 >= s1);
+            cnt += (int)(m & 1);
+        } else if (KIND == 7) {   // 4 fma + 4 (v_cmp -> vcc, v_addc per-lane counter)
+            a0 = __builtin_fmaf(a0, s0, a2); a1 = __builtin_fmaf(a1, s1, a3); a2 = __builtin_fmaf(a2, s0, a4); a3 = __builtin_fmaf(a3, s1, a5);
+            cnt += (a0 >= s0); cnt += (a1 >= s0); cnt += (a2 >= s1); cnt += (a3 >= s1);
+        } else if (KIND == 8) {   // 4 fma + 4 x (v_sub, v_min |.|) : the band-distance accumulation
+            a0 = __builtin_fmaf(a0, s0, a2); a1 = __builtin_fmaf(a1, s1, a3); a2 = __builtin_fmaf(a2, s0, a4); a3 = __builtin_fmaf(a3, s1, a5);
+            a4 = __builtin_fminf(a4, __builtin_fabsf(a0 - s0)); a4 = __builtin_fminf(a4, __builtin_fabsf(a1 - s0));
+            a5 = __builtin_fminf(a5, __builtin_fabsf(a2 - s1)); a5 = __builtin_fminf(a5, __builtin_fabsf(a3 - s1));
         } else if (KIND == 5) {   // 8 v_readlane
             int l = i & 63;
             cnt += __builtin_amdgcn_readlane(__builtin_bit_cast(int, a0), l) + __builtin_amdgcn_readlane(__builtin_bit_cast(int, a1), l)
@@ -53,9 +65,10 @@ template <int KIND> void run(const char* name, int wgs_per_cu) {
     hipFree(out);
 }
 int main() {
-    for (int w : {1, 2, 4, 8}) {
+    for (int w : {4, 8}) {
         run<0>("v_fma_f32 vgpr", w); run<1>("v_fma_f32 sgpr operand", w); run<2>("v_pk_fma_f32", w);
         run<3>("v_pk_fma_f32 splat sgpr", w); run<4>("4 fma + 4 cmp->sgpr+bcnt (per 8)", w); run<5>("v_readlane x8", w);
+        run<6>("4 fma + 4 cmp->sgpr, OR (per 8)", w); run<7>("4 fma + 4 cmp->vcc + addc (per 8)", w); run<8>("4 fma + 4 (sub + min|.|) (per 8: 12 instr)", w);
     }
     return 0;
 }
