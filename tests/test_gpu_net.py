@@ -208,14 +208,16 @@ def test_net_vs_float64_cpu(lib, dev, encoder, B, H, W):
         assert err <= 1e-4 * max(1.0, ref[k].abs().max().item()), (k, err)
 
 
-def test_net_fullsize_vs_torch_modules(lib, dev):
-    """640x480, ResNet18: engine logits vs the torch-ROCm module path; the fused class compression
-    is bit-identical to the stand-alone kernel on the engine's own logits."""
+@pytest.mark.parametrize("encoder,B", [("resnet18", 1), ("resnet34", 3)], ids=["config2-r18-b1", "config3-r34-b3"])
+def test_net_fullsize_vs_torch_modules(lib, dev, encoder, B):
+    """640x480 (BASELINE configs[1]: ResNet18 B = 1; configs[2]'s shape: ResNet34, batch > 1 with per-image
+    seeds): engine logits vs the torch-ROCm module path; the fused class compression is bit-identical to the
+    stand-alone kernel on the engine's own logits."""
     import gpu_tensor_funcs as gtf
     from fastposecnn_amd import synth
-    m, hp = _model(lib, dev, "resnet18")
+    m, hp = _model(lib, dev, encoder)
     m = m.to(dev)
-    x = synth.make_image(0)[None].to(dev)
+    x = torch.stack([synth.make_image(i) for i in range(B)]).to(dev)
     with torch.no_grad():
         out = m(x)
     assert m._engines
@@ -230,7 +232,7 @@ def test_net_fullsize_vs_torch_modules(lib, dev):
         assert torch.equal(cat[k], out["categorical"][k]), k
     # schema of the reference's forward
     assert set(out) == {"logits", "categorical", "aggregated"} and out["aggregated"] is None
-    assert out["categorical"]["mask"].dtype == torch.int64 and tuple(out["categorical"]["z"].shape) == (1, 480, 640)
+    assert out["categorical"]["mask"].dtype == torch.int64 and tuple(out["categorical"]["z"].shape) == (B, 480, 640)
 
 
 def test_engine_invalidation(lib, dev):
