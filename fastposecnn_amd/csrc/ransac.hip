@@ -100,6 +100,7 @@ struct Ws {
     int32_t* chunk_kept;  // [n, nch]
     int32_t* meta;        // [n, kMeta]
     float* hyp;           // [n, hn, 2]
+    float* hrec;          // [n, hnp, 4]  {fx, fy, E_h, 0} per hypothesis for k_count_hi's scalar loads (hnp = hn rounded up to 64)
     double* partial;      // [n, kSelP, kPartial]   k_refine partial sums
     float4* px;           // [n, HW]  {x, y, dx, dy}
     size_t zero_bytes;    // leading bytes cleared per call
@@ -119,6 +120,7 @@ static Ws carve(void* base, int n, int H, int W, int hn) {
     w.chunk_kept = (int32_t*)(p + off); off = align_up(off + sizeof(int32_t) * (size_t)n * nch, 256);
     w.meta = (int32_t*)(p + off); off = align_up(off + sizeof(int32_t) * (size_t)n * kMeta, 256);
     w.hyp = (float*)(p + off); off = align_up(off + sizeof(float) * (size_t)n * hn * 2, 256);
+    w.hrec = (float*)(p + off); off = align_up(off + sizeof(float) * (size_t)n * (size_t)(cdiv(hn, kWave) * kWave) * 4, 256);
     w.partial = (double*)(p + off); off = align_up(off + sizeof(double) * (size_t)n * kSelP * kPartial, 256);
     w.px = (float4*)(p + off); off = align_up(off + sizeof(float4) * (size_t)n * HW, 256);
     w.total = off;
@@ -258,17 +260,32 @@ __device__ __forceinline__ void make_hypothesis(const float4* __restrict__ P, in
     if (t0 >= 0 && t0 < tn && t1 >= 0 && t1 < tn) intersect(P[t0], P[t1], x, y);
 }
 
-__global__ __launch_bounds__(256) void k_hypothesis(const float4* __restrict__ px, int HW, int hn,
+// Also writes the record k_count_hi walks with scalar loads: {fx, fy, E_h, 0} — the point used by the cones and
+// their rounding allowance E_h = 2e-6 (|hx| + |hy| + W + H).  Outside the filter's domain (huge / non-finite
+// coordinates) E = +inf: every voting pixel is "maybe" and is decided by the exact test.  Padding entries
+// (hi >= hn, up to the next multiple of 64) get E = NaN: nothing ever counts.
+__global__ __launch_bounds__(256) void k_hypothesis(const float4* __restrict__ px, int HW, int hn, int hnp,
                                                     const int32_t* __restrict__ idxs, uint64_t seed,
-                                                    const int32_t* __restrict__ meta, float* __restrict__ hyp, const int32_t* __restrict__ n_dev) {
+                                                    const int32_t* __restrict__ meta, float* __restrict__ hyp,
+                                                    float* __restrict__ hrec, float wh, const int32_t* __restrict__ n_dev) {
     if (n_dev && (int)(blockIdx.y) >= *n_dev) return;   // capacity rows past the device-side instance count
     int inst = blockIdx.y;
     int hi = blockIdx.x * blockDim.x + threadIdx.x;
-    if (hi >= hn) return;
+    if (hi >= hnp) return;
+    float4* rec = hrec ? reinterpret_cast<float4*>(hrec) + (size_t)inst * hnp + hi : nullptr;
+    if (hi >= hn) {
+        if (rec) *rec = make_float4(0.f, 0.f, __builtin_nanf(""), 0.f);
+        return;
+    }
     float x, y;
     make_hypothesis(px + (size_t)inst * HW, meta[inst * kMeta + 1], hn, inst, hi, idxs, seed, x, y);
     hyp[((size_t)inst * hn + hi) * 2] = x;
     hyp[((size_t)inst * hn + hi) * 2 + 1] = y;
+    if (rec) {
+        float s = fabsf(x) + fabsf(y);
+        *rec = s <= 1e18f ? make_float4(x, y, 2e-6f * (s + wh), 0.f)           // false for inf / NaN
+                          : make_float4(0.f, 0.f, __builtin_huge_valf(), 0.f);
+    }
 }
 
 // Exact inlier counts, one lane per hypothesis, pixel tile broadcast from LDS.
@@ -320,9 +337,10 @@ __global__ __launch_bounds__(256) void k_count_exact(const float4* __restrict__ 
 // SGPRs, so a (tile, hypothesis) step is 6 FMA + 2 compares per lane, two ballots — no LDS or memory
 // traffic inside the loop; the exact test runs only for the lanes of a tile that fall between the cones.
 template <int T>
-__global__ __launch_bounds__(256) void k_count_hi(const float4* __restrict__ px, int HW, int hn, float wh,
+__global__ __launch_bounds__(256) void k_count_hi(const float4* __restrict__ px, int HW, int hn, int hnp,
                                                   float kappa1, float kappa2, float thresh,
                                                   const int32_t* __restrict__ meta, const float* __restrict__ hyp,
+                                                  const float* __restrict__ hrec,
                                                   int32_t* __restrict__ counts, const int32_t* __restrict__ n_dev) {
     if (n_dev && (int)blockIdx.z >= *n_dev) return;
     constexpr int kBlk = 4 * kWave * T;
@@ -334,17 +352,13 @@ __global__ __launch_bounds__(256) void k_count_hi(const float4* __restrict__ px,
     const float4* P = px + (size_t)inst * HW;
     if (threadIdx.x < kWave) s_cnt[threadIdx.x] = 0;
 
-    // this lane's hypothesis: the true point (hx, hy) for the exact test, (fx, fy, E_h) for the cones.
-    // Outside the filter's domain (huge / non-finite coordinates) E = +inf: every voting pixel is "maybe"
-    // and is decided by the exact test.  Past hn E = NaN: nothing ever counts.
-    float hx = 0.f, hy = 0.f, fx = 0.f, fy = 0.f, eh = __builtin_nanf("");
+    // this lane's hypothesis: the true point (hx, hy), read only by the exact test of the band pairs; the cones
+    // take (fx, fy, E_h) of hypothesis h0 + g from k_hypothesis' records with SCALAR loads (the address is
+    // workgroup-uniform) — three v_readlane per hypothesis cost 30 cycles of vector issue (tools_dev/valu_bench.hip)
+    float hx = 0.f, hy = 0.f;
     int hi = h0 + lane;
-    if (hi < hn) {
-        hx = hyp[((size_t)inst * hn + hi) * 2]; hy = hyp[((size_t)inst * hn + hi) * 2 + 1];
-        float s = fabsf(hx) + fabsf(hy);
-        if (s <= 1e18f) { fx = hx; fy = hy; eh = 2e-6f * (s + wh); }   // false for inf / NaN
-        else eh = __builtin_huge_valf();
-    }
+    if (hi < hn) { hx = hyp[((size_t)inst * hn + hi) * 2]; hy = hyp[((size_t)inst * hn + hi) * 2 + 1]; }
+    const float4* HR = reinterpret_cast<const float4*>(hrec) + (size_t)inst * hnp + h0;
     if (tn == 0) return;   // uniform
     __syncthreads();
 
@@ -373,9 +387,8 @@ __global__ __launch_bounds__(256) void k_count_hi(const float4* __restrict__ px,
         }
 #pragma unroll 4
         for (int g = 0; g < kWave; ++g) {
-            float gx = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, fx), g));
-            float gy = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, fy), g));
-            float ge = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, eh), g));
+            const float4 rec = HR[g];
+            const float gx = rec.x, gy = rec.y, ge = rec.z;
             int c = 0;
             unsigned long long band[T], any = 0;
 #pragma unroll
@@ -604,8 +617,9 @@ extern "C" int fpc_ransac_voting_v3(const float* mask, const float* vertex, int6
                        w.chunk_kept, n_dev);
     hipLaunchKernelGGL(k_compact, dim3(nch, n), dim3(256), 0, s, mask, vertex, vs_n, vs_h, vs_w, vs_c, keep, W, HW,
                        nch, seed, min_num, max_num, w.chunk_fg, w.chunk_kept, w.meta, w.px, n_dev);
-    hipLaunchKernelGGL(k_hypothesis, dim3(cdiv(hn, 256), n), dim3(256), 0, s, w.px, HW, hn, idxs, seed, w.meta, w.hyp,
-                       n_dev);
+    const int hnp = cdiv(hn, kWave) * kWave;
+    hipLaunchKernelGGL(k_hypothesis, dim3(cdiv(hnp, 256), n), dim3(256), 0, s, w.px, HW, hn, hnp, idxs, seed, w.meta, w.hyp,
+                       w.hrec, (float)(W + H), n_dev);
 
     // the cones need th' = th - 1e-6 > 0; otherwise every pair takes the reference's arithmetic
     bool fast = inlier_thresh > 2e-6f && inlier_thresh < 3.0e38f;
@@ -614,11 +628,10 @@ extern "C" int fpc_ransac_voting_v3(const float* mask, const float* vertex, int6
         double k1 = 1.0 - th1 * th1, k2 = 1.0 - th2 * th2;
         float kappa1 = (float)((k1 > 0.0 ? sqrt(k1) : 0.0) / th1) * (1.0f + 1e-6f);        // wider
         float kappa2 = (th2 < 1.0 && k2 > 0.0) ? (float)(sqrt(k2) / th2) * (1.0f - 1e-6f) : 0.0f;   // narrower (0: no "sure")
-        float wh = (float)(W + H);
         int split = cdiv(max_num < HW ? max_num + max_num / 8 + 64 : HW, kBlkPx);
         split = split < 1 ? 1 : (split > 64 ? 64 : split);
-        hipLaunchKernelGGL(k_count_hi<kT>, dim3(cdiv(hn, kWave), split, n), dim3(256), 0, s, w.px, HW, hn, wh, kappa1,
-                           kappa2, inlier_thresh, w.meta, w.hyp, w.counts, n_dev);
+        hipLaunchKernelGGL(k_count_hi<kT>, dim3(cdiv(hn, kWave), split, n), dim3(256), 0, s, w.px, HW, hn, hnp, kappa1,
+                           kappa2, inlier_thresh, w.meta, w.hyp, w.hrec, w.counts, n_dev);
     } else {
         int hb = cdiv(hn, 256);
         int split = 2048 / (n * hb);
