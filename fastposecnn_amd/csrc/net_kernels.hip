@@ -1591,7 +1591,8 @@ int launch_conv_wino(const WinoArgs& a, int groups, hipStream_t s) {
     if (a.waves == 8 && a.variant == 2) {
         if (a.dbg) hipLaunchKernelGGL((k_conv_wino<8, false, true, true>), grid, dim3(512), 0, s, a);
         else hipLaunchKernelGGL((k_conv_wino<8, false, true>), grid, dim3(512), 0, s, a);
-    } else if (a.waves == 8) hipLaunchKernelGGL((k_conv_wino<8, false, false>), grid, dim3(512), 0, s, a);
+    } else if (a.waves == 8 && a.dbg) hipLaunchKernelGGL((k_conv_wino<8, false, false, true>), grid, dim3(512), 0, s, a);
+    else if (a.waves == 8) hipLaunchKernelGGL((k_conv_wino<8, false, false>), grid, dim3(512), 0, s, a);
     else if (a.variant == 1) hipLaunchKernelGGL((k_conv_wino<4, true, false>), grid, dim3(256), 0, s, a);
     else if (a.dbg) hipLaunchKernelGGL((k_conv_wino<4, false, false, true>), grid, dim3(256), 0, s, a);
     else hipLaunchKernelGGL((k_conv_wino<4, false, false>), grid, dim3(256), 0, s, a);

@@ -1,54 +1,53 @@
-"""Stage timer with the reference's interface (F/tools/timer.py:8-63).
+"""Stage timer with the reference's interface (F/tools/timer.py:8-63): a decorator object per stage with
+`enabled`, `runtimes` (ms), `average`, `fps` and `clear()`.  lib/pose_regressor.py uses the same six stage names,
+so `model.report_runtime()` prints the same table.
 
-Same decorator protocol (`enabled`, `runtimes`, `average` in ms, `fps`, `clear`) and the same
-six stage names are used by lib/pose_regressor.py, so `model.report_runtime()` prints the same
-table.  Events are HIP events (torch.cuda.Event on ROCm), created lazily so that importing the
-package on a CPU-only box does not touch the GPU runtime.
+Differences by design: the two HIP events (torch.cuda.Event on ROCm) are created on first use, so importing the
+package on a CPU-only box never touches the GPU runtime; a timed call waits on its own end event instead of
+synchronising the whole device (the reference's `torch.cuda.synchronize()`, timer.py:37), so other streams keep
+running; without a GPU the wrapper is a pass-through.
 """
 import functools
+import statistics
 
-import numpy as np
 import torch
 
 
-class TimerDecorator(object):
-    """Decorator for timing functions"""
+class TimerDecorator:
 
     def __init__(self, name):
         self.name = name
-        self.runtimes = []
         self.enabled = False
-        self.start = None
-        self.end = None
+        self.runtimes = []
+        self._events = None
 
-    def __call__(self, function):
+    def _timed(self, fn, args, kwargs):
+        if self._events is None:
+            self._events = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+        begin, finish = self._events
+        begin.record()
+        out = fn(*args, **kwargs)
+        finish.record()
+        finish.synchronize()
+        self.runtimes.append(begin.elapsed_time(finish))
+        return out
 
-        @functools.wraps(function)
-        def wrapper(*args, **kwargs):
-            if not self.enabled or not torch.cuda.is_available():
-                return function(*args, **kwargs)
-            if self.start is None:
-                self.start = torch.cuda.Event(enable_timing=True)
-                self.end = torch.cuda.Event(enable_timing=True)
-            self.start.record()
-            result = function(*args, **kwargs)
-            self.end.record()
-            # the reference synchronises the whole device here (timer.py:37); the end event suffices
-            self.end.synchronize()
-            self.runtimes.append(self.start.elapsed_time(self.end))
-            return result
-
-        return wrapper
+    def __call__(self, fn):
+        @functools.wraps(fn)
+        def timed_or_plain(*args, **kwargs):
+            if self.enabled and torch.cuda.is_available():
+                return self._timed(fn, args, kwargs)
+            return fn(*args, **kwargs)
+        return timed_or_plain
 
     @property
     def average(self):
-        self._average = np.mean(np.array(self.runtimes))
-        return self._average
+        """Mean runtime in ms (NaN before the first timed call, like numpy's mean of nothing)."""
+        return statistics.fmean(self.runtimes) if self.runtimes else float("nan")
 
     @property
     def fps(self):
-        self._fps = 1000 / self.average
-        return self._fps
+        return 1000.0 / self.average
 
     def clear(self):
         self.runtimes.clear()
