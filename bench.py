@@ -181,6 +181,12 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # set-up, not warm-up: every stream's plan is built and autotuned here (seconds), whatever --warmup says
+    if not args.vote_only:
+        streamer.prepare(x, categorical_override=cat)
+    for _ in range(2 * (depth + 1)):       # ... and every stream's allocator pool has seen a full pipeline of frames
+        step()
+    drain()
     for _ in range(args.warmup):
         step()
     drain()

@@ -73,6 +73,12 @@ class FrameStreamer:
                         ticket["agg_only"] = model.aggregate(src)
         return ticket
 
+    def prepare(self, x, categorical_override=None):
+        """Build (and autotune) every stream's native plan for this input shape now, one at a time on an otherwise
+        idle GPU, by running one frame through each.  Optional: `submit` does the same lazily on a plan's first frame."""
+        for _ in range(len(self.models)):
+            self.collect(self.submit(x, categorical_override=categorical_override))
+
     def submit(self, x, categorical_override=None):
         """Enqueue one frame (x f32 [B,3,H,W] on the device).  `categorical_override` replaces the
         network's categorical output as the input of the post-network stages (benchmark fixture)."""
