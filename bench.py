@@ -103,12 +103,13 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch N>1 with `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N`")
         raise SystemExit(f"--gpus {args.gpus} does not match WORLD_SIZE {world}")
-    dev = torch.device("cuda", local_rank)
+    dev = torch.device("cuda", local_rank % max(1, torch.cuda.device_count()))    # (several ranks on one GPU only in tests)
     torch.cuda.set_device(dev)
     import torch.distributed as dist
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        backend = os.environ.get("FPC_BENCH_BACKEND", "nccl")        # "gloo": lets two ranks share one GPU in a smoke test
+        dist.init_process_group(backend, **({"device_id": dev} if backend == "nccl" else {}))
 
     import fastposecnn_amd.lib as L
     from fastposecnn_amd import config, synth, parallel, _native
