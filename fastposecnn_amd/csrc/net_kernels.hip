@@ -1531,15 +1531,25 @@ __global__ __launch_bounds__(64 * NW, 2) void k_conv_wino(const WinoArgs a) {
                 s2 += val * val;
             }
         if (P.gn_part) {
-            // per-channel sums of this workgroup's outputs: NT tile slots -> LDS -> 32 threads
-            __syncthreads();
-            float* red = lds;                                  // [NT slots][32 ch][2]
+            // per-channel sums of this workgroup's outputs.  A wave holds 8 tiles (lane bits 3-5) of 8 channel quads
+            // (lane bits 0-2): butterfly over the tile bits, then the NW waves' sums through LDS in wave order
+            // (a serial walk of the NT tile slots by 32 threads cost ~4000 cycles per 32-channel half).
 #pragma unroll
-            for (int k = 0; k < 4; ++k) { red[(ot * 32 + oc4 + k) * 2] = s1[k]; red[(ot * 32 + oc4 + k) * 2 + 1] = s2[k]; }
+            for (int o = 8; o < 64; o <<= 1) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) { s1[k] += __shfl_xor(s1[k], o, 64); s2[k] += __shfl_xor(s2[k], o, 64); }
+            }
+            __syncthreads();
+            float* red = lds;                                  // [NW waves][32 ch][2]
+            if (lane < 8) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) { red[(wv * 32 + oc4 + k) * 2] = s1[k]; red[(wv * 32 + oc4 + k) * 2 + 1] = s2[k]; }
+            }
             __syncthreads();
             if (t < 32) {
                 float u1 = 0.f, u2 = 0.f;
-                for (int sI = 0; sI < NT; ++sI) { u1 += red[(sI * 32 + t) * 2]; u2 += red[(sI * 32 + t) * 2 + 1]; }
+#pragma unroll
+                for (int w = 0; w < NW; ++w) { u1 += red[(w * 32 + t) * 2]; u2 += red[(w * 32 + t) * 2 + 1]; }
                 int Pn = a.tbx * a.tby;
                 float* g = P.gn_part + (((size_t)b * Pn + by * a.tbx + bx) * Cout + nb * kWinoBN + nt * 32 + t) * 2;
                 g[0] = u1; g[1] = u2;
