@@ -42,6 +42,7 @@ _SIGNATURES = {
     "fpc_mask_iou": (_i, [_vp, _i, _vp, _i, _i64, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
     "fpc_net_create": (_i, [ctypes.c_char_p, _i, _i, _i, _i, ctypes.POINTER(_vp)]),
     "fpc_net_destroy": (None, [_vp]),
+    "fpc_net_set_graph": (_i, [_vp, _i]),
     "fpc_net_param_count": (_i, [_vp]),
     "fpc_net_param_name": (ctypes.c_char_p, [_vp, _i]),
     "fpc_net_param_numel": (_i64, [_vp, _i]),

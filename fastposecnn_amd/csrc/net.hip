@@ -128,6 +128,8 @@ struct fpc_net {
     int gn_P[7];
     Act a_low[4];                 // low-res logits
     size_t splitk_off = 0, splitk_floats = 0;
+    int use_graph = 0;            // replay the frame-invariant launches as a HIP graph (fpc_net_set_graph)
+    hipGraphExec_t graph_exec = nullptr;
     size_t zeros_off = 0;         // 64 zero floats (DMA source for out-of-image positions)
 
     // per-conv launch plans (index = conv id of decoder 0 for grouped ones)
@@ -296,7 +298,21 @@ extern "C" int fpc_net_create(const char* encoder, int classes, int B, int H, in
     return FPC_OK;
 }
 
-extern "C" void fpc_net_destroy(fpc_net_t* n) { delete n; }
+extern "C" void fpc_net_destroy(fpc_net_t* n) {
+    if (!n) return;
+    if (n->graph_exec) (void)hipGraphExecDestroy(n->graph_exec);
+    delete n;
+}
+
+// 1: after autotuning, the ~57 launches of a frame that only touch the plan's workspace are captured once and
+// replayed with one hipGraphLaunch per frame (the first and the last kernel take the caller's tensors and stay
+// ordinary launches).  Changing the tilings (fpc_net_autotune_next) or the parameters drops the recorded graph.
+extern "C" int fpc_net_set_graph(fpc_net_t* n, int on) {
+    if (!n) return FPC_EINVAL;
+    n->use_graph = on ? 1 : 0;
+    if (!on && n->graph_exec) { (void)hipGraphExecDestroy(n->graph_exec); n->graph_exec = nullptr; }
+    return FPC_OK;
+}
 extern "C" int fpc_net_param_count(const fpc_net_t* n) { return n ? (int)n->pnames.size() : 0; }
 extern "C" const char* fpc_net_param_name(const fpc_net_t* n, int i) {
     return (n && i >= 0 && i < (int)n->pnames.size()) ? n->pnames[i].c_str() : nullptr;
@@ -310,6 +326,7 @@ extern "C" int fpc_net_load_params(fpc_net_t* n, const float* const* params, int
                                    fpc_stream_t stream) {
     if (!n || !params || count != (int)n->pnames.size() || !ws) return FPC_EINVAL;
     if (((uintptr_t)ws & 255) != 0 || ws_bytes < n->total_floats * sizeof(float)) return FPC_EWORKSPACE;
+    if (n->graph_exec) { (void)hipGraphExecDestroy(n->graph_exec); n->graph_exec = nullptr; }       // pointers may change
     for (int i = 0; i < count; ++i)
         if (!params[i] || ((uintptr_t)params[i] & 15)) return FPC_EINVAL;
     hipStream_t s = (hipStream_t)stream;
@@ -441,23 +458,16 @@ int run_conv(fpc_net* n, ConvArgs& a, int groups, int ci, hipStream_t s) {
 
 #define FPC_TRY(x) do { int rc__ = (x); if (rc__) return rc__; } while (0)
 
-extern "C" int fpc_net_forward(fpc_net_t* n, const float* x, float* logits_mask, float* logits_quat,
-                               float* logits_scales, float* logits_xy, float* logits_z, int64_t* cat_mask, float* cq,
-                               float* cs, float* cxy, float* cz, fpc_stream_t stream) {
-    if (!n || !n->loaded || !x || !cat_mask || !cq || !cs || !cxy || !cz) return FPC_EINVAL;
-    bool any = logits_mask || logits_quat || logits_scales || logits_xy || logits_z;
-    bool all = logits_mask && logits_quat && logits_scales && logits_xy && logits_z;
-    if (any && !all) return FPC_EINVAL;
-    hipStream_t s = (hipStream_t)stream;
+// Everything between the NCHW -> NHWC4 conversion of the caller's image and the final upsample / class
+// compression into the caller's tensors: ~57 launches that touch only the plan's workspace and parameters, i.e.
+// identical every frame — the part that can be replayed as a HIP graph.
+static int forward_middle(fpc_net* n, hipStream_t s) {
     float* ws = n->ws;
     const int B = n->B, H = n->H, W = n->W;
     ConvArgs a;
     auto nhwc = [&](const Act& t, long long& sb, long long& sh, long long& sw, long long& sc) {
         sc = 1; sw = t.C; sh = (long long)t.W * t.C; sb = (long long)t.H * sh;
     };
-
-    // stem: image -> NHWC4 (16-byte pixels), 7x7/2 with BN + ReLU in the epilogue
-    FPC_TRY(launch_nchw3_to_nhwc4(x, ws + n->a_img4.off, B, H * W, s));
     {
         const PackedConv& c = n->convs[n->c_stem];
         fill_conv_args(n, a, c, n->cplan[n->c_stem], H, W, n->a_stem.H, n->a_stem.W, (long long)4 * H * W, (long long)4 * W, 4,
@@ -590,6 +600,45 @@ extern "C" int fpc_net_forward(fpc_net_t* n, const float* x, float* logits_mask,
         m.B = B; m.h = n->a_seg[0][2].H; m.w = n->a_seg[0][2].W; m.C = 128;
         FPC_TRY(launch_merge_head(m, 4, s));
     }
+    return FPC_OK;
+}
+
+extern "C" int fpc_net_forward(fpc_net_t* n, const float* x, float* logits_mask, float* logits_quat,
+                               float* logits_scales, float* logits_xy, float* logits_z, int64_t* cat_mask, float* cq,
+                               float* cs, float* cxy, float* cz, fpc_stream_t stream) {
+    if (!n || !n->loaded || !x || !cat_mask || !cq || !cs || !cxy || !cz) return FPC_EINVAL;
+    bool any = logits_mask || logits_quat || logits_scales || logits_xy || logits_z;
+    bool all = logits_mask && logits_quat && logits_scales && logits_xy && logits_z;
+    if (any && !all) return FPC_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    float* ws = n->ws;
+    const int B = n->B, H = n->H, W = n->W;
+    ConvArgs a;
+    auto nhwc = [&](const Act& t, long long& sb, long long& sh, long long& sw, long long& sc) {
+        sc = 1; sw = t.C; sh = (long long)t.W * t.C; sb = (long long)t.H * sh;
+    };
+
+    // stem: image -> NHWC4 (16-byte pixels), 7x7/2 with BN + ReLU in the epilogue
+    FPC_TRY(launch_nchw3_to_nhwc4(x, ws + n->a_img4.off, B, H * W, s));
+    // graph replay needs a capturable stream: not the null (legacy default) stream
+    if (n->use_graph && !n->tuning && s != nullptr && !n->graph_exec) {
+        // first such frame after tuning: record the launches instead of running them
+        hipGraph_t g = nullptr;
+        if (hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal) == hipSuccess) {
+            int rc = forward_middle(n, s);
+            hipError_t e = hipStreamEndCapture(s, &g);
+            if (rc) { if (g) (void)hipGraphDestroy(g); return rc; }
+            if (e == hipSuccess && g) e = hipGraphInstantiate(&n->graph_exec, g, nullptr, nullptr, 0);
+            if (g) (void)hipGraphDestroy(g);
+            if (e != hipSuccess) n->graph_exec = nullptr;
+        }
+        if (!n->graph_exec) { (void)hipGetLastError(); n->use_graph = 0; }      // not capturable here: plain launches from now on
+    }
+    if (n->use_graph && !n->tuning && s != nullptr && n->graph_exec) {
+        if (hipGraphLaunch(n->graph_exec, s) != hipSuccess) return FPC_ELAUNCH;
+    } else {
+        FPC_TRY(forward_middle(n, s));
+    }
     {
         Up4Args u;
         memset(&u, 0, sizeof(u));
@@ -611,6 +660,7 @@ extern "C" int fpc_net_autotune_next(fpc_net_t* n, int mode) {
     if (!n || !n->loaded || mode < 0 || mode > 1) return FPC_EINVAL;
     n->tuning = true;
     n->tune_mode = mode;
+    if (n->graph_exec) { (void)hipGraphExecDestroy(n->graph_exec); n->graph_exec = nullptr; }      // tilings may change
     return FPC_OK;
 }
 

@@ -14,7 +14,7 @@ from fastposecnn_amd import _native as nat
 
 class NetEngine:
 
-    def __init__(self, model, B, H, W, device, autotune=True, tune_mode=0):
+    def __init__(self, model, B, H, W, device, autotune=True, tune_mode=0, graph=False):
         L = nat.lib()
         self._lib = L
         self.B, self.H, self.W, self.device = B, H, W, device
@@ -48,6 +48,8 @@ class NetEngine:
             # one (discarded) forward that times every candidate tiling per convolution on this device
             nat.check(L.fpc_net_autotune_next(h, int(tune_mode)), "fpc_net_autotune_next")
             self.forward(torch.zeros((B, 3, H, W), dtype=torch.float32, device=device), want_logits=False)
+        if graph:
+            nat.check(L.fpc_net_set_graph(h, 1), "fpc_net_set_graph")
 
     def conv_plans(self):
         out = []

@@ -246,7 +246,8 @@ class PoseRegressor(Model, torch.nn.Module):
             # run (tuned plans may differ in split-K, i.e. in f32 summation order)
             eng = NetEngine(self, key[0], key[1], key[2], x.device,
                             autotune=getattr(self.HPARAM, 'ENGINE_AUTOTUNE', True),
-                            tune_mode=int(getattr(self.HPARAM, 'ENGINE_TUNE_MODE', 0)))
+                            tune_mode=int(getattr(self.HPARAM, 'ENGINE_TUNE_MODE', 0)),
+                            graph=bool(getattr(self.HPARAM, 'ENGINE_GRAPH', True)))
             self._engines[key] = eng
         return eng
 

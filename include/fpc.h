@@ -189,6 +189,10 @@ int fpc_net_forward(fpc_net_t* net, const float* x, float* logits_mask, float* l
  * fpc_net_conv_plan reports the tiling in use for convolution i: out5 = bm, bn, nsplit, Cout, K. */
 int fpc_net_autotune_next(fpc_net_t* net, int mode /* 0: minimise each conv's latency; 1: latency x sqrt(share of
                                                       the chip its grid occupies) — for several frames in flight */);
+/* HIP graph replay (default 0).  1: after autotuning, the frame-invariant launches of fpc_net_forward (everything
+ * between the image conversion and the final upsample / class compression, ~57 kernels on the plan's workspace) are
+ * captured once on the caller's stream and replayed with one hipGraphLaunch per frame. */
+int fpc_net_set_graph(fpc_net_t* net, int on);
 int fpc_net_conv_count(const fpc_net_t* net);
 int fpc_net_conv_plan(const fpc_net_t* net, int i, int* out5);
 /* Intermediate activations (NHWC f32 inside the workspace) for tests: "stem", "pool", "c2".."c5",

@@ -329,3 +329,37 @@ def test_forward_with_runtime_timing_and_report(lib, dev, capsys):
     hp.RUNTIME_TIMING = False
     m2 = lib.pose_regressor.MODELS['PoseRegressor'].construct_model(hp)       # resets the module-level timers
     assert not any(t.enabled for t in m2.TIMERS)
+
+
+def test_graph_replay_is_bit_identical(lib, dev):
+    """fpc_net_set_graph: on a non-default stream the frame-invariant launches are captured once and replayed;
+    same plan (static tilings), so logits and categorical outputs must equal the plain-launch run bit for bit —
+    over several frames with different images.  On the null stream the plan silently keeps plain launches."""
+    from fastposecnn_amd import synth
+    m, hp = _model(lib, dev, "resnet18")
+    hp.ENGINE_AUTOTUNE = False
+    m = m.to(dev)
+    xs = [torch.stack([synth.make_image(i, 96, 128)]).to(dev) for i in range(3)]
+    side = torch.cuda.Stream(device=dev)
+
+    def run(graph):
+        hp.ENGINE_GRAPH = graph
+        m._drop_engines()
+        outs = []
+        with torch.no_grad(), torch.cuda.stream(side):
+            for x in xs + xs:
+                lg = m.pure_model_forward(x)
+                cat = m.class_compression(lg)
+                outs.append({k: v.clone() for k, v in lg.items()} | {"cat_" + k: v.clone() for k, v in cat.items()})
+        side.synchronize()
+        return outs
+
+    plain, replay = run(False), run(True)
+    for a, b in zip(plain, replay):
+        for k in a:
+            assert torch.equal(a[k], b[k]), k
+    with torch.no_grad():                      # null stream: not capturable, must still work
+        m._drop_engines()
+        lg = m.pure_model_forward(xs[0])
+    torch.cuda.synchronize()
+    assert torch.equal(lg["mask"], plain[0]["mask"])

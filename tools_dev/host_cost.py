@@ -12,7 +12,7 @@ ap.add_argument("--n", type=int, default=60)
 ap.add_argument("--net-streams", type=int, default=4)
 a = ap.parse_args()
 dev = torch.device("cuda:0")
-hp = config.INFERENCE(); hp.RUNTIME_TIMING = False
+hp = config.INFERENCE(); hp.RUNTIME_TIMING = False; hp.ENGINE_GRAPH = bool(int(os.environ.get('FPC_ENGINE_GRAPH', '1')))
 torch.manual_seed(0)
 model = L.pose_regressor.MODELS[hp.MODEL].load_from_ckpt(None, hp).eval().to(dev)
 x = synth.make_image(0)[None].to(dev)
