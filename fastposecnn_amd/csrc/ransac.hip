@@ -88,7 +88,7 @@ __global__ void k_b1_vote(const float* __restrict__ direct, const float* __restr
 constexpr int kChunk = 1024;       // pixels per compaction chunk = 256 threads x 4
 constexpr int kTile = 256;         // pixels staged in LDS per step of the exact count
 constexpr int kMeta = 8;           // i32 per instance: fg, tn, win_idx, win_cnt, inl
-constexpr int kT = 4;              // pixel tiles (of 64) held in registers per lane in k_count_hi
+constexpr int kT = 2;              // pixel tiles (of 64) held in registers per lane in k_count_hi
 constexpr int kBlkPx = 4 * 64 * kT;  // pixels per k_count_hi workgroup pass (4 waves)
 constexpr int kSelP = 16;          // workgroups per instance in k_refine
 constexpr int kPartial = 8;        // doubles per k_refine partial record
