@@ -421,16 +421,14 @@ int run_conv(fpc_net* n, ConvArgs& a, int groups, int ci, hipStream_t s) {
         for (const ConvPlan& q : cands) {
             if (splitk_floats_for(q, groups, a.B, a.Npad) > cap) continue;
             int rc = launch_conv_plan(a, q, groups, s);     // warm-up (also validates the launch)
-            if (rc) { hipEventDestroy(e0); hipEventDestroy(e1); return rc; }
+            if (rc) { (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); return rc; }
             float ms = 1e30f;
             for (int rep = 0; rep < 2; ++rep) {
-                hipEventRecord(e0, s);
-                launch_conv_plan(a, q, groups, s);
-                hipEventRecord(e1, s);
-                hipEventSynchronize(e1);
                 float t = 0.f;
-                hipEventElapsedTime(&t, e0, e1);
-                if (t < ms) ms = t;
+                bool timed = hipEventRecord(e0, s) == hipSuccess && launch_conv_plan(a, q, groups, s) == FPC_OK &&
+                             hipEventRecord(e1, s) == hipSuccess && hipEventSynchronize(e1) == hipSuccess &&
+                             hipEventElapsedTime(&t, e0, e1) == hipSuccess;
+                if (timed && t < ms) ms = t;             // a candidate that cannot be timed keeps ms = 1e30: never chosen
             }
             // objective: latency, or (throughput mode) latency x the share of the chip the launch occupies —
             // with several frames in flight a launch that leaves CUs free lets another stream's kernels run
@@ -446,8 +444,8 @@ int run_conv(fpc_net* n, ConvArgs& a, int groups, int ci, hipStream_t s) {
             }
             if (score < best_ms) { best_ms = score; best = q; }
         }
-        hipEventDestroy(e0);
-        hipEventDestroy(e1);
+        (void)hipEventDestroy(e0);
+        (void)hipEventDestroy(e1);
         n->cplan[ci] = best;
     }
     ConvPlan p = n ? n->cplan[ci] : ConvPlan{a.bm, a.bn, a.nsplit, a.mtiles, a.ntiles, 0};
@@ -613,10 +611,6 @@ extern "C" int fpc_net_forward(fpc_net_t* n, const float* x, float* logits_mask,
     hipStream_t s = (hipStream_t)stream;
     float* ws = n->ws;
     const int B = n->B, H = n->H, W = n->W;
-    ConvArgs a;
-    auto nhwc = [&](const Act& t, long long& sb, long long& sh, long long& sw, long long& sc) {
-        sc = 1; sw = t.C; sh = (long long)t.W * t.C; sb = (long long)t.H * sh;
-    };
 
     // stem: image -> NHWC4 (16-byte pixels), 7x7/2 with BN + ReLU in the epilogue
     FPC_TRY(launch_nchw3_to_nhwc4(x, ws + n->a_img4.off, B, H * W, s));
