@@ -55,8 +55,8 @@ H, W = 480, 640
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=300)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--hn", type=int, default=1000, help="HV_NUM_OF_HYPOTHESES (1000 = config.INFERENCE)")
     ap.add_argument("--encoder", default="resnet18")
     ap.add_argument("--batch", type=int, default=1, help="frames per GPU per step (1 = BASELINE.json configs[1]; 32 = configs[2]/[3])")
