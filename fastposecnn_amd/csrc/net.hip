@@ -24,6 +24,7 @@ namespace fpc {
 
 struct PackedConv {
     int Cin = 0, Cinp = 0, Cout = 0, Kh = 1, Kw = 1, stride = 1, pad = 0;   // Cinp: channels of the input LAYOUT
+    int Kwp = 1;             // taps per kernel row in the packed layout (= Kw; 8 for the stem's row-per-K-step form)
     int K = 0, Kpad = 0, Npad = 0;
     int p_w = -1;            // parameter index of the OIHW weight
     int p_bn = -1;           // first of (weight, bias, running_mean, running_var) or -1
@@ -141,10 +142,11 @@ struct fpc_net {
     int add_param(const std::string& n, int64_t numel) { pnames.push_back(n); pnumel.push_back(numel); return (int)pnames.size() - 1; }
 
     int add_conv(const std::string& wname, int Cin, int Cout, int k, int stride, int pad, const char* bn_prefix,
-                 const char* bias_name, int Cinp = 0) {
+                 const char* bias_name, int Cinp = 0, int Kwp = 0) {
         PackedConv c;
         c.Cin = Cin; c.Cinp = Cinp ? Cinp : Cin; c.Cout = Cout; c.Kh = c.Kw = k; c.stride = stride; c.pad = pad;
-        c.K = c.Cinp * k * k; c.Kpad = cdiv(c.K, kConvBK) * kConvBK; c.Npad = cdiv(Cout, kConvNAlign) * kConvNAlign;
+        c.Kwp = Kwp ? Kwp : k;
+        c.K = c.Cinp * k * c.Kwp; c.Kpad = cdiv(c.K, kConvBK) * kConvBK; c.Npad = cdiv(Cout, kConvNAlign) * kConvNAlign;
         c.p_w = add_param(wname, (int64_t)Cout * Cin * k * k);
         if (bn_prefix) {
             std::string p(bn_prefix);
@@ -178,7 +180,7 @@ extern "C" int fpc_net_create(const char* encoder, int classes, int B, int H, in
     char buf[256];
 
     // ---- parameters + packed storage (persistent region first)
-    n->c_stem = n->add_conv("encoder.conv1.weight", 3, 64, 7, 2, 3, "encoder.bn1", nullptr, 4);
+    n->c_stem = n->add_conv("encoder.conv1.weight", 3, 64, 7, 2, 3, "encoder.bn1", nullptr, 4, 8);     // NHWC4 pixels, 8 taps per row
     const int planes[4] = {64, 128, 256, 512};
     int inpl = 64;
     for (int L = 0; L < 4; ++L)
@@ -334,7 +336,7 @@ extern "C" int fpc_net_load_params(fpc_net_t* n, const float* const* params, int
     n->pptr.assign(params, params + count);
     if (hipMemsetAsync(n->ws + n->zeros_off, 0, 64 * sizeof(float), s) != hipSuccess) return FPC_ELAUNCH;
     for (const PackedConv& c : n->convs) {
-        int rc = launch_pack_weight(n->pptr[c.p_w], n->ws + c.w_off, c.Cout, c.Cin, c.Cinp, c.Kh, c.Kw, c.Npad, c.Kpad, s);
+        int rc = launch_pack_weight(n->pptr[c.p_w], n->ws + c.w_off, c.Cout, c.Cin, c.Cinp, c.Kh, c.Kw, c.Kwp, c.Npad, c.Kpad, s);
         if (rc) return rc;
         if (c.wino_ok) {
             rc = launch_wino_pack(n->pptr[c.p_w], n->ws + c.wino_off, c.Cout, c.Cin, s);
@@ -468,9 +470,13 @@ static int forward_middle(fpc_net* n, hipStream_t s) {
     };
     {
         const PackedConv& c = n->convs[n->c_stem];
+        // The 7x7/2 stem as a 7x1 convolution over "pixels" of 8 x 4 channels: one K-step = one kernel row = the 8
+        // consecutive 16-byte pixels starting at wi0, which are 128 contiguous bytes of the NHWC4 image — the fast
+        // loader's case (scalar tap walk, two vector instructions per row and step) instead of the per-lane tap
+        // decode of MODE 2 (3500 cycles per K-step of 16 MFMAs, measured).  The eighth tap has zero weights.
         fill_conv_args(n, a, c, n->cplan[n->c_stem], H, W, n->a_stem.H, n->a_stem.W, (long long)4 * H * W, (long long)4 * W, 4,
-                       1, true, 2);
-        a.Cin = c.Cinp;
+                       1, true, 0);
+        a.Cin = 8 * c.Cinp; a.Kw = 1; a.K = c.K; a.lanepx = 1;
         a.p[0] = ConvPtrs{ws + n->a_img4.off, ws + c.w_off, ws + n->a_stem.off, ws + c.scale_off, ws + c.shift_off, nullptr, nullptr, nullptr};
         FPC_TRY(run_conv(n, a, 1, n->c_stem, s));
     }
@@ -720,7 +726,7 @@ extern "C" int fpc_conv2d(const float* in, int64_t sb, int64_t sh, int64_t sw, i
     c.K = Cin * Kh * Kw; c.Kpad = cdiv(c.K, kConvBK) * kConvBK; c.Npad = cdiv(Cout, kConvNAlign) * kConvNAlign;
     hipStream_t s = (hipStream_t)stream;
     float* packed = (float*)ws;
-    FPC_TRY(launch_pack_weight(w_oihw, packed, Cout, Cin, Cin, Kh, Kw, c.Npad, c.Kpad, s));
+    FPC_TRY(launch_pack_weight(w_oihw, packed, Cout, Cin, Cin, Kh, Kw, Kw, c.Npad, c.Kpad, s));
     bool wino = nsplit <= -1 && nsplit >= -4;      // -1: 4 waves, -2: 8 waves, -3: 4 waves wave-private, -4: 8 waves all-DMA 3-stage
     ConvPlan p = plan_conv(Ho * Wo, B, Cout, c.Kpad / kConvBK, 1, wino ? 0 : bm, bn, wino ? 1 : nsplit);
     int mode = (sc == 1 && Cin % kConvBK == 0 && Kh * Kw <= 32 && ((int64_t)Hi + 2 * pad) * sh * 4 < ((int64_t)1 << 31)) ? 0

@@ -181,7 +181,8 @@ __global__ __launch_bounds__(256, (BM * BN >= 128 * 128) ? 1 : 2) void k_conv_ig
         if (MODE == 0) {
             avo[i] = (unsigned)((ho * stride * ish + wo * stride * isw + 4 * sq) * 4);
             unsigned vw = 0, m = 0;                        // valid columns (bit kw), valid taps (bit kh*Kw + kw)
-            for (int kw = 0; kw < Kw; ++kw) vw |= (unsigned)(a_wi0[i] + kw >= 0 && a_wi0[i] + kw < Wi) << kw;
+            const int lpx = a.lanepx ? sq : 0;             // lane-pixel layout: this lane's 16 bytes are pixel wi0 + sq
+            for (int kw = 0; kw < Kw; ++kw) vw |= (unsigned)(a_wi0[i] + kw + lpx >= 0 && a_wi0[i] + kw + lpx < Wi) << kw;
             for (int kh = 0; kh < a.Kh; ++kh)
                 if (ok && a_hi0[i] + kh >= 0 && a_hi0[i] + kh < Hi) m |= vw << (kh * Kw);
             anm[i] = ~m;
@@ -891,19 +892,20 @@ __global__ __launch_bounds__(256) void k_up4_compress7(const Up4Args a) {
 // ------------------------------------------------------------------------------------------
 // parameter repacking (once per plan)
 
-// OIHW [Cout][Cin][Kh][Kw] -> OHWI rows [Npad][Kpad], k = (kh*Kw + kw)*Cinp + ci (Cinp >= Cin: channel
-// padding of the input layout, e.g. 4 for the RGB stem), zero padded
+// OIHW [Cout][Cin][Kh][Kw] -> OHWI rows [Npad][Kpad], k = (kh*Kwp + kw)*Cinp + ci, zero padded.  Cinp >= Cin: channel
+// padding of the input layout (4 for the RGB stem); Kwp >= Kw: taps per kernel row in the layout (8 for the stem,
+// whose K-step is one kernel row = 8 consecutive 4-channel pixels)
 __global__ __launch_bounds__(256) void k_pack_weight(const float* __restrict__ w, float* __restrict__ out, int Cout,
-                                                     int Cin, int Cinp, int Kh, int Kw, int Npad, int Kpad) {
+                                                     int Cin, int Cinp, int Kh, int Kw, int Kwp, int Npad, int Kpad) {
     long long total = (long long)Npad * Kpad;
-    int K = Cinp * Kh * Kw;
+    int K = Cinp * Kh * Kwp;
     for (long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (long long)gridDim.x * blockDim.x) {
         int k = (int)(g % Kpad), n = (int)(g / Kpad);
         float v = 0.f;
         if (n < Cout && k < K) {
             int tap = k / Cinp, ci = k - tap * Cinp;
-            int kh = tap / Kw, kw = tap - kh * Kw;
-            if (ci < Cin) v = w[(((size_t)n * Cin + ci) * Kh + kh) * Kw + kw];
+            int kh = tap / Kwp, kw = tap - kh * Kwp;
+            if (ci < Cin && kw < Kw) v = w[(((size_t)n * Cin + ci) * Kh + kh) * Kw + kw];
         }
         out[g] = v;
     }
@@ -1615,10 +1617,11 @@ int launch_wino_pack(const float* w_oihw, float* packed, int Cout, int Cin, hipS
     return check_launch();
 }
 
-int launch_pack_weight(const float* w, float* packed, int Cout, int Cin, int Cinp, int Kh, int Kw, int Npad, int Kpad,
-                       hipStream_t s) {
+int launch_pack_weight(const float* w, float* packed, int Cout, int Cin, int Cinp, int Kh, int Kw, int Kwp, int Npad,
+                       int Kpad, hipStream_t s) {
+    if (Kwp < Kw || Cinp < Cin) return FPC_EINVAL;
     hipLaunchKernelGGL(k_pack_weight, dim3(stream_grid((long long)Npad * Kpad)), dim3(256), 0, s, w, packed, Cout, Cin,
-                       Cinp, Kh, Kw, Npad, Kpad);
+                       Cinp, Kh, Kw, Kwp, Npad, Kpad);
     return check_launch();
 }
 

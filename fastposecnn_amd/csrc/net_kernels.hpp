@@ -26,6 +26,8 @@ struct ConvArgs {
     int B, Hi, Wi, Cin, Ho, Wo, Cout, Npad, Kh, Kw, stride, pad, K, Kpad;
     long long in_sb, in_sh, in_sw, in_sc;   // element strides of the input
     int relu, nsplit, mtiles, ntiles, ksteps, bm, bn, generic, groups;
+    int lanepx;           // MODE 0 only: 1 = a K-step is 8 consecutive pixels of `Cin / 8` channels (one kernel ROW of the
+                          // stem: Kw = 1, Cin = 32 virtual channels); horizontal padding is then per lane
     const float* wino_w[kMaxGroup];   // host side only: Winograd-packed weights per group (or null)
     const float* zeros;               // host side only: 64 zero floats for the all-DMA Winograd form (or null)
     void* dbg;                        // host side only: diagnostic stamp buffer for k_conv_wino (or null)
@@ -88,7 +90,7 @@ int launch_gn_finalize(const GnFinArgs& a, int groups, hipStream_t s);
 int launch_gn_relu_up2(const GnUpArgs& a, int groups, hipStream_t s);
 int launch_merge_head(const MergeHeadArgs& a, int groups, hipStream_t s);
 int launch_up4_compress(const Up4Args& a, hipStream_t s);
-int launch_pack_weight(const float* w_oihw, float* packed, int Cout, int Cin, int Cinp, int Kh, int Kw, int Npad,
+int launch_pack_weight(const float* w_oihw, float* packed, int Cout, int Cin, int Cinp, int Kh, int Kw, int Kwp, int Npad,
                        int Kpad, hipStream_t s);
 int launch_nchw3_to_nhwc4(const float* x, float* out, int B, int HW, hipStream_t s);
 int launch_fold_bn(const float* gamma, const float* beta, const float* mean, const float* var, float eps, int C,
