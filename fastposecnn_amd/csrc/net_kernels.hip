@@ -46,7 +46,12 @@ __device__ __forceinline__ f32x4 sub_pk(f32x4 a, f32x4 b) {
     return __builtin_shufflevector(rl, rh, 0, 1, 2, 3);
 }
 
-constexpr int kLdsRow = kConvBK + 4;   // 36 floats: 16 distinct 16-byte slots for 16 consecutive rows
+// LDS operand rows are 32 floats (128 B) with NO padding: the 16-byte chunk c of row r lives in slot c ^ (r & 7), which
+// keeps both the staging writes and the fragment reads conflict-free (8 consecutive rows hit 8 distinct slots of
+// each half of the 64-bank window).  32 KB for the 64x64 tiling, 48 KB for 64x128 / 128x64 (36-float padded rows:
+// 36.9 / 55.3 KB), i.e. room for 3 instead of 2 of the latter per CU.  (A fifth 64x64 workgroup per CU — registers
+// squeezed to 96 — did not shorten the 1200-workgroup launches: their workgroups share the matrix pipe.)
+constexpr int kLdsRow = kConvBK;
 
 
 // ------------------------------------------------------------------------------------------
@@ -118,9 +123,9 @@ constexpr int kLdsRow = kConvBK + 4;   // 36 floats: 16 distinct 16-byte slots f
         float* As_ = lds + (BUF) * (BM + BN) * kLdsRow;                                                       \
         float* Bs_ = As_ + BM * kLdsRow;                                                                      \
         _Pragma("unroll") for (int i = 0; i < AR; ++i)                                                        \
-            *reinterpret_cast<f32x4*>(As_ + (sr + 32 * i) * kLdsRow + 4 * sq) = ra[i];                       \
+            *reinterpret_cast<f32x4*>(As_ + (sr + 32 * i) * kLdsRow + swz_w) = ra[i];                        \
         _Pragma("unroll") for (int i = 0; i < BR; ++i)                                                        \
-            *reinterpret_cast<f32x4*>(Bs_ + (sr + 32 * i) * kLdsRow + 4 * sq) = rb[i];                       \
+            *reinterpret_cast<f32x4*>(Bs_ + (sr + 32 * i) * kLdsRow + swz_w) = rb[i];                        \
     } while (0)
 
 // (the 128x128 tiling keeps 64 accumulator + 64 staging registers per lane: one workgroup per CU, no spills)
@@ -166,6 +171,10 @@ __global__ __launch_bounds__(256, (BM * BN >= 128 * 128) ? 1 : 2) void k_conv_ig
     }
 
     const int sr = t >> 3, sq = t & 7;
+    // swizzled 16-byte slot (in floats) of this thread's staging writes, and of its fragment reads per k-group:
+    // lanes 0-31 carry k = kk*8 + e (chunk 2kk), lanes 32-63 k = kk*8 + 4 + e (chunk 2kk + 1); rows sr + 32i / li + 32i
+    const int swz_w = 4 * (sq ^ (sr & 7));
+    const int swz_r[4] = {4 * ((0 + lh) ^ (li & 7)), 4 * ((2 + lh) ^ (li & 7)), 4 * ((4 + lh) ^ (li & 7)), 4 * ((6 + lh) ^ (li & 7))};
     long long a_off[AR];     // MODE 1, 2: element offset of (b, hi0, wi0, 0)
     int a_hi0[AR], a_wi0[AR];
     unsigned avo[AR], anm[AR];   // MODE 0: byte offset of (ho*stride, wo*stride, 4*sq) from the shifted base; padding mask
@@ -221,9 +230,9 @@ __global__ __launch_bounds__(256, (BM * BN >= 128 * 128) ? 1 : 2) void k_conv_ig
 #define FPC_CONV_FRAG(KK, FA, FB)                                                                             \
     do {                                                                                                      \
         _Pragma("unroll") for (int i = 0; i < TM; ++i) FA[i] =                                                \
-            *reinterpret_cast<const f32x4*>(As + i * 32 * kLdsRow + (KK) * 8);                                \
+            *reinterpret_cast<const f32x4*>(As + i * 32 * kLdsRow + swz_r[KK]);                               \
         _Pragma("unroll") for (int j = 0; j < TN; ++j) FB[j] =                                                \
-            *reinterpret_cast<const f32x4*>(Bs + j * 32 * kLdsRow + (KK) * 8);                                \
+            *reinterpret_cast<const f32x4*>(Bs + j * 32 * kLdsRow + swz_r[KK]);                               \
     } while (0)
     /* lanes 0-31 carry k = kk*8 + e, lanes 32-63 carry k = kk*8 + 4 + e: each MFMA sums two k */
 #define FPC_CONV_MFMA(FA, FB)                                                                                 \
@@ -235,9 +244,8 @@ __global__ __launch_bounds__(256, (BM * BN >= 128 * 128) ? 1 : 2) void k_conv_ig
     } while (0)
 #define FPC_CONV_COMPUTE(BUF)                                                                                  \
     do {                                                                                                      \
-        const float* As = lds + (BUF) * (BM + BN) * kLdsRow + (wm * (BM / 2) + li) * kLdsRow + 4 * lh;        \
-        const float* Bs = lds + (BUF) * (BM + BN) * kLdsRow + BM * kLdsRow + (wn * (BN / 2) + li) * kLdsRow + \
-                          4 * lh;                                                                             \
+        const float* As = lds + (BUF) * (BM + BN) * kLdsRow + (wm * (BM / 2) + li) * kLdsRow;                 \
+        const float* Bs = lds + (BUF) * (BM + BN) * kLdsRow + BM * kLdsRow + (wn * (BN / 2) + li) * kLdsRow;  \
         f32x4 fa0[TM], fb0[TN], fa1[TM], fb1[TN];                                                             \
         FPC_CONV_FRAG(0, fa0, fb0);                                                                           \
         FPC_CONV_FRAG(1, fa1, fb1);                                                                           \
