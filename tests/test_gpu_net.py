@@ -279,6 +279,9 @@ def test_frame_streamer_matches_forward(lib, dev, kw):
             torch.manual_seed(100 + i)
             ref.append((logits, cat, m.agg_hough_and_generate_RT(cats[i])))
     st = FrameStreamer(m, **kw)
+    torch.manual_seed(99)
+    st.prepare(xs[0], categorical_override=cats[0])        # builds every stream's plan up front (bench.py's set-up)
+    assert len(st._warm) == len(st.models)
     tickets = []
     for i in range(5):
         torch.manual_seed(100 + i)                     # the vote's sampler seed is drawn at submit time
