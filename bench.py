@@ -120,6 +120,7 @@ def main():
     hp.HV_NUM_OF_HYPOTHESES = args.hn
     hp.ENCODER = args.encoder
     hp.ENGINE_TUNE_MODE = args.tune_mode
+    hp.ENGINE_SPLIT_PRECISION = bool(int(os.environ.get('FPC_SPLIT_PRECISION', '0')))      # opt-in experiment
     hp.ENGINE_GRAPH = bool(int(os.environ.get('FPC_ENGINE_GRAPH', '1')))      # HIP graph replay of the frame-invariant launches
     torch.manual_seed(0)
     model = L.pose_regressor.MODELS[hp.MODEL].load_from_ckpt(None, hp).eval()

@@ -43,6 +43,7 @@ _SIGNATURES = {
     "fpc_net_create": (_i, [ctypes.c_char_p, _i, _i, _i, _i, ctypes.POINTER(_vp)]),
     "fpc_net_destroy": (None, [_vp]),
     "fpc_net_set_graph": (_i, [_vp, _i]),
+    "fpc_net_set_split_precision": (_i, [_vp, _i]),
     "fpc_net_param_count": (_i, [_vp]),
     "fpc_net_param_name": (ctypes.c_char_p, [_vp, _i]),
     "fpc_net_param_numel": (_i64, [_vp, _i]),

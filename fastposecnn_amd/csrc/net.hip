@@ -36,7 +36,7 @@ struct PackedConv {
 
 struct Act { size_t off = 0; int H = 0, W = 0, C = 0; };
 
-struct ConvPlan { int bm = 64, bn = 64, nsplit = 1, mtiles = 1, ntiles = 1, wino = 0; };
+struct ConvPlan { int bm = 64, bn = 64, nsplit = 1, mtiles = 1, ntiles = 1, wino = 0, bf3 = 0; };
 
 static ConvPlan plan_conv(int HoWo, int B, int Cout, int ksteps, int groups, int force_bm = 0, int force_bn = 0,
                           int force_split = 0) {
@@ -130,6 +130,7 @@ struct fpc_net {
     Act a_low[4];                 // low-res logits
     size_t splitk_off = 0, splitk_floats = 0;
     int use_graph = 0;            // replay the frame-invariant launches as a HIP graph (fpc_net_set_graph)
+    int split_precision = 0;      // autotuning may pick the bf16 x 3 form of a direct convolution (fpc_net_set_split_precision)
     hipGraphExec_t graph_exec = nullptr;
     size_t zeros_off = 0;         // 64 zero floats (DMA source for out-of-image positions)
 
@@ -309,6 +310,15 @@ extern "C" void fpc_net_destroy(fpc_net_t* n) {
 // 1: after autotuning, the ~57 launches of a frame that only touch the plan's workspace are captured once and
 // replayed with one hipGraphLaunch per frame (the first and the last kernel take the caller's tensors and stay
 // ordinary launches).  Changing the tilings (fpc_net_autotune_next) or the parameters drops the recorded graph.
+// 1: the next autotuning pass also times the split-precision (bf16 x 3, f32 accumulation) form of every direct
+// fast-path convolution and keeps it where it is faster.  Opt-in: the results then differ from the f32 product chain
+// by rounding (about 2^-24 relative per product, like a different f32 summation order), not bit for bit.
+extern "C" int fpc_net_set_split_precision(fpc_net_t* n, int on) {
+    if (!n) return FPC_EINVAL;
+    n->split_precision = on ? 1 : 0;
+    return FPC_OK;
+}
+
 extern "C" int fpc_net_set_graph(fpc_net_t* n, int on) {
     if (!n) return FPC_EINVAL;
     n->use_graph = on ? 1 : 0;
@@ -392,6 +402,7 @@ int launch_conv_plan(ConvArgs& a, const ConvPlan& p, int groups, hipStream_t s) 
         return launch_conv_wino(w, groups, s);
     }
     a.bm = p.bm; a.bn = p.bn; a.nsplit = p.nsplit; a.mtiles = p.mtiles; a.ntiles = p.ntiles; a.groups = groups;
+    a.bf3 = (p.bf3 && a.generic == 0) ? 1 : 0;
     int rc = launch_conv(a, groups, s);
     if (rc) return rc;
     if (a.nsplit > 1) rc = launch_conv_splitk_epilogue(a, groups, s);
@@ -413,6 +424,10 @@ int run_conv(fpc_net* n, ConvArgs& a, int groups, int ci, hipStream_t s) {
         ConvPlan best = n->cplan[ci];
         size_t cap = n->splitk_floats;
         std::vector<ConvPlan> cands = conv_candidates(a.Ho * a.Wo, a.B, a.Cout, a.ksteps, groups);
+        if (n->split_precision && a.generic == 0) {          // the same tilings with split-precision matrix products
+            size_t nc = cands.size();
+            for (size_t i = 0; i < nc; ++i) { ConvPlan q = cands[i]; q.bf3 = 1; cands.push_back(q); }
+        }
         if (a.wino_w[0] && !a.p[0].up) {
             ConvPlan wq;
             wq.wino = 1; cands.push_back(wq);
@@ -450,7 +465,7 @@ int run_conv(fpc_net* n, ConvArgs& a, int groups, int ci, hipStream_t s) {
         (void)hipEventDestroy(e1);
         n->cplan[ci] = best;
     }
-    ConvPlan p = n ? n->cplan[ci] : ConvPlan{a.bm, a.bn, a.nsplit, a.mtiles, a.ntiles, 0};
+    ConvPlan p = n ? n->cplan[ci] : ConvPlan{a.bm, a.bn, a.nsplit, a.mtiles, a.ntiles, 0, a.bf3};
     return launch_conv_plan(a, p, groups, s);
 }
 
@@ -707,6 +722,7 @@ extern "C" int fpc_conv2d_plan(int B, int Ho, int Wo, int Cin, int Cout, int Kh,
                                int* out4) {
     if (!out4) return FPC_EINVAL;
     int Kpad = cdiv(Cin * Kh * Kw, kConvBK) * kConvBK;
+    if (nsplit >= 1000) nsplit -= 1000;      // fpc_conv2d's split-precision hook does not change the tiling
     ConvPlan p = plan_conv(Ho * Wo, B, Cout, Kpad / kConvBK, 1, bm, bn, nsplit);
     if (nsplit <= -1 && nsplit >= -4) { p.wino = -nsplit; p.nsplit = nsplit; }
     out4[0] = p.bm; out4[1] = p.bn; out4[2] = p.nsplit; out4[3] = plan_gn_rows(p, Ho, Wo);
@@ -727,8 +743,11 @@ extern "C" int fpc_conv2d(const float* in, int64_t sb, int64_t sh, int64_t sw, i
     hipStream_t s = (hipStream_t)stream;
     float* packed = (float*)ws;
     FPC_TRY(launch_pack_weight(w_oihw, packed, Cout, Cin, Cin, Kh, Kw, Kw, c.Npad, c.Kpad, s));
+    int bf3 = 0;
+    if (nsplit >= 1000) { bf3 = 1; nsplit -= 1000; }      // test hook: 1000 + split = split-precision matrix products
     bool wino = nsplit <= -1 && nsplit >= -4;      // -1: 4 waves, -2: 8 waves, -3: 4 waves wave-private, -4: 8 waves all-DMA 3-stage
     ConvPlan p = plan_conv(Ho * Wo, B, Cout, c.Kpad / kConvBK, 1, wino ? 0 : bm, bn, wino ? 1 : nsplit);
+    p.bf3 = bf3;
     int mode = (sc == 1 && Cin % kConvBK == 0 && Kh * Kw <= 32 && ((int64_t)Hi + 2 * pad) * sh * 4 < ((int64_t)1 << 31)) ? 0
                : (sc == 1 && Cin % 4 == 0 && sw % 4 == 0 && sh % 4 == 0 && sb % 4 == 0 && ((uintptr_t)in & 15) == 0) ? 2 : 1;
     fpc_net tmp;
@@ -756,5 +775,7 @@ extern "C" int fpc_conv2d(const float* in, int64_t sb, int64_t sh, int64_t sw, i
         p.wino = -nsplit;
         return launch_conv_plan(a, p, 1, s);
     }
+    a.bf3 = (p.bf3 && mode == 0) ? 1 : 0;
+    if (p.bf3 && mode != 0) return FPC_EINVAL;
     return run_conv(nullptr, a, 1, 0, s);
 }

@@ -25,6 +25,31 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));   // native vector: stays in registers (HIP's float4 struct copies can land in scratch)
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+// Split-precision operands (opt-in, ConvArgs::bf3): x = p1 + p2 + p3 exactly, each part 8 significant bits (bf16 by
+// truncation), four values -> three packed 8-byte groups.  The six products p_i q_j with i + j <= 4 on
+// v_mfma_f32_32x32x16_bf16 (f32 accumulation) reproduce the f32 product chain to ~2^-24 relative
+// (tools_dev/split_precision_check.py) at 2.2x the f32 matrix rate (tools_dev/bf16x3_probe.hip).
+__device__ __forceinline__ unsigned pack_hi16(float lo, float hi) {        // {bf16(lo), bf16(hi)}: the two high halves
+    return __builtin_amdgcn_perm(__builtin_bit_cast(unsigned, hi), __builtin_bit_cast(unsigned, lo), 0x07060302u);
+}
+__device__ __forceinline__ void split_bf3(f32x4 v, u32x2& p1, u32x2& p2, u32x2& p3) {
+    float r[4], q[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const float x = v[e];                     // (bit_cast of a vector ELEMENT expression misbehaved: go through a scalar)
+        const unsigned xb = __builtin_bit_cast(unsigned, x) & 0xFFFF0000u;
+        r[e] = x - __builtin_bit_cast(float, xb);
+        const float y = r[e];
+        const unsigned yb = __builtin_bit_cast(unsigned, y) & 0xFFFF0000u;
+        q[e] = y - __builtin_bit_cast(float, yb);
+    }
+    p1 = u32x2{pack_hi16(v[0], v[1]), pack_hi16(v[2], v[3])};
+    p2 = u32x2{pack_hi16(r[0], r[1]), pack_hi16(r[2], r[3])};
+    p3 = u32x2{pack_hi16(q[0], q[1]), pack_hi16(q[2], q[3])};
+}
 
 // raw buffer descriptor over [base, base + 2 GB): offsets are 32-bit, an offset >= 2^31 reads zeros without
 // touching memory (measured, tools_dev/dma_vs_mfma.hip) — the zero fill of the convolution padding
@@ -128,12 +153,31 @@ constexpr int kLdsRow = kConvBK;
             *reinterpret_cast<f32x4*>(Bs_ + (sr + 32 * i) * kLdsRow + swz_w) = rb[i];                        \
     } while (0)
 
+// Split-precision staging: the f32 registers of one K-step -> three bf16 planes per operand in LDS.  Plane rows are
+// 32 bf16 = 64 bytes = four 16-byte chunks (one MFMA operand each); chunk c of row r sits in slot c ^ ((r >> 2) & 1)
+// so that the eight rows a ds_read_b128 group touches hit eight different 16-byte positions of the bank window.
+#define FPC_CONV_STORE_BF3(BUF, ra, rb)                                                                       \
+    do {                                                                                                      \
+        char* st_ = reinterpret_cast<char*>(lds) + (BUF) * (BM + BN) * 192;                                   \
+        _Pragma("unroll") for (int i = 0; i < AR + BR; ++i) {                                                 \
+            const int row_ = (i < AR ? 0 : BM) + sr + 32 * (i < AR ? i : i - AR);                             \
+            u32x2 p1_, p2_, p3_;                                                                              \
+            split_bf3(i < AR ? ra[i < AR ? i : 0] : rb[i < AR ? 0 : i - AR], p1_, p2_, p3_);                  \
+            char* d_ = st_ + row_ * 64 + bf3_w;                                                               \
+            *reinterpret_cast<u32x2*>(d_) = p1_;                                                              \
+            *reinterpret_cast<u32x2*>(d_ + (BM + BN) * 64) = p2_;                                             \
+            *reinterpret_cast<u32x2*>(d_ + 2 * (BM + BN) * 64) = p3_;                                         \
+        }                                                                                                     \
+    } while (0)
+
 // (the 128x128 tiling keeps 64 accumulator + 64 staging registers per lane: one workgroup per CU, no spills)
-template <int BM, int BN, int MODE>
+template <int BM, int BN, int MODE, bool BF3 = false>
 __global__ __launch_bounds__(256, (BM * BN >= 128 * 128) ? 1 : 2) void k_conv_igemm(const ConvArgs a) {
     constexpr int TM = BM / 64, TN = BN / 64;     // 32x32 tiles per wave
     constexpr int AR = BM / 32, BR = BN / 32;     // float4 rows staged per thread
-    __shared__ __attribute__((aligned(16))) float lds[2 * (BM + BN) * kLdsRow];
+    // f32 operands: 2 stages x (BM + BN) rows x 128 B;  split precision: 2 stages x 3 planes x (BM + BN) rows x 64 B
+    __shared__ __attribute__((aligned(16))) float lds[BF3 ? 2 * (BM + BN) * 48 : 2 * (BM + BN) * kLdsRow];
+    static_assert(!BF3 || MODE == 0, "split precision rides on the fast loader");
 #ifdef FPC_STAMP_IGEMM      // diagnostic build (tools_dev/igemm_stamps.py): phase stamps per wave into a.dbg
     const long long st0 = clock64();
 #endif
@@ -174,6 +218,10 @@ __global__ __launch_bounds__(256, (BM * BN >= 128 * 128) ? 1 : 2) void k_conv_ig
     // swizzled 16-byte slot (in floats) of this thread's staging writes, and of its fragment reads per k-group:
     // lanes 0-31 carry k = kk*8 + e (chunk 2kk), lanes 32-63 k = kk*8 + 4 + e (chunk 2kk + 1); rows sr + 32i / li + 32i
     const int swz_w = 4 * (sq ^ (sr & 7));
+    // split precision: byte offset inside a 64-byte plane row of this thread's four k (write) and of this lane's
+    // eight k per 16-deep MFMA (read): chunk = k / 8, slot = chunk ^ ((row >> 2) & 1); rows sr + 32i / li + 32i
+    const int bf3_w = (((sq >> 1) ^ ((sr >> 2) & 1)) << 4) + ((sq & 1) << 3);
+    const int bf3_r[2] = {((0 + lh) ^ ((li >> 2) & 1)) << 4, ((2 + lh) ^ ((li >> 2) & 1)) << 4};
     const int swz_r[4] = {4 * ((0 + lh) ^ (li & 7)), 4 * ((2 + lh) ^ (li & 7)), 4 * ((4 + lh) ^ (li & 7)), 4 * ((6 + lh) ^ (li & 7))};
     long long a_off[AR];     // MODE 1, 2: element offset of (b, hi0, wi0, 0)
     int a_hi0[AR], a_wi0[AR];
@@ -264,9 +312,47 @@ __global__ __launch_bounds__(256, (BM * BN >= 128 * 128) ? 1 : 2) void k_conv_ig
         __builtin_amdgcn_s_setprio(0);                                                                        \
     } while (0)
 
+    // split precision: per 16-deep k group three planes per operand, six MFMAs per 32x32 tile
+#define FPC_BF3_FRAG(KK, FA, FB)                                                                              \
+    do {                                                                                                      \
+        _Pragma("unroll") for (int p_ = 0; p_ < 3; ++p_) {                                                    \
+            _Pragma("unroll") for (int i = 0; i < TM; ++i) FA[p_][i] = __builtin_bit_cast(bf16x8,             \
+                *reinterpret_cast<const u32x4*>(Ab + p_ * (BM + BN) * 64 + i * 32 * 64 + bf3_r[KK]));         \
+            _Pragma("unroll") for (int j = 0; j < TN; ++j) FB[p_][j] = __builtin_bit_cast(bf16x8,             \
+                *reinterpret_cast<const u32x4*>(Bb + p_ * (BM + BN) * 64 + j * 32 * 64 + bf3_r[KK]));         \
+        }                                                                                                     \
+    } while (0)
+#define FPC_BF3_MFMA(FA, FB)                                                                                  \
+    do {                                                                                                      \
+        _Pragma("unroll") for (int i = 0; i < TM; ++i)                                                        \
+            _Pragma("unroll") for (int j = 0; j < TN; ++j) {                                                  \
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(FA[2][i], FB[0][j], acc[i][j], 0, 0, 0);  \
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(FA[0][i], FB[2][j], acc[i][j], 0, 0, 0);  \
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(FA[1][i], FB[1][j], acc[i][j], 0, 0, 0);  \
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(FA[1][i], FB[0][j], acc[i][j], 0, 0, 0);  \
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(FA[0][i], FB[1][j], acc[i][j], 0, 0, 0);  \
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(FA[0][i], FB[0][j], acc[i][j], 0, 0, 0);  \
+            }                                                                                                 \
+    } while (0)
+#define FPC_CONV_COMPUTE_BF3(BUF)                                                                             \
+    do {                                                                                                      \
+        const char* Ab = reinterpret_cast<const char*>(lds) + (BUF) * (BM + BN) * 192 + (wm * (BM / 2) + li) * 64;        \
+        const char* Bb = reinterpret_cast<const char*>(lds) + (BUF) * (BM + BN) * 192 + (BM + wn * (BN / 2) + li) * 64;   \
+        bf16x8 ga0[3][TM], gb0[3][TN], ga1[3][TM], gb1[3][TN];                                                \
+        FPC_BF3_FRAG(0, ga0, gb0);                                                                            \
+        FPC_BF3_FRAG(1, ga1, gb1);                                                                            \
+        __builtin_amdgcn_sched_barrier(0);                                                                    \
+        __builtin_amdgcn_s_setprio(1);                                                                        \
+        FPC_BF3_MFMA(ga0, gb0);                                                                               \
+        FPC_BF3_MFMA(ga1, gb1);                                                                               \
+        __builtin_amdgcn_s_setprio(0);                                                                        \
+    } while (0)
+#define FPC_STORE_ANY(BUF, ra, rb) do { if (BF3) FPC_CONV_STORE_BF3(BUF, ra, rb); else FPC_CONV_STORE(BUF, ra, rb); } while (0)
+#define FPC_COMPUTE_ANY(BUF) do { if (BF3) FPC_CONV_COMPUTE_BF3(BUF); else FPC_CONV_COMPUTE(BUF); } while (0)
+
     if (ks0 < ks1) {
         FPC_CONV_LOAD(ks0, ra0, rb0);
-        FPC_CONV_STORE(0, ra0, rb0);
+        FPC_STORE_ANY(0, ra0, rb0);
     }
     if (ks0 + 1 < ks1) FPC_CONV_LOAD(ks0 + 1, ra0, rb0);
     __syncthreads();
@@ -276,14 +362,14 @@ __global__ __launch_bounds__(256, (BM * BN >= 128 * 128) ? 1 : 2) void k_conv_ig
     for (int ks = ks0; ks < ks1; ks += 2) {
         // even phase: LDS buffer 0 holds step ks, set 0 holds ks+1
         if (ks + 2 < ks1) FPC_CONV_LOAD(ks + 2, ra1, rb1);
-        FPC_CONV_COMPUTE(0);
-        if (ks + 1 < ks1) FPC_CONV_STORE(1, ra0, rb0);
+        FPC_COMPUTE_ANY(0);
+        if (ks + 1 < ks1) FPC_STORE_ANY(1, ra0, rb0);
         __syncthreads();
         if (ks + 1 >= ks1) break;
         // odd phase: LDS buffer 1 holds step ks+1, set 1 holds ks+2
         if (ks + 3 < ks1) FPC_CONV_LOAD(ks + 3, ra0, rb0);
-        FPC_CONV_COMPUTE(1);
-        if (ks + 2 < ks1) FPC_CONV_STORE(0, ra1, rb1);
+        FPC_COMPUTE_ANY(1);
+        if (ks + 2 < ks1) FPC_STORE_ANY(0, ra1, rb1);
         __syncthreads();
     }
 
@@ -948,7 +1034,9 @@ __global__ void k_fold_bn(const float* __restrict__ gamma, const float* __restri
 template <int BM, int BN>
 static void launch_conv_t(const ConvArgs& a, int groups, hipStream_t s) {
     dim3 grid(a.mtiles * a.B * a.ntiles * a.nsplit * groups);
-    if (a.generic == 0)
+    if (a.generic == 0 && a.bf3)
+        hipLaunchKernelGGL((k_conv_igemm<BM, BN, 0, true>), grid, dim3(256), 0, s, a);
+    else if (a.generic == 0)
         hipLaunchKernelGGL((k_conv_igemm<BM, BN, 0>), grid, dim3(256), 0, s, a);
     else if (a.generic == 2)
         hipLaunchKernelGGL((k_conv_igemm<BM, BN, 2>), grid, dim3(256), 0, s, a);

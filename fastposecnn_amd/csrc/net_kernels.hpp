@@ -26,6 +26,7 @@ struct ConvArgs {
     int B, Hi, Wi, Cin, Ho, Wo, Cout, Npad, Kh, Kw, stride, pad, K, Kpad;
     long long in_sb, in_sh, in_sw, in_sc;   // element strides of the input
     int relu, nsplit, mtiles, ntiles, ksteps, bm, bn, generic, groups;
+    int bf3;              // MODE 0 only: split-precision matrix products (three bf16 planes per operand, six MFMAs per tile)
     int lanepx;           // MODE 0 only: 1 = a K-step is 8 consecutive pixels of `Cin / 8` channels (one kernel ROW of the
                           // stem: Kw = 1, Cin = 32 virtual channels); horizontal padding is then per lane
     const float* wino_w[kMaxGroup];   // host side only: Winograd-packed weights per group (or null)

@@ -14,7 +14,7 @@ from fastposecnn_amd import _native as nat
 
 class NetEngine:
 
-    def __init__(self, model, B, H, W, device, autotune=True, tune_mode=0, graph=False):
+    def __init__(self, model, B, H, W, device, autotune=True, tune_mode=0, graph=False, split_precision=False):
         L = nat.lib()
         self._lib = L
         self.B, self.H, self.W, self.device = B, H, W, device
@@ -44,6 +44,8 @@ class NetEngine:
             self._ws = torch.empty(nbytes, dtype=torch.uint8, device=device)
             assert self._ws.data_ptr() % 256 == 0
             nat.check(L.fpc_net_load_params(h, ptrs, n, self._ws.data_ptr(), nbytes, nat.stream()), "fpc_net_load_params")
+        if split_precision:
+            nat.check(L.fpc_net_set_split_precision(h, 1), "fpc_net_set_split_precision")
         if autotune:
             # one (discarded) forward that times every candidate tiling per convolution on this device
             nat.check(L.fpc_net_autotune_next(h, int(tune_mode)), "fpc_net_autotune_next")

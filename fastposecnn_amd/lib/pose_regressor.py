@@ -247,7 +247,8 @@ class PoseRegressor(Model, torch.nn.Module):
             eng = NetEngine(self, key[0], key[1], key[2], x.device,
                             autotune=getattr(self.HPARAM, 'ENGINE_AUTOTUNE', True),
                             tune_mode=int(getattr(self.HPARAM, 'ENGINE_TUNE_MODE', 0)),
-                            graph=bool(getattr(self.HPARAM, 'ENGINE_GRAPH', True)))
+                            graph=bool(getattr(self.HPARAM, 'ENGINE_GRAPH', True)),
+                            split_precision=bool(getattr(self.HPARAM, 'ENGINE_SPLIT_PRECISION', False)))
             self._engines[key] = eng
         return eng
 

@@ -51,3 +51,7 @@ class TimerDecorator:
 
     def clear(self):
         self.runtimes.clear()
+
+    def __deepcopy__(self, memo):
+        # a stage timer is shared by every model that uses the stage (and HIP events cannot be copied)
+        return self

@@ -106,6 +106,13 @@ CONV_CASES = [
     (1, 128, 34, 50, 128, 3, 1, 1, (0, 0, -4), "gn"),
     (1, 8, 7, 9, 64, 3, 1, 1, (0, 0, -4), "bias_relu"),       # a single K-step
     (1, 16, 20, 24, 64, 3, 1, 1, (0, 0, -4), "bias_relu"),    # two K-steps
+    # split-precision matrix products (nsplit = 1000 + split): bf16 x 3 planes, six MFMAs per tile, f32 accumulation
+    (1, 64, 30, 40, 64, 3, 1, 1, (64, 64, 1001), "bn_relu_res"),
+    (2, 256, 15, 20, 128, 3, 1, 1, (64, 64, 1004), "gn"),         # split-K + GroupNorm partials, ragged M
+    (1, 128, 16, 24, 128, 3, 1, 1, (128, 128, 1001), "gn"),
+    (1, 128, 16, 24, 128, 3, 1, 1, (64, 128, 1001), "gn"),
+    (2, 64, 24, 32, 256, 1, 1, 0, (64, 64, 1001), "bias_up"),     # FPN lateral
+    (1, 64, 24, 32, 128, 1, 2, 0, (128, 64, 1001), "bn"),         # 1x1 stride 2
     # 8-wave form (8x8 tile patch per workgroup, nsplit = -2)
     (1, 64, 30, 40, 64, 3, 1, 1, (0, 0, -2), "bn_relu_res"),
     (2, 256, 15, 20, 128, 3, 1, 1, (0, 0, -2), "gn"),
@@ -366,3 +373,25 @@ def test_graph_replay_is_bit_identical(lib, dev):
         lg = m.pure_model_forward(xs[0])
     torch.cuda.synchronize()
     assert torch.equal(lg["mask"], plain[0]["mask"])
+
+
+def test_engine_split_precision_meets_the_f32_bar(lib, dev):
+    """HPARAM.ENGINE_SPLIT_PRECISION (opt-in): autotuning may pick the bf16 x 3 form of the direct convolutions.
+    The whole network must stay within the same 1e-4 bar against the float64 CPU reference as the f32 engine."""
+    from fastposecnn_amd import synth
+    m, hp = _model(lib, dev, "resnet18")
+    hp.ENGINE_SPLIT_PRECISION = True
+    x = torch.stack([synth.make_image(i, 64, 96) for i in range(2)])
+    import copy
+    ref_m = copy.deepcopy(m).double()
+    ref_m.HPARAM = copy.copy(hp); ref_m.HPARAM.USE_NATIVE_ENGINE = False
+    with torch.no_grad():
+        ref = ref_m.pure_model_forward(x.double())
+    m = m.to(dev)
+    with torch.no_grad():
+        out = m(x.to(dev))
+    assert m._engines
+    for k in ("mask", "quaternion", "scales", "xy", "z"):
+        got = out["logits"][k].cpu().double()
+        err = (got - ref[k]).abs().max().item()
+        assert err <= 1e-4 * max(1.0, ref[k].abs().max().item()), (k, err)

@@ -23,7 +23,7 @@ SHAPES = {
     "l4": (1, 512, 15, 20, 512, 3, 1, 1),
     "p2lat x4": (4, 64, 120, 160, 256, 1, 1, 0),
 }
-CONFIGS = [(0, 0, -1), (0, 0, -3), (0, 0, -2), (0, 0, -4), (0, 0, 0), (64, 64, 1), (64, 128, 1), (128, 64, 1), (128, 128, 1), (64, 64, 2), (64, 64, 4), (64, 64, 8),
+CONFIGS = [(64, 64, 1001), (64, 128, 1001), (128, 128, 1001), (64, 64, 1004), (0, 0, -1), (0, 0, -3), (0, 0, -2), (0, 0, -4), (0, 0, 0), (64, 64, 1), (64, 128, 1), (128, 64, 1), (128, 128, 1), (64, 64, 2), (64, 64, 4), (64, 64, 8),
            (64, 128, 2), (64, 128, 4), (128, 128, 2)]
 
 for name, (B, Cin, Hi, Wi, Cout, k, stride, pad) in SHAPES.items():
@@ -43,7 +43,9 @@ for name, (B, Cin, Hi, Wi, Cout, k, stride, pad) in SHAPES.items():
             continue
         plan = (ctypes.c_int * 4)()
         L.fpc_conv2d_plan(B, Ho, Wo, Cin, Cout, k, k, bm, bn, ns, plan)
-        if ns > 0 and plan[2] != ns:
+        if 0 < ns < 1000 and plan[2] != ns:
+            continue
+        if ns >= 1000 and (Cin % 32 or plan[2] != ns - 1000):
             continue
         if ns < 0 and (k != 3 or Cin % 8 or Cout % 64):
             continue
