@@ -243,6 +243,22 @@ def main():
         with open(tpath) as f:
             traffic = json.load(f).get("traffic_bytes_per_launch")
 
+    # measured device-to-device copy ceiling on this GPU (read + write bytes), beside the 8 TB/s spec
+    copy_gbps = None
+    try:
+        src = torch.empty(256 << 20, dtype=torch.uint8, device=dev); dst = torch.empty_like(src)
+        for _ in range(2):
+            dst.copy_(src)
+        c0, c1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        c0.record()
+        for _ in range(10):
+            dst.copy_(src)
+        c1.record(); c1.synchronize()
+        copy_gbps = round(10 * 2 * src.numel() / (c0.elapsed_time(c1) * 1e-3) / 1e9, 1)
+        del src, dst
+    except Exception:
+        pass
+
     if rank == 0:
         line = {
             "metric": "img/s end-to-end 640x480 inference; hough-vote kernel HBM GB/s vs roofline",
@@ -258,7 +274,7 @@ def main():
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": traffic,
                          "kernel": "fpc_ransac_voting_v3 launch sequence (k_chunk_count .. k_count_hi .. k_refine)",
-                         "algorithmic_bytes_per_launch": alg_bytes, "launch_ms": round(vote_t * 1e3, 4),
+                         "algorithmic_bytes_per_launch": alg_bytes, "measured_copy_GBps": copy_gbps, "launch_ms": round(vote_t * 1e3, 4),
                          "note": "HIP events on the launch stream around the whole call; at hn=1000 the count "
                                  "kernel is VALU-bound (DESIGN.md); traffic from profiles/r01_vote_traffic.json (PMC)"},
         }
