@@ -29,7 +29,7 @@ _SIGNATURES = {
     "fpc_voting_for_hypothesis": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _f, _vp]),
     "fpc_ransac_workspace_bytes": (_sz, [_i, _i, _i, _i]),
     "fpc_ransac_voting_v3": (_i, [_vp, _vp, _i64, _i64, _i64, _i64, _i, _vp, _i, _i, _i, _vp, _vp, _u64, _f, _i, _i,
-                                  _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+                                  _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "fpc_class_compress": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     "fpc_cc_workspace_bytes": (_sz, [_i, _i, _i]),
     "fpc_cc_label": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _i, _vp, _sz, _vp]),
@@ -53,6 +53,7 @@ _SIGNATURES = {
     "fpc_net_autotune_next": (_i, [_vp, _i]),
     "fpc_net_conv_count": (_i, [_vp]),
     "fpc_net_conv_plan": (_i, [_vp, _i, ctypes.POINTER(_i)]),
+    "fpc_net_flops": (_i, [_vp, ctypes.POINTER(ctypes.c_double)]),
     "fpc_net_tensor": (_i, [_vp, ctypes.c_char_p, ctypes.POINTER(_vp), ctypes.POINTER(_i), ctypes.POINTER(_i),
                             ctypes.POINTER(_i)]),
     "fpc_conv2d_workspace_bytes": (_sz, [_i, _i, _i, _i, _i, _i, _i]),
@@ -77,7 +78,7 @@ def lib():
             fn = getattr(L, name)
             fn.restype = res
             fn.argtypes = args
-        if L.fpc_abi_version() != 3:
+        if L.fpc_abi_version() != 4:
             raise RuntimeError("fastposecnn_amd: libfpc_hip.so ABI version mismatch")
         _lib = L
     return _lib
@@ -87,7 +88,7 @@ def check(rc, what):
     if rc != 0:
         L = lib()
         msg = L.fpc_error_string(rc).decode()
-        hip = L.fpc_last_hip_error().decode()
+        hip = L.fpc_last_hip_error().decode() if rc == -3 else ""      # FPC_ELAUNCH: the HIP error of THIS call
         raise RuntimeError(f"fastposecnn_amd: {what} failed: {msg} (code {rc}){' — HIP: ' + hip if hip else ''}")
 
 

@@ -4,6 +4,7 @@ hipcc cross-compiles without a GPU; the .so is git-ignored but travels with the 
 snapshot.  -ffp-contract=off: every float op is separately rounded, matching the CPU oracle
 bit for bit on the integer-valued outputs (inlier counts, winners, class ids, labels).
 """
+import hashlib
 import os
 import subprocess
 import sys
@@ -30,8 +31,8 @@ def _deps_mtime():
     return max(os.path.getmtime(h) for h in hdrs)
 
 
-def _compile(src, dep_mtime, force, extra):
-    obj = os.path.join(OBJ, os.path.basename(src)[:-4] + ".o")
+def _compile(src, objdir, dep_mtime, force, extra):
+    obj = os.path.join(objdir, os.path.basename(src)[:-4] + ".o")
     if not force and os.path.exists(obj) and os.path.getmtime(obj) >= max(os.path.getmtime(src), dep_mtime):
         return obj
     subprocess.check_call([HIPCC, *FLAGS, *extra, "-c", src, "-o", obj])
@@ -39,15 +40,25 @@ def _compile(src, dep_mtime, force, extra):
 
 
 def build(force=False, verbose=False, extra=()):
-    os.makedirs(OBJ, exist_ok=True)
+    """Objects are cached per flag set (a diagnostic build with -DFPC_STAMP_* never shares objects with the product
+    build), and the library records the flag set it was linked from: a different one relinks."""
+    extra = list(extra)
+    tag = hashlib.sha256(" ".join([HIPCC, *FLAGS, *extra]).encode()).hexdigest()[:12]
+    objdir = os.path.join(OBJ, tag)
+    os.makedirs(objdir, exist_ok=True)
     srcs = sources()
     dep = _deps_mtime()
     with ThreadPoolExecutor(max_workers=min(6, len(srcs))) as ex:
-        objs = list(ex.map(lambda s: _compile(s, dep, force, list(extra)), srcs))
-    if force or not os.path.exists(LIB) or os.path.getmtime(LIB) < max(os.path.getmtime(o) for o in objs):
+        objs = list(ex.map(lambda s: _compile(s, objdir, dep, force, extra), srcs))
+    stamp = os.path.join(OBJ, "linked_from")
+    linked = open(stamp).read().strip() if os.path.exists(stamp) else ""
+    if (force or linked != tag or not os.path.exists(LIB)
+            or os.path.getmtime(LIB) < max(os.path.getmtime(o) for o in objs)):
         subprocess.check_call([HIPCC, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", LIB, *objs])
+        with open(stamp, "w") as f:
+            f.write(tag)
     if verbose:
-        print("built", LIB)
+        print("built", LIB, "(diagnostic flags: %s)" % " ".join(extra) if extra else "")
     return LIB
 
 

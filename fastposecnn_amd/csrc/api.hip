@@ -10,6 +10,7 @@ void set_hip_error(hipError_t e) {
     strncpy(g_last_hip_error, s ? s : "unknown", sizeof(g_last_hip_error) - 1);
     g_last_hip_error[sizeof(g_last_hip_error) - 1] = 0;
 }
+void clear_hip_error() { g_last_hip_error[0] = 0; }
 }  // namespace fpc
 
 extern "C" int fpc_abi_version(void) { return FPC_ABI_VERSION; }

@@ -11,6 +11,7 @@ namespace fpc {
 constexpr int kWave = 64;  // CDNA wavefront
 
 void set_hip_error(hipError_t e);
+void clear_hip_error();      // fpc_last_hip_error() describes the LAST failing call of this thread only
 
 inline int check_launch() {
     hipError_t e = hipGetLastError();
@@ -18,6 +19,7 @@ inline int check_launch() {
         set_hip_error(e);
         return FPC_ELAUNCH;
     }
+    clear_hip_error();
     return FPC_OK;
 }
 

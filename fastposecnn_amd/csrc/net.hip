@@ -136,6 +136,7 @@ struct fpc_net {
 
     // per-conv launch plans (index = conv id of decoder 0 for grouped ones)
     std::vector<ConvPlan> cplan;
+    std::vector<int> c_howo, c_groups;   // output pixels per image and launch multiplicity of every planned conv site (0: not a site)
 
     size_t bump = 0;
     size_t alloc(size_t n) { size_t o = bump; bump += (n + 63) / 64 * 64; return o; }
@@ -267,8 +268,11 @@ extern "C" int fpc_net_create(const char* encoder, int classes, int B, int H, in
 
     // ---- conv plans (+ split-K scratch for the worst candidate, GroupNorm partials for the largest P32)
     n->cplan.resize(n->convs.size());
+    n->c_howo.assign(n->convs.size(), 0);
+    n->c_groups.assign(n->convs.size(), 0);
     auto plan = [&](int ci, int HoWo, int groups) {
         const PackedConv& c = n->convs[ci];
+        n->c_howo[ci] = HoWo; n->c_groups[ci] = groups;
         n->cplan[ci] = plan_conv(HoWo, B, c.Cout, c.Kpad / kConvBK, groups);
         size_t need = splitk_floats_for(n->cplan[ci], groups, B, c.Npad);
         for (const ConvPlan& q : conv_candidates(HoWo, B, c.Cout, c.Kpad / kConvBK, groups)) {
@@ -685,6 +689,26 @@ extern "C" int fpc_net_conv_plan(const fpc_net_t* n, int i, int* out5) {
     if (!n || !out5 || i < 0 || i >= (int)n->convs.size()) return FPC_EINVAL;
     out5[0] = n->cplan[i].bm; out5[1] = n->cplan[i].bn; out5[2] = n->cplan[i].wino ? -n->cplan[i].wino : n->cplan[i].nsplit;
     out5[3] = n->convs[i].Cout; out5[4] = n->convs[i].K;
+    return FPC_OK;
+}
+
+// FLOP of one forward over the whole batch: out3[0] = 2 x MACs of the direct convolutions (the algorithmic count the
+// reference's cuDNN path would execute), out3[1] = multiply-adds the CURRENT plans execute (a Winograd F(2x2,3x3)
+// site does 16 instead of 36 per 2x2 output tile: direct / 2.25), out3[2] = share of out3[0] on Winograd sites.
+extern "C" int fpc_net_flops(const fpc_net_t* n, double* out3) {
+    if (!n || !out3) return FPC_EINVAL;
+    double direct = 0.0, executed = 0.0, wino = 0.0;
+    for (size_t i = 0; i < n->convs.size(); ++i) {
+        if (!n->c_groups[i]) continue;
+        const PackedConv& c = n->convs[i];
+        const double f = 2.0 * n->B * (double)n->c_howo[i] * c.Cout * c.Cin * c.Kh * c.Kw * n->c_groups[i];
+        direct += f;
+        if (n->cplan[i].wino) { executed += f / 2.25; wino += f; } else executed += f;
+    }
+    for (int d = 0; d < 4; ++d)      // the 1x1 heads run inside k_merge_head
+        direct += 2.0 * n->B * (double)n->a_low[d].H * n->a_low[d].W * 128.0 * n->dec[d].head_ch,
+        executed += 2.0 * n->B * (double)n->a_low[d].H * n->a_low[d].W * 128.0 * n->dec[d].head_ch;
+    out3[0] = direct; out3[1] = executed; out3[2] = direct > 0.0 ? wino / direct : 0.0;
     return FPC_OK;
 }
 

@@ -23,27 +23,13 @@ class NetEngine:
         enc = model.encoder.name.encode()
         nat.check(L.fpc_net_create(enc, self.classes, B, H, W, ctypes.byref(h)), "fpc_net_create")
         self._h = h
-        tensors = dict(model.named_parameters())
-        tensors.update(dict(model.named_buffers()))
-        n = L.fpc_net_param_count(h)
-        self._params = []           # keeps the tensors alive: the plan reads some of them in place
-        for i in range(n):
-            name = L.fpc_net_param_name(h, i).decode()
-            if name not in tensors:
-                raise RuntimeError(f"fastposecnn_amd: the model has no parameter {name!r} (smp naming expected)")
-            t = tensors[name].detach()
-            if t.device != device or t.dtype != torch.float32 or not t.is_contiguous():
-                raise RuntimeError(f"fastposecnn_amd: parameter {name!r} must be a contiguous f32 tensor on {device}")
-            if t.numel() != L.fpc_net_param_numel(h, i):
-                raise RuntimeError(f"fastposecnn_amd: parameter {name!r} has {t.numel()} elements, expected "
-                                   f"{L.fpc_net_param_numel(h, i)}")
-            self._params.append(t)
-        ptrs = (ctypes.c_void_p * n)(*[t.data_ptr() for t in self._params])
+        self._names = [L.fpc_net_param_name(h, i).decode() for i in range(L.fpc_net_param_count(h))]
         nbytes = L.fpc_net_workspace_bytes(h)
         with torch.cuda.device(device):
             self._ws = torch.empty(nbytes, dtype=torch.uint8, device=device)
             assert self._ws.data_ptr() % 256 == 0
-            nat.check(L.fpc_net_load_params(h, ptrs, n, self._ws.data_ptr(), nbytes, nat.stream()), "fpc_net_load_params")
+        self.reloads = 0
+        self.bind(model)
         if split_precision:
             nat.check(L.fpc_net_set_split_precision(h, 1), "fpc_net_set_split_precision")
         if autotune:
@@ -53,6 +39,43 @@ class NetEngine:
         if graph:
             nat.check(L.fpc_net_set_graph(h, 1), "fpc_net_set_graph")
 
+    def bind(self, model):
+        """(Re)pack the model's current parameters into the plan's workspace.  The tuned tilings are kept; a
+        recorded graph is dropped by the library and re-captured on the next forward."""
+        L, h, device = self._lib, self._h, self.device
+        tensors = dict(model.named_parameters())
+        tensors.update(dict(model.named_buffers()))
+        params = []                 # keeps the tensors alive: the plan reads some of them in place
+        for i, name in enumerate(self._names):
+            if name not in tensors:
+                raise RuntimeError(f"fastposecnn_amd: the model has no parameter {name!r} (smp naming expected)")
+            t = tensors[name]
+            if t.device != device or t.dtype != torch.float32 or not t.is_contiguous():
+                raise RuntimeError(f"fastposecnn_amd: parameter {name!r} must be a contiguous f32 tensor on {device}")
+            if t.numel() != L.fpc_net_param_numel(h, i):
+                raise RuntimeError(f"fastposecnn_amd: parameter {name!r} has {t.numel()} elements, expected "
+                                   f"{L.fpc_net_param_numel(h, i)}")
+            params.append(t)
+        self._params = params
+        n = len(params)
+        ptrs = (ctypes.c_void_p * n)(*[t.data_ptr() for t in params])
+        with torch.cuda.device(device):
+            nat.check(L.fpc_net_load_params(h, ptrs, n, self._ws.data_ptr(), self._ws.numel(), nat.stream()),
+                      "fpc_net_load_params")
+        self._stamp = self._fingerprint()
+        self.reloads += 1
+
+    def _fingerprint(self):
+        # (storage address, in-place version) of every bound tensor: changes on load_state_dict (of the model or of
+        # any sub-module), optimizer / EMA steps, p.copy_(), .to() — anything but a write through `p.data`, which
+        # PyTorch itself does not version
+        return [(t.data_ptr(), t._version) for t in self._params]
+
+    def stale(self):
+        """True when a bound parameter was rewritten or replaced since it was packed (packed conv weights and folded
+        BatchNorm are a snapshot; biases / GroupNorm / head weights are read in place)."""
+        return self._fingerprint() != self._stamp
+
     def conv_plans(self):
         out = []
         buf = (ctypes.c_int * 5)()
@@ -60,6 +83,12 @@ class NetEngine:
             self._lib.fpc_net_conv_plan(self._h, i, buf)
             out.append(tuple(buf))
         return out
+
+    def flops(self):
+        """(direct-convolution FLOP, FLOP the current plans execute, Winograd share) of one forward over the batch."""
+        buf = (ctypes.c_double * 3)()
+        nat.check(self._lib.fpc_net_flops(self._h, buf), "fpc_net_flops")
+        return tuple(buf)
 
     def __del__(self):
         h = getattr(self, "_h", None)

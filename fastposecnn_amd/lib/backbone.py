@@ -102,11 +102,39 @@ class ResNetEncoder(nn.Module):
         return feats
 
 
+_WARNED_WEIGHTS = set()
+
+
 def get_encoder(name, in_channels=3, depth=5, weights=None):
-    """smp.encoders.get_encoder stand-in.  Pretrained weights cannot be downloaded here
-    (no network): `weights` is recorded but the encoder is randomly initialised."""
+    """smp.encoders.get_encoder stand-in (call site F/lib/pose_regressor.py:608-613).
+
+    smp downloads the torchvision ImageNet checkpoint for weights='imagenet' (every HPARAM preset asks for it,
+    F/config.py).  There is no network here, so pretrained weights come from a local file:
+    `FPC_ENCODER_WEIGHTS_DIR/<name>.pth` (or `FPC_ENCODER_WEIGHTS=<file>`) holding the torchvision ResNet state
+    dict (keys conv1.weight, bn1.*, layer1.0.conv1.weight, ...; fc.* is dropped, as smp does).  When `weights` is
+    requested and no file is configured the encoder stays randomly initialised and a warning says so once per
+    encoder — a checkpoint loaded afterwards (load_from_ckpt) overwrites the encoder anyway."""
+    import logging
+    import os
     enc = ResNetEncoder(name, in_channels=in_channels, depth=depth)
     enc.requested_weights = weights
+    enc.loaded_weights = None
+    if weights is not None:
+        path = os.environ.get("FPC_ENCODER_WEIGHTS")
+        if not path and os.environ.get("FPC_ENCODER_WEIGHTS_DIR"):
+            path = os.path.join(os.environ["FPC_ENCODER_WEIGHTS_DIR"], f"{name}.pth")
+        if path:
+            import torch
+            sd = torch.load(path, map_location="cpu")
+            sd = {k: v for k, v in sd.items() if not k.startswith("fc.")}
+            enc.load_state_dict(sd)                  # strict: a wrong file fails loudly
+            enc.loaded_weights = path
+        elif (name, weights) not in _WARNED_WEIGHTS:
+            _WARNED_WEIGHTS.add((name, weights))
+            logging.getLogger('fastposecnn').warning(
+                "encoder %s: ENCODER_WEIGHTS=%r requested but no local file is configured "
+                "(FPC_ENCODER_WEIGHTS / FPC_ENCODER_WEIGHTS_DIR): the encoder is RANDOMLY initialised, unlike "
+                "smp.get_encoder, until a checkpoint is loaded", name, weights)
     return enc
 
 

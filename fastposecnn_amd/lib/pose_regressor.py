@@ -250,24 +250,21 @@ class PoseRegressor(Model, torch.nn.Module):
                             graph=bool(getattr(self.HPARAM, 'ENGINE_GRAPH', True)),
                             split_precision=bool(getattr(self.HPARAM, 'ENGINE_SPLIT_PRECISION', False)))
             self._engines[key] = eng
+        elif eng.stale():
+            # a parameter changed since the plan packed it (load_state_dict on the model or a sub-module, an optimizer
+            # or EMA step, p.copy_()): repack; the tuned tilings and the workspace stay.  Checked per forward, by every
+            # FrameStreamer copy for its own plans; train()/eval() alone no longer costs a re-tune.
+            eng.bind(self)
         return eng
 
     def _drop_engines(self):
-        # packed weights are a snapshot of the parameters: anything that may change them drops the plans
         self._engines = {}
         self._fused = None
 
-    def train(self, mode: bool = True):
-        self._drop_engines()
-        return super().train(mode)
-
     def _apply(self, fn, *args, **kwargs):
+        # .to() / .cuda() / .float(): the parameters become new tensors, possibly on another device
         self._drop_engines()
         return super()._apply(fn, *args, **kwargs)
-
-    def load_state_dict(self, *args, **kwargs):
-        self._drop_engines()
-        return super().load_state_dict(*args, **kwargs)
 
     @MODEL_TIMER
     def pure_model_forward(self, x: torch.Tensor):

@@ -50,6 +50,12 @@ class FrameStreamer:
     def _enqueue(self, k, x, x_ready, categorical_override, seed):
         model, stream = self.models[k], self.net_streams[k]
         stream.wait_event(x_ready)                            # x was produced on the caller's stream
+        # x is read on `stream` after the caller may have dropped it: tell the caching allocator, or the block can be
+        # handed out again (and overwritten) on the caller's stream while this frame's first kernel still reads it
+        x.record_stream(stream)
+        if categorical_override is not None:
+            for t in categorical_override.values():
+                t.record_stream(stream)
         with torch.no_grad():
             with torch.cuda.stream(stream):
                 model._inv_k(x.device)
@@ -99,7 +105,12 @@ class FrameStreamer:
         return self._enqueue(k, x, x_ready, categorical_override, seed)
 
     def collect(self, ticket):
-        """Wait for the ticket's frame (only) and return forward()'s dict."""
+        """Wait for the ticket's frame (only) and return forward()'s dict.
+
+        Ownership: the returned tensors were allocated on the frame's own stream; the frame is complete when
+        this returns, and every tensor is registered with the caller's current stream (`record_stream`), so the
+        caller may consume them asynchronously there and drop them at any time — their blocks go back to the
+        frame stream's pool only after the caller's queued work has finished."""
         model = ticket["model"]
         agg = None
         if ticket["post"] is not None:
@@ -110,4 +121,11 @@ class FrameStreamer:
             agg = ticket["agg_only"]
         else:
             ticket["net_event"].synchronize()
-        return {"logits": ticket["logits"], "categorical": ticket["categorical"], "aggregated": agg}
+        out = {"logits": ticket["logits"], "categorical": ticket["categorical"], "aggregated": agg}
+        consumer = torch.cuda.current_stream(self.device)
+        for group in out.values():
+            if group:
+                for t in group.values():
+                    if torch.is_tensor(t) and t.is_cuda:
+                        t.record_stream(consumer)
+        return out

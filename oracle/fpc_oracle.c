@@ -37,6 +37,21 @@
 /* RV/src/ransac_voting_kernel.cu:11-49  generate_hypothesis_kernel          */
 /* direct [tn,vn,2], coords [tn,2] (x=col, y=row), idxs [hn,vn,2]            */
 /* -> hyp [hn,vn,2], zero-initialised as the launcher does (:75).            */
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+/* Threads used by the parallel loops (bench.py's cpu_baseline): n <= 0 = all cores.  Returns the count in effect. */
+int fpco_set_threads(int n) {
+#ifdef _OPENMP
+    if (n <= 0) n = omp_get_num_procs();
+    omp_set_num_threads(n);
+    return n;
+#else
+    (void)n;
+    return 1;
+#endif
+}
+
 int fpco_generate_hypothesis(const float* direct, const float* coords, const int32_t* idxs,
                              float* hyp, int tn, int vn, int hn) {
     if (tn < 0 || vn < 1 || hn < 0) return FPCO_EINVAL;
@@ -211,12 +226,21 @@ int fpco_ransac_voting_v3(const float* mask, const float* vertex,
 
         /* :562-567 counts and arg-max; torch.max returns the first maximal index */
         int best = 0, best_cnt = -1;
+        /* the hn x tn decisions are independent: OpenMP over the hypotheses when the library is built with it
+         * (bench.py's all-cores baseline; fpco_set_threads(1) = the scalar port); the arg-max stays sequential */
+#ifdef _OPENMP
+#pragma omp parallel for schedule(static)
+#endif
         for (int hi = 0; hi < hn; ++hi) {
             int cnt = 0;
             float hx = hyp[2 * hi], hy = hyp[2 * hi + 1];
             for (int ti = 0; ti < tn; ++ti)
                 cnt += fpco_pair_is_inlier(coords[2 * ti], coords[2 * ti + 1],
                                            direct[2 * ti], direct[2 * ti + 1], hx, hy, thresh);
+            pair[2 * hi] = cnt;                              /* pair[] is free after generate_hypothesis */
+        }
+        for (int hi = 0; hi < hn; ++hi) {
+            int cnt = pair[2 * hi];
             if (out_counts) out_counts[(size_t)bi * hn + hi] = cnt;
             if (cnt > best_cnt) { best_cnt = cnt; best = hi; }
         }

@@ -49,6 +49,13 @@ def lib():
     return _lib
 
 
+def set_threads(n):
+    """Threads of the oracle's parallel loops (the vote's hn x tn decisions): 1 = scalar port, <= 0 = all cores."""
+    f = lib().fpco_set_threads
+    f.restype = ctypes.c_int
+    return int(f(int(n)))
+
+
 def _p(a, t):
     return None if a is None else a.ctypes.data_as(t)
 

@@ -243,23 +243,50 @@ def test_net_fullsize_vs_torch_modules(lib, dev, encoder, B):
 
 
 def test_engine_invalidation(lib, dev):
-    """Packed weights are a snapshot: train()/eval(), load_state_dict and .to() must drop the plan."""
+    """Packed weights are a snapshot keyed on (address, version) of every bound tensor: in-place updates, a
+    load_state_dict on the model OR on a sub-module, and FrameStreamer's plan copies all pick the new values up
+    without losing the tuned plan; train()/eval() alone do not repack; .to() drops the plans."""
+    import copy
     from fastposecnn_amd import synth
+    from fastposecnn_amd.streaming import FrameStreamer
     m, hp = _model(lib, dev, "resnet18")
     m = m.to(dev)
     x = synth.make_image(1, 64, 64)[None].to(dev)
     with torch.no_grad():
         a = m(x)["logits"]["mask"].clone()
         assert m._engines
-        with torch.no_grad():
-            m.segmentation_head[0].bias.add_(1.0)
-        m.eval()                                              # any train()/eval() call drops the plans
-        assert not m._engines
-        b = m(x)["logits"]["mask"]
-    assert torch.allclose(b, a + 1.0, atol=1e-5)
+        eng = next(iter(m._engines.values()))
+        plans = eng.conv_plans()
+        m.train(); m.eval()                                   # no parameter changed: same plan, not repacked
+        assert next(iter(m._engines.values())) is eng and not eng.stale() and eng.reloads == 1
+        m.segmentation_head[0].bias.add_(1.0)                 # read in place by the plan; still flagged
+        assert eng.stale()
+        b = m(x)["logits"]["mask"].clone()
+        assert eng.reloads == 2 and eng.conv_plans() == plans # repacked, tilings kept
+        assert torch.allclose(b, a + 1.0, atol=1e-5)
+        # a SNAPSHOTTED tensor (conv weight, folded BN) changed through a sub-module's load_state_dict
+        sd = copy.deepcopy(m.encoder.state_dict())
+        sd["conv1.weight"] = sd["conv1.weight"] * 0.5
+        sd["bn1.running_var"] = sd["bn1.running_var"] * 4.0
+        m.encoder.load_state_dict(sd)
+        c = m(x)["logits"]["mask"].clone()
+        assert eng.reloads == 3
+        ref = _torch_path(m, x)["mask"]
+        assert (c - ref).abs().max().item() <= 2e-4 * max(1.0, ref.abs().max().item())
+        assert (c - b).abs().max().item() > 1e-3              # the change is visible at all
+        # FrameStreamer copies own their plans and re-check for themselves
+        st = FrameStreamer(m, net_streams=2)
+        for _ in range(2):
+            st.collect(st.submit(x))
+        m.segmentation_head[0].bias.sub_(1.0)
+        outs = [st.collect(st.submit(x))["logits"]["mask"] for _ in range(2)]
+        for o in outs:
+            assert torch.allclose(o, c - 1.0, atol=1e-5)
     m.train()
     out = m(x)                                                # training mode: torch modules, autograd works
-    assert not m._engines and out["logits"]["mask"].requires_grad
+    assert out["logits"]["mask"].requires_grad
+    m2 = m.eval().to("cpu").to(dev)                           # .to(): parameters are new tensors, plans dropped
+    assert not m2._engines
 
 
 @pytest.mark.parametrize("kw", [dict(), dict(net_streams=2, post_inline=False)], ids=["4-streams-inline", "2-streams+post-stream"])

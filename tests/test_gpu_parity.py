@@ -58,6 +58,25 @@ def test_b1_kernels_bit_exact(lib, oracle, dev):
         assert set(torch.unique(inl).tolist()) <= {1, 7}
 
 
+def test_b1_hand_derived_kernel_vectors(lib, dev):
+    """tests/golden/kernel_kat.json (hand-derived from RV/src/ransac_voting_kernel.cu:22-48,100-125, no oracle
+    involved): the B1 kernels, and the same decisions through the fused path's two-cone classification."""
+    import json, os
+    import ransac_voting_gpu_layer.ransac_voting as ext
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "kernel_kat.json")) as f:
+        kat = json.load(f)
+    for c in kat["generate_hypothesis"]:
+        hyp = ext.generate_hypothesis(T(np.asarray(c["direct"], np.float32)[:, None, :], dev),
+                                      T(np.asarray(c["coords"], np.float32), dev),
+                                      T(np.asarray([c["pair"]], np.int32)[:, None, :], dev))
+        assert np.array_equal(hyp.cpu().numpy()[0, 0], np.asarray(c["expect"], np.float32)), c["name"]
+    for c in kat["voting_for_hypothesis"]:
+        inl = torch.zeros((1, 1, 1), dtype=torch.uint8, device=dev)
+        ext.voting_for_hypothesis(T(np.asarray([[c["vote"]]], np.float32), dev), T(np.asarray([c["c"]], np.float32), dev),
+                                  T(np.asarray([[c["h"]]], np.float32), dev), inl, float(np.float32(c["thresh"])))
+        assert int(inl.item()) == c["inlier"], c["name"]
+
+
 def test_b1_input_checks(lib, dev):
     import ransac_voting_gpu_layer.ransac_voting as ext
     d = torch.zeros((4, 1, 2), device=dev); c = torch.zeros((4, 2), device=dev)
@@ -79,7 +98,18 @@ def _run_v3(lib, dev, mask, vertex, hn, **kw):
     return out.cpu().numpy(), [{k: v.cpu().numpy() for k, v in d.items()} for d in dbg]
 
 
-def _assert_v3_equal(out, dbg, want, wdbg):
+def _assert_bound(d, exact=False):
+    """The count kernel's per-hypothesis figure is an UPPER bound of the exact inlier count (csrc/ransac.hip);
+    with a threshold outside the filter's domain it is the count itself.  The refinement counts few hypotheses."""
+    live = d["tn"] > 0
+    assert (d["upper"][live] >= d["counts"][live]).all()
+    if exact:
+        assert np.array_equal(d["upper"][live], d["counts"][live])
+    assert (d["evals"][live] >= 1).all() and (d["evals"][~live] == 0).all()
+
+
+def _assert_v3_equal(out, dbg, want, wdbg, exact=False):
+    _assert_bound(dbg[0], exact)
     for k in ("tn", "win_idx", "win_count", "inlier_count"):
         assert np.array_equal(dbg[0][k], wdbg[0][k]), k
     assert np.array_equal(dbg[0]["hyp"], wdbg[0]["hyp"])       # same divisions, bit for bit
@@ -322,6 +352,11 @@ def test_fullsize_vote_bench_frame(lib, oracle, dev):
         assert np.array_equal(d[k], wdbg[0][k]), k
     assert np.array_equal(d["hyp"], wdbg[0]["hyp"])
     np.testing.assert_allclose(out.cpu().numpy(), want, atol=1e-4, rtol=0)
+    # the bound is tight on realistic votes: a handful of exact recounts per instance, a few pixels of slack
+    _assert_bound(d)
+    assert d["evals"].max() <= 16, d["evals"]
+    top = d["upper"][np.arange(len(d["tn"])), np.maximum(d["win_idx"], 0)] - d["win_count"]
+    assert (top >= 0).all() and top.max() <= 64, top
     # size-independent cross-check through the B1 path for the largest instance
     i = int(np.argmax(d["tn"]))
     m = agg["instance_masks"][i].bool()
@@ -343,7 +378,7 @@ def test_fullsize_vote_bench_frame(lib, oracle, dev):
 @pytest.mark.parametrize("case", ["perfect", "noise", "scaled", "parallel_mix"])
 @pytest.mark.parametrize("thresh", [0.5, 0.999, 0.99999])
 def test_v3_filter_never_changes_the_answer(lib, oracle, dev, case, thresh):
-    """k_count_hi only bounds the counts; k_select must still return exactly the winner of the
+    """k_vote_count only bounds the counts; k_vote_refine must still return exactly the winner of the
     exhaustive vote (lowest index on ties), also on tie-heavy and ill-conditioned inputs."""
     rng = np.random.default_rng(hash((case, thresh)) % 2 ** 32)
     H, W, n, hn = 72, 88, 3, 160
@@ -365,6 +400,7 @@ def test_v3_filter_never_changes_the_answer(lib, oracle, dev, case, thresh):
     out, dbg = _run_v3(lib, dev, mask, vertex, hn, seed=5, inlier_thresh=thresh)
     want, wdbg = oracle.ransac_voting_layer_v3(mask, xy.transpose(0, 2, 3, 1)[:, :, :, None, :], hn, seed=5,
                                                inlier_thresh=thresh, return_debug=True)
+    _assert_bound(dbg[0])
     for k in ("tn", "win_idx", "win_count", "inlier_count", "counts"):
         assert np.array_equal(dbg[0][k], wdbg[0][k]), k
     assert np.array_equal(dbg[0]["hyp"], wdbg[0]["hyp"], equal_nan=True)
@@ -378,7 +414,7 @@ def test_v3_exact_mode_for_nonpositive_threshold(lib, oracle, dev):
         out, dbg = _run_v3(lib, dev, g["mask"], vertex, 64, seed=3, inlier_thresh=th)
         want, wdbg = oracle.ransac_voting_layer_v3(g["mask"], g["xy"].transpose(0, 2, 3, 1)[:, :, :, None, :], 64,
                                                    seed=3, inlier_thresh=th, return_debug=True)
-        _assert_v3_equal(out, dbg, want, wdbg)
+        _assert_v3_equal(out, dbg, want, wdbg, exact=True)
 
 
 # ----------------------------------------------------------------------------- deferred post-network path

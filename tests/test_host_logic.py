@@ -35,7 +35,7 @@ def test_abi_exports_every_declared_symbol(hiplib):
     for name in sorted(declared):
         assert hasattr(raw, name), f"{name} is declared in include/fpc.h but not exported"
     assert declared == set(_native.EXPORTED), declared ^ set(_native.EXPORTED)
-    assert hiplib.fpc_abi_version() == 3
+    assert hiplib.fpc_abi_version() == 4
     assert hiplib.fpc_error_string(-2).decode().startswith("workspace")
 
 
@@ -200,3 +200,72 @@ def test_config1_cpu_mask_head_plumbing():
     for k in ("encoder.layer1.0.conv1.weight", "mask_decoder.p4.skip_conv.bias",
               "rotation_decoder.seg_blocks.0.block.2.block.1.weight", "scales_head.0.bias"):
         assert k in sd, k
+
+
+def test_load_from_ckpt_lightning_round_trip(tmp_path):
+    """F/lib/pose_regressor.py:506-539 with a Lightning-style checkpoint: keys carry the 'model.' prefix, and
+    MODEL / BACKBONE_ARCH / ENCODER / ENCODER_WEIGHTS / SELECTED_CLASSES (only those) come from the checkpoint's
+    'hyper_parameters', overriding the caller's HPARAM."""
+    import fastposecnn_amd.lib as L
+    from fastposecnn_amd import config, synth
+    hp_src = config.HEAD_TRAINING()
+    hp_src.ENCODER = 'resnet34'
+    hp_src.SELECTED_CLASSES = ['bg', 'bottle', 'bowl', 'mug']           # 4 classes: head widths change too
+    torch.manual_seed(3)
+    src = L.pose_regressor.MODELS['PoseRegressor'].load_from_ckpt(None, hp_src).eval()
+    ckpt = {
+        'state_dict': {'model.' + k: v.clone() for k, v in src.state_dict().items()},
+        'hyper_parameters': {'MODEL': 'PoseRegressor', 'BACKBONE_ARCH': 'FPN', 'ENCODER': 'resnet34',
+                             'ENCODER_WEIGHTS': None, 'SELECTED_CLASSES': hp_src.SELECTED_CLASSES,
+                             'BATCH_SIZE': 99, 'HV_NUM_OF_HYPOTHESES': 7},
+        'epoch': 3, 'global_step': 1234,
+    }
+    path = tmp_path / "last.ckpt"
+    torch.save(ckpt, path)
+
+    hp = config.INFERENCE()                                             # resnet18, 7 classes, imagenet weights
+    torch.manual_seed(99)
+    m = L.pose_regressor.MODELS['PoseRegressor'].load_from_ckpt(str(path), hp).eval()
+    assert hp.ENCODER == 'resnet34' and hp.ENCODER_WEIGHTS is None and hp.SELECTED_CLASSES == hp_src.SELECTED_CLASSES
+    assert hp.BATCH_SIZE == 1 and hp.HV_NUM_OF_HYPOTHESES == 1000       # not among the five copied fields
+    assert m.encoder.name == 'resnet34' and m.classes == 4
+    assert tuple(m.rotation_head[0].weight.shape) == (12, 128, 1, 1)
+    sd, want = m.state_dict(), src.state_dict()
+    assert list(sd) == list(want)
+    for k in want:
+        assert torch.equal(sd[k], want[k]), k
+    x = synth.make_image(0, 64, 64)[None]
+    hp.PERFORM_AGGREGATION = False
+    hp_src.PERFORM_AGGREGATION = False
+    with torch.no_grad():
+        a, b = m(x), src(x)
+    for k in a["logits"]:
+        assert torch.equal(a["logits"][k], b["logits"][k]), k
+    # a checkpoint of another architecture is refused by the strict load (as in the reference)
+    bad = dict(ckpt)
+    bad['hyper_parameters'] = dict(ckpt['hyper_parameters'], ENCODER='resnet18')
+    torch.save(bad, path)
+    with pytest.raises(RuntimeError):
+        L.pose_regressor.MODELS['PoseRegressor'].load_from_ckpt(str(path), config.INFERENCE())
+
+
+def test_encoder_weights_from_local_file(tmp_path, monkeypatch, caplog):
+    """ENCODER_WEIGHTS='imagenet' (every preset): smp downloads the torchvision checkpoint; here it is read from a
+    configured local file (fc.* dropped), and without one the random initialisation is announced, not silent."""
+    import logging
+    import backbone as bb
+    torch.manual_seed(1)
+    donor = bb.ResNetEncoder('resnet18')
+    tv = {k: v.clone() for k, v in donor.state_dict().items()}
+    tv['fc.weight'] = torch.zeros(1000, 512); tv['fc.bias'] = torch.zeros(1000)      # torchvision's classifier
+    torch.save(tv, tmp_path / "resnet18.pth")
+    monkeypatch.setenv("FPC_ENCODER_WEIGHTS_DIR", str(tmp_path))
+    torch.manual_seed(2)
+    enc = bb.get_encoder('resnet18', weights='imagenet')
+    assert enc.loaded_weights and all(torch.equal(v, donor.state_dict()[k]) for k, v in enc.state_dict().items())
+    monkeypatch.delenv("FPC_ENCODER_WEIGHTS_DIR")
+    bb._WARNED_WEIGHTS.clear()
+    with caplog.at_level(logging.WARNING, logger='fastposecnn'):
+        enc = bb.get_encoder('resnet18', weights='imagenet')
+    assert enc.loaded_weights is None and "RANDOMLY initialised" in caplog.text
+    assert bb.get_encoder('resnet18', weights=None).requested_weights is None

@@ -81,3 +81,26 @@ def test_cc_label_matches_scipy(oracle):
     want, n = scipy.ndimage.label(fg, structure=s)
     got, m = oracle.cc_label(fg)
     assert m == n and np.array_equal(got, want.astype(np.int32))
+
+
+def _kernel_kat():
+    import json, os
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "kernel_kat.json")) as f:
+        return json.load(f)
+
+
+def test_hand_derived_kernel_vectors(oracle):
+    """tests/golden/kernel_kat.json: every skip branch of .cu:22-48 / :100-125 with the expected output derived by
+    hand (exact fp32 arithmetic on powers of two), incl. the float32(1e-6)-vs-double-literal case."""
+    kat = _kernel_kat()
+    for c in kat["generate_hypothesis"]:
+        direct = np.asarray(c["direct"], np.float32)[:, None, :]
+        coords = np.asarray(c["coords"], np.float32)
+        idxs = np.asarray([c["pair"]], np.int32)[:, None, :]
+        hyp = oracle.generate_hypothesis(direct, coords, idxs)
+        assert np.array_equal(hyp[0, 0], np.asarray(c["expect"], np.float32)), (c["name"], hyp[0, 0])
+    for c in kat["voting_for_hypothesis"]:
+        inl = np.zeros((1, 1, 1), np.uint8)
+        oracle.voting_for_hypothesis(np.asarray([[c["vote"]]], np.float32), np.asarray([c["c"]], np.float32),
+                                     np.asarray([[c["h"]]], np.float32), inl, np.float32(c["thresh"]))
+        assert int(inl[0, 0, 0]) == c["inlier"], c["name"]
