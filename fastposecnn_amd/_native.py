@@ -29,7 +29,7 @@ _SIGNATURES = {
     "fpc_voting_for_hypothesis": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _f, _vp]),
     "fpc_ransac_workspace_bytes": (_sz, [_i, _i, _i, _i]),
     "fpc_ransac_voting_v3": (_i, [_vp, _vp, _i64, _i64, _i64, _i64, _i, _vp, _i, _i, _i, _vp, _vp, _u64, _f, _i, _i,
-                                  _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+                                  _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "fpc_class_compress": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     "fpc_cc_workspace_bytes": (_sz, [_i, _i, _i]),
     "fpc_cc_label": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _i, _vp, _sz, _vp]),

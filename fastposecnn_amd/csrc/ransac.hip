@@ -44,6 +44,8 @@
 // reference's arithmetic.  Thresholds <= 2e-6 have no cone: every pair takes the reference's arithmetic (U exact).
 //
 // One RANSAC round: the reference's rounds re-evaluate identical samples.
+#include <stdlib.h>
+
 #include <algorithm>
 
 #include "common.hpp"
@@ -106,26 +108,35 @@ __global__ void k_b1_vote(const float* __restrict__ direct, const float* __restr
 // ----------------------------------------------------------------------------
 // fused v3
 
-constexpr int kChunkPx = 4096;       // pixels per k_vote_scan task
+constexpr int kChunkPx = 4096;       // pixels per k_vote_scan task; a chunk owns list slots [c * 4096, c * 4096 + its count)
 constexpr int kChunkWords = 64;      // 64-pixel words per chunk
-constexpr int kBlockPx = 256;        // pixels per k_vote_count task (one per lane of a 256-thread workgroup)
-constexpr int kPlanI = 8;            // i32 per instance: fg, tn, nblocks
-constexpr int kMaxHn = 8192;         // k_vote_refine keeps U in LDS (32 KB)
+constexpr int kBlockPx = 512;        // list entries per k_vote_count / k_vote_exact task: 4 waves x 2 tiles of 64
+constexpr int kPlanI = 8;            // i32 per instance: fg, tn, thinned, origin x, origin y, radius
+constexpr int kMaxHn = 65536;
+constexpr int kRec = 6;              // doubles per refinement record: inliers, a00, a01, a11, b0, b1
 
 struct Ws {
     int32_t* plan;        // [n, kPlanI]
-    int32_t* chunk_fg;    // [n, nch]
-    int32_t* chunk_pre;   // [n, nch + 1]   exclusive prefix of chunk_fg (after thinning: of the kept counts)
+    int32_t* chunk_fg;    // [n, nch]       foreground count per chunk (k_vote_plan overwrites it with the kept count when thinning)
+    int32_t* chunk_pre;   // [n, nch + 1]   exclusive prefix of the foreground counts: rank -> chunk
     uint32_t* word_pre;   // [n, nwords]    exclusive count of the word inside its chunk
-    uint64_t* bits;       // [n, nwords]    1 bit per pixel (after k_vote_plan: per KEPT pixel)
+    uint64_t* bits;       // [n, nwords]    1 bit per foreground pixel
+    int32_t* chunk_preK;  // [n, nch + 1]   the same three over the KEPT pixels of a thinned instance (hypothesis sampling only)
+    uint32_t* word_preK;  // [n, nwords]
+    uint64_t* bitsK;      // [n, nwords]
+    int32_t* chunk_box;   // [n, nch, 4]    x min / max, y min / max of the chunk's foreground pixels
     float* hx;            // [n, hnp]       hypothesis points, SoA (hnp = hn rounded up to 64)
     float* hy;            // [n, hnp]
+    float* hxs;           // [n, hnp]       the same minus the instance's origin (centre of its bounding box)
+    float* hys;           // [n, hnp]
     float* eg;            // [n, hnp / 64]  E_g per group of 64 hypotheses
     float* hyp;           // [n, hn, 2]     the same points as the reference's [hn,1,2] tensor
-    int32_t* upper;       // [n, hnp]       U_h (exact counts in exact mode); zeroed by k_vote_plan
-    float4* list;         // [n, HW]        {x, y, dx, dy} of pixel rank j (written by k_vote_count, slice 0)
-    float4* clist;        // [n, HW]        {ey, -ex, cs, ct}: the pixel's filter constants (NaN cs: never an inlier)
-    int nch, nwords, hnp;
+    int32_t* upper;       // [n, hnp]       exact inlier count of every hypothesis; zeroed by k_vote_plan
+    int32_t* tickets;     // [n]            k_vote_final arrivals; zeroed by k_vote_plan
+    double* partial;      // [n, nbx, kRec] k_vote_final per-task records
+    float4* list;         // [n, HW]        {x, y, dx, dy} of the foreground pixels, compacted per chunk (k_vote_scan)
+    float4* clist;        // [n, HW]        {ey, -ex, cs, ct}: their filter constants (NaN cs: never an inlier)
+    int nch, nwords, hnp, nbx;
     size_t total;
 };
 
@@ -135,6 +146,7 @@ static Ws carve(void* base, int n, int H, int W, int hn) {
     w.nch = cdiv((int)HW, kChunkPx);
     w.nwords = w.nch * kChunkWords;
     w.hnp = cdiv(hn, kWave) * kWave;
+    w.nbx = cdiv((int)HW, kBlockPx);
     char* p = (char*)base;
     size_t off = 0;
     auto take = [&](size_t bytes) { char* q = p + off; off = align_up(off + bytes, 256); return q; };
@@ -143,11 +155,19 @@ static Ws carve(void* base, int n, int H, int W, int hn) {
     w.chunk_pre = (int32_t*)take(sizeof(int32_t) * (size_t)n * (w.nch + 1));
     w.word_pre = (uint32_t*)take(sizeof(uint32_t) * (size_t)n * w.nwords);
     w.bits = (uint64_t*)take(sizeof(uint64_t) * (size_t)n * w.nwords);
+    w.chunk_preK = (int32_t*)take(sizeof(int32_t) * (size_t)n * (w.nch + 1));
+    w.word_preK = (uint32_t*)take(sizeof(uint32_t) * (size_t)n * w.nwords);
+    w.bitsK = (uint64_t*)take(sizeof(uint64_t) * (size_t)n * w.nwords);
+    w.chunk_box = (int32_t*)take(sizeof(int32_t) * (size_t)n * w.nch * 4);
     w.hx = (float*)take(sizeof(float) * (size_t)n * w.hnp);
     w.hy = (float*)take(sizeof(float) * (size_t)n * w.hnp);
+    w.hxs = (float*)take(sizeof(float) * (size_t)n * w.hnp);
+    w.hys = (float*)take(sizeof(float) * (size_t)n * w.hnp);
     w.eg = (float*)take(sizeof(float) * (size_t)n * (w.hnp / kWave));
     w.hyp = (float*)take(sizeof(float) * (size_t)n * hn * 2);
     w.upper = (int32_t*)take(sizeof(int32_t) * (size_t)n * w.hnp);
+    w.tickets = (int32_t*)take(sizeof(int32_t) * (size_t)n);
+    w.partial = (double*)take(sizeof(double) * (size_t)n * w.nbx * kRec);
     w.list = (float4*)take(sizeof(float4) * (size_t)n * HW);
     w.clist = (float4*)take(sizeof(float4) * (size_t)n * HW);
     w.total = off;
@@ -185,13 +205,47 @@ __device__ __forceinline__ int wave_excl_scan(int v, int& total) {
     return incl - v;
 }
 
+// The filter constants of one pixel q = {x, y, dx, dy}: {a_s = ey, b_s = -ex, cs, ct} with e the unit vote, so that for a
+// point g:  s = d x e = a_s gx + b_s gy + cs  and  t = d . e = -b_s gx + a_s gy + ct  (d = g - p).  A vote that the
+// reference skips (norm < 1e-6, .cu:121) or that is not finite gets NaN constants: no compare ever accepts it.
+// k_vote_scan stores them for the frame origin; the count / exact kernels re-centre them on the instance
+// (recentre_constants), which shrinks every magnitude the rounding allowance E is proportional to.
+__device__ __forceinline__ float4 pixel_constants(float4 q) {
+    const float qnan = __builtin_nanf("");
+    const float n1 = sqrtf(q.z * q.z + q.w * q.w);
+    float4 c = make_float4(0.f, 0.f, qnan, qnan);
+    if (!below_eps(n1) && n1 <= 3.0e38f) {
+        const float ex = q.z / n1, ey = q.w / n1;
+        c.x = ey; c.y = -ex;
+        c.z = -(q.x * ey - q.y * ex);
+        c.w = -(q.x * ex + q.y * ey);
+    }
+    return c;
+}
+
+// The same constants for coordinates measured from the integer origin (ox, oy): the unit vote is kept, cs / ct are
+// recomputed from the exactly shifted pixel (q.x - ox and q.y - oy are exact: small integers).
+__device__ __forceinline__ float4 recentre_constants(float4 cst, float4 q, float ox, float oy) {
+    if (cst.z != cst.z) return cst;                                  // NaN: the pixel never votes
+    const float xs = q.x - ox, ys = q.y - oy, ey = cst.x, ex = -cst.y;
+    return make_float4(cst.x, cst.y, -(xs * ey - ys * ex), -(xs * ex + ys * ey));
+}
+
 // ---- k_vote_scan -------------------------------------------------------------------
-// grid-stride over (instance, chunk) tasks; 256 threads; a chunk = 4096 pixels = 4 float4 per lane.
-template <bool VEC4>
-__global__ __launch_bounds__(256) void k_vote_scan(const float* __restrict__ mask, int HW, int nch, int n,
-                                                   const int32_t* __restrict__ n_dev, uint64_t* __restrict__ bits,
-                                                   uint32_t* __restrict__ word_pre, int32_t* __restrict__ chunk_fg) {
+// grid-stride over (instance, chunk) tasks; 256 threads; a chunk = 4096 pixels = 4 float4 of the mask per lane.
+// Writes the chunk's bit words / in-chunk prefix / count, and compacts its foreground pixels (vote gathered from the
+// caller's strided planes, filter constants computed once) into the chunk's own slots of the two lists.
+template <bool VEC4, bool VGATHER4>
+__global__ __launch_bounds__(256) void k_vote_scan(const float* __restrict__ mask, const float* __restrict__ vertex,
+                                                   int64_t vs_n, int64_t vs_h, int64_t vs_w, int64_t vs_c, int W, int HW,
+                                                   int nch, int n, const int32_t* __restrict__ n_dev,
+                                                   uint64_t* __restrict__ bits, uint32_t* __restrict__ word_pre,
+                                                   int32_t* __restrict__ chunk_fg, int32_t* __restrict__ chunk_box,
+                                                   float4* __restrict__ list, float4* __restrict__ clist) {
     __shared__ __attribute__((aligned(16))) uint8_t s_nib[kChunkPx / 4];
+    __shared__ uint64_t s_word[kChunkWords];
+    __shared__ int s_wpre[kChunkWords];
+    __shared__ int s_box[4];
     const int total = active_instances(n, n_dev) * nch;
     for (int t = blockIdx.x; t < total; t += gridDim.x) {
         const int inst = t / nch, c = t - inst * nch;
@@ -224,20 +278,79 @@ __global__ __launch_bounds__(256) void k_vote_scan(const float* __restrict__ mas
             const size_t wi = (size_t)inst * nch * kChunkWords + (size_t)c * kChunkWords + threadIdx.x;
             bits[wi] = word;
             word_pre[wi] = (uint32_t)ex;
-            if (threadIdx.x == 0) chunk_fg[(size_t)inst * nch + c] = tot;
+            s_word[threadIdx.x] = word;
+            s_wpre[threadIdx.x] = ex;
+            if (threadIdx.x == 0) {
+                chunk_fg[(size_t)inst * nch + c] = tot;
+                s_box[0] = 0x7fffffff; s_box[1] = -1; s_box[2] = 0x7fffffff; s_box[3] = -1;
+            }
         }
+        __syncthreads();
+        int bx0 = 0x7fffffff, bx1 = -1, by0 = 0x7fffffff, by1 = -1;
+        const float* v = vertex + (int64_t)inst * vs_n;
+        const size_t lbase = (size_t)inst * HW + (size_t)c * kChunkPx;
+        // the votes of this lane's four 4-pixel groups: on the x-contiguous, 16-byte aligned layout (the reference's
+        // permuted view of two planes) two float4 loads per group, predicated on the group having a foreground pixel and
+        // issued together (one memory latency for all eight); any other layout gathers pixel by pixel
+        float4 vx[4], vy[4];
+        if (VGATHER4) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                vx[k] = vy[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (nb[k]) {
+                    const int p = c * kChunkPx + (k * 256 + threadIdx.x) * 4;
+                    const int y = p / W, x = p - y * W;             // W % 4 == 0: the group stays in one row
+                    const float* a = v + (int64_t)y * vs_h + x;
+                    vx[k] = *reinterpret_cast<const float4*>(a);
+                    vy[k] = *reinterpret_cast<const float4*>(a + vs_c);
+                }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (!nb[k]) continue;
+            const int fi = k * 256 + threadIdx.x;
+            const int wq = fi >> 4, bit0 = (fi & 15) * 4;
+            const uint64_t word = s_word[wq];
+            const int wpre = s_wpre[wq];
+            const int p0 = c * kChunkPx + fi * 4;
+            const int y0 = p0 / W, x0 = p0 - y0 * W;
+            const float gx4[4] = {vx[k].x, vx[k].y, vx[k].z, vx[k].w}, gy4[4] = {vy[k].x, vy[k].y, vy[k].z, vy[k].w};
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                if (!((nb[k] >> q) & 1u)) continue;
+                const int bit = bit0 + q;
+                const int pos = wpre + __popcll(word & ((1ull << bit) - 1ull));
+                float4 e;
+                if (VGATHER4) {
+                    e = make_float4((float)(x0 + q), (float)y0, gx4[q], gy4[q]);
+                } else {
+                    const int p = p0 + q;
+                    const int y = p / W, x = p - y * W;
+                    const int64_t o = (int64_t)y * vs_h + (int64_t)x * vs_w;
+                    e = make_float4((float)x, (float)y, v[o], v[o + vs_c]);
+                }
+                list[lbase + pos] = e;
+                clist[lbase + pos] = pixel_constants(e);
+                const int xi = (int)e.x, yi = (int)e.y;
+                bx0 = min(bx0, xi); bx1 = max(bx1, xi); by0 = min(by0, yi); by1 = max(by1, yi);
+            }
+        }
+#pragma unroll
+        for (int o = kWave / 2; o > 0; o >>= 1) {                  // per wave first: same-address LDS atomics serialise
+            bx0 = min(bx0, __shfl_xor(bx0, o, kWave)); bx1 = max(bx1, __shfl_xor(bx1, o, kWave));
+            by0 = min(by0, __shfl_xor(by0, o, kWave)); by1 = max(by1, __shfl_xor(by1, o, kWave));
+        }
+        if ((threadIdx.x & (kWave - 1)) == 0 && bx1 >= 0) {
+            atomicMin(&s_box[0], bx0); atomicMax(&s_box[1], bx1); atomicMin(&s_box[2], by0); atomicMax(&s_box[3], by1);
+        }
+        __syncthreads();
+        if (threadIdx.x < 4) chunk_box[((size_t)inst * nch + c) * 4 + threadIdx.x] = s_box[threadIdx.x];
         __syncthreads();
     }
 }
 
-// ---- pixel look-up by rank ---------------------------------------------------------
-struct Lut {
-    const int32_t* chunk_pre;   // [nch + 1] of this instance (global, or a copy in LDS)
-    const uint32_t* word_pre;   // [nwords]
-    const uint64_t* bits;       // [nwords]
-    int nch;
-};
-
+// ---- rank -> list slot -------------------------------------------------------------
 // position of the r-th (0-based) set bit of w; r < popcount(w)
 __device__ __forceinline__ int select64(uint64_t w, int r) {
     int pos = 0;
@@ -249,31 +362,28 @@ __device__ __forceinline__ int select64(uint64_t w, int r) {
     return pos;
 }
 
-// linear pixel index of the j-th foreground (kept) pixel in raster order; 0 <= j < chunk_pre[nch]
-__device__ __forceinline__ int lookup_pixel(const Lut& L, int j) {
-    int lo = 0, hi = L.nch;                       // chunk_pre[lo] <= j < chunk_pre[hi]
+// chunk holding rank e: largest c with cpre[c] <= e (cpre has nch + 1 entries, cpre[nch] > e)
+__device__ __forceinline__ int rank_chunk(const int32_t* cpre, int nch, int e) {
+    int lo = 0, hi = nch;
     while (hi - lo > 1) {
         const int mid = (lo + hi) >> 1;
-        if (L.chunk_pre[mid] <= j) lo = mid; else hi = mid;
+        if (cpre[mid] <= e) lo = mid; else hi = mid;
     }
-    int r = j - L.chunk_pre[lo];
-    const uint32_t* wp = L.word_pre + (size_t)lo * kChunkWords;
-    int wl = 0, wh = kChunkWords;                 // wp[wl] <= r, and r < wp[wh] where wh < 64
-#pragma unroll
-    for (int s = 0; s < 6; ++s) {
-        const int mid = (wl + wh) >> 1;
-        if ((int)wp[mid] <= r) wl = mid; else wh = mid;
-    }
-    r -= (int)wp[wl];
-    const int w = lo * kChunkWords + wl;
-    return w * 64 + select64(L.bits[w], r);
+    return lo;
 }
 
-__device__ __forceinline__ float4 gather_pixel(const float* __restrict__ v, int64_t vs_h, int64_t vs_w, int64_t vs_c,
-                                               int W, int p) {
-    const int y = p / W, x = p - y * W;
-    const int64_t o = (int64_t)y * vs_h + (int64_t)x * vs_w;
-    return make_float4((float)x, (float)y, v[o], v[o + vs_c]);
+// list slot of the e-th foreground pixel (raster order) of an instance
+__device__ __forceinline__ int entry_slot(const int32_t* cpre, int nch, int e) {
+    const int c = rank_chunk(cpre, nch, e);
+    return c * kChunkPx + (e - cpre[c]);
+}
+
+// Is the list entry q of a THINNED instance kept (RV/ransac_voting_gpu.py:541-545)?
+__device__ __forceinline__ bool entry_kept(float4 q, int W, int HW, int inst, int fg, int max_num, uint64_t seed,
+                                           const uint8_t* __restrict__ keep) {
+    const int p = (int)q.y * W + (int)q.x;
+    return keep ? (keep[(size_t)inst * HW + p] != 0)
+                : (fpc_rand_keep(seed, (uint32_t)inst, (uint32_t)p, (uint32_t)fg, (uint32_t)max_num) != 0);
 }
 
 // ---- k_vote_plan -------------------------------------------------------------------
@@ -299,32 +409,68 @@ __device__ __forceinline__ int block_scan_chunks(const int32_t* __restrict__ arr
     return carry;
 }
 
-// dynamic LDS: the chunk prefix of the instance when it fits (lds_table != 0)
-__global__ __launch_bounds__(1024) void k_vote_plan(const float* __restrict__ vertex, int64_t vs_n, int64_t vs_h,
-                                                    int64_t vs_w, int64_t vs_c, const uint8_t* __restrict__ keep,
-                                                    int W, int HW, int nch, int n, const int32_t* __restrict__ n_dev,
-                                                    int hn, int hnp, const int32_t* __restrict__ idxs, uint64_t seed,
-                                                    int min_num, int max_num, float efac, float wh, int lds_table,
-                                                    int32_t* __restrict__ chunk_fg, int32_t* __restrict__ chunk_pre,
-                                                    uint32_t* __restrict__ word_pre, uint64_t* __restrict__ bits,
-                                                    int32_t* __restrict__ plan, float* __restrict__ hx,
-                                                    float* __restrict__ hy, float* __restrict__ eg,
-                                                    float* __restrict__ hyp, int32_t* __restrict__ upper) {
-    extern __shared__ __attribute__((aligned(16))) int s_cpre[];     // [nch + 1] when lds_table
+// One 1024-thread workgroup per instance.  dynamic LDS: two chunk prefixes [nch + 1] when lds_table.
+__global__ __launch_bounds__(1024) void k_vote_plan(const uint8_t* __restrict__ keep, int W, int HW, int nch, int n,
+                                                    const int32_t* __restrict__ n_dev, int hn, int hnp,
+                                                    const int32_t* __restrict__ idxs, uint64_t seed, int min_num,
+                                                    int max_num, float efac, int lds_table,
+                                                    int32_t* __restrict__ chunk_fg, const int32_t* __restrict__ chunk_box,
+                                                    int32_t* __restrict__ chunk_pre,
+                                                    const uint32_t* __restrict__ word_pre,
+                                                    const uint64_t* __restrict__ bits, int32_t* __restrict__ chunk_preK,
+                                                    uint32_t* __restrict__ word_preK, uint64_t* __restrict__ bitsK,
+                                                    const float4* __restrict__ list, int32_t* __restrict__ plan,
+                                                    float* __restrict__ hx, float* __restrict__ hy,
+                                                    float* __restrict__ hxs, float* __restrict__ hys,
+                                                    float* __restrict__ eg, float* __restrict__ hyp,
+                                                    int32_t* __restrict__ upper, int32_t* __restrict__ tickets) {
+    extern __shared__ __attribute__((aligned(16))) int s_tab[];      // [2][nch + 1] when lds_table
     __shared__ int s_w[20];
+    __shared__ int s_box[4];
+    int* s_cpre = lds_table ? s_tab : nullptr;
+    int* s_cpreK = lds_table ? s_tab + (nch + 1) : nullptr;
     const int n_act = active_instances(n, n_dev);
     const int lane = threadIdx.x & (kWave - 1), wv = threadIdx.x / kWave, nw = blockDim.x / kWave;
     for (int inst = blockIdx.x; inst < n_act; inst += gridDim.x) {
         int32_t* cfg = chunk_fg + (size_t)inst * nch;
         int32_t* cpre = chunk_pre + (size_t)inst * (nch + 1);
-        uint32_t* wpre = word_pre + (size_t)inst * nch * kChunkWords;
-        uint64_t* bw = bits + (size_t)inst * nch * kChunkWords;
+        int32_t* cpreK = chunk_preK + (size_t)inst * (nch + 1);
+        const uint32_t* wpre = word_pre + (size_t)inst * nch * kChunkWords;
+        const uint64_t* bw = bits + (size_t)inst * nch * kChunkWords;
+        uint32_t* wpreK = word_preK + (size_t)inst * nch * kChunkWords;
+        uint64_t* bwK = bitsK + (size_t)inst * nch * kChunkWords;
         for (int h = threadIdx.x; h < hnp; h += blockDim.x) upper[(size_t)inst * hnp + h] = 0;
-        const int fg = block_scan_chunks(cfg, cpre, lds_table ? s_cpre : nullptr, nch, s_w);
+        if (threadIdx.x == 0) { tickets[inst] = 0; s_box[0] = 0x7fffffff; s_box[1] = -1; s_box[2] = 0x7fffffff; s_box[3] = -1; }
+        const int fg = block_scan_chunks(cfg, cpre, s_cpre, nch, s_w);
+        // bounding box of the instance -> the origin the filter's coordinates are measured from, and the largest
+        // |x - ox| + |y - oy| of its pixels (both only scale the rounding allowance: any values are sound)
+        {
+            int b0 = 0x7fffffff, b1 = -1, b2 = 0x7fffffff, b3 = -1;
+            for (int c = threadIdx.x; c < nch; c += blockDim.x) {
+                const int32_t* bx = chunk_box + ((size_t)inst * nch + c) * 4;
+                b0 = min(b0, bx[0]); b1 = max(b1, bx[1]); b2 = min(b2, bx[2]); b3 = max(b3, bx[3]);
+            }
+#pragma unroll
+            for (int o = kWave / 2; o > 0; o >>= 1) {
+                b0 = min(b0, __shfl_xor(b0, o, kWave)); b1 = max(b1, __shfl_xor(b1, o, kWave));
+                b2 = min(b2, __shfl_xor(b2, o, kWave)); b3 = max(b3, __shfl_xor(b3, o, kWave));
+            }
+            if (lane == 0 && b1 >= 0) { atomicMin(&s_box[0], b0); atomicMax(&s_box[1], b1); atomicMin(&s_box[2], b2); atomicMax(&s_box[3], b3); }
+            __syncthreads();
+        }
+        int ox = 0, oy = 0, rad = W + HW / W;
+        if (s_box[1] >= 0) {
+            ox = (s_box[0] + s_box[1]) / 2; oy = (s_box[2] + s_box[3]) / 2;
+            rad = max(s_box[1] - ox, ox - s_box[0]) + max(s_box[3] - oy, oy - s_box[2]);
+        }
+        const float fox = (float)ox, foy = (float)oy, frad = (float)rad;
         int tn = fg;
-        if (fg > max_num) {
+        const bool thin = fg > max_num;
+        if (thin) {
             // RV/ransac_voting_gpu.py:541-545: keep each foreground pixel with probability max_num / fg (injected
             // selection, or the counter-based stream of include/fpc_rng.h).  One wave per chunk, one lane per word.
+            // The kept image only serves the pair sampling below: the lists keep every foreground pixel and the
+            // count / exact kernels re-derive each entry's decision.
             for (int c = wv; c < nch; c += nw) {
                 const size_t wi = (size_t)c * kChunkWords + lane;
                 uint64_t rem = bw[wi], kept = 0;
@@ -338,26 +484,48 @@ __global__ __launch_bounds__(1024) void k_vote_plan(const float* __restrict__ ve
                 }
                 int tot;
                 const int ex = wave_excl_scan(__popcll(kept), tot);
-                bw[wi] = kept;
-                wpre[wi] = (uint32_t)ex;
+                bwK[wi] = kept;
+                wpreK[wi] = (uint32_t)ex;
                 if (lane == 0) cfg[c] = tot;
             }
             __syncthreads();
-            tn = block_scan_chunks(cfg, cpre, lds_table ? s_cpre : nullptr, nch, s_w);
+            tn = block_scan_chunks(cfg, cpreK, s_cpreK, nch, s_w);
         }
         if (fg < min_num) tn = 0;      // :536-539
         if (threadIdx.x == 0) {
             plan[inst * kPlanI + 0] = fg;
             plan[inst * kPlanI + 1] = tn;
-            plan[inst * kPlanI + 2] = (tn + kBlockPx - 1) / kBlockPx;
+            plan[inst * kPlanI + 2] = thin ? 1 : 0;
+            plan[inst * kPlanI + 3] = ox;
+            plan[inst * kPlanI + 4] = oy;
+            plan[inst * kPlanI + 5] = rad;
         }
-        __syncthreads();               // the look-up tables of this instance are complete (same CU: visible)
+        __syncthreads();               // the tables of this instance are complete (same CU: visible)
 
-        Lut L{lds_table ? s_cpre : cpre, wpre, bw, nch};
-        const float* v = vertex + (int64_t)inst * vs_n;
+        const int32_t* tab = lds_table ? s_cpre : cpre;
+        const int32_t* tabK = lds_table ? s_cpreK : cpreK;
+        const float4* E = list + (size_t)inst * HW;
+        // list slot of the t-th pixel the pair sampling may draw (the t-th KEPT one when thinned)
+        auto sample_slot = [&](int t) -> int {
+            if (!thin) return entry_slot(tab, nch, t);
+            const int c = rank_chunk(tabK, nch, t);
+            int r = t - tabK[c];
+            const uint32_t* wp = wpreK + (size_t)c * kChunkWords;
+            int wl = 0, wh2 = kChunkWords;
+#pragma unroll
+            for (int s = 0; s < 6; ++s) {
+                const int mid = (wl + wh2) >> 1;
+                if ((int)wp[mid] <= r) wl = mid; else wh2 = mid;
+            }
+            r -= (int)wp[wl];
+            const int w = c * kChunkWords + wl;
+            const int bit = select64(bwK[w], r);
+            return c * kChunkPx + (int)wpre[w] + __popcll(bw[w] & ((1ull << bit) - 1ull));
+        };
         for (int h0 = 0; h0 < hnp; h0 += blockDim.x) {       // uniform trip count; a wave holds one group of 64
             const int hi = h0 + threadIdx.x;
             float x = 0.0f, y = 0.0f, e = 0.0f;
+            bool wild = false;
             if (hi < hn) {
                 if (tn > 0) {
                     int t0, t1;
@@ -369,81 +537,101 @@ __global__ __launch_bounds__(1024) void k_vote_plan(const float* __restrict__ ve
                         t1 = fpc_rand_index(seed, (uint32_t)inst, (uint32_t)hi, 1u, (uint32_t)tn);
                     }
                     if (t0 >= 0 && t0 < tn && t1 >= 0 && t1 < tn) {      // the reference reads out of bounds here
-                        const int p0 = lookup_pixel(L, t0), p1 = lookup_pixel(L, t1);
-                        const float4 a = gather_pixel(v, vs_h, vs_w, vs_c, W, p0);
-                        const float4 b = gather_pixel(v, vs_h, vs_w, vs_c, W, p1);
-                        intersect(a, b, x, y);
+                        const int s0 = sample_slot(t0), s1 = sample_slot(t1);
+                        intersect(E[s0], E[s1], x, y);
                     }
                 }
                 hyp[((size_t)inst * hn + hi) * 2] = x;
                 hyp[((size_t)inst * hn + hi) * 2 + 1] = y;
                 const float s = fabsf(x) + fabsf(y);
-                if (s <= 1e18f) e = efac * (s + wh);          // false for inf / NaN: outside the filter's domain
+                wild = !(s <= 1e18f);                          // inf / NaN / huge: outside the filter's domain
+                if (!wild) e = efac * (fabsf(x - fox) + fabsf(y - foy) + frad);
             }
             if (hi < hnp) {
                 hx[(size_t)inst * hnp + hi] = x;
                 hy[(size_t)inst * hnp + hi] = y;
+                hxs[(size_t)inst * hnp + hi] = x - fox;
+                hys[(size_t)inst * hnp + hi] = y - foy;
                 float m = e;
 #pragma unroll
                 for (int o = kWave / 2; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, kWave));
+                if (__builtin_amdgcn_ballot_w64(wild)) m = -1.0f;     // the whole group takes the reference's arithmetic
                 if (lane == 0) eg[(size_t)inst * (hnp / kWave) + hi / kWave] = m;
             }
         }
-        __syncthreads();               // s_w / s_cpre are reused by the next instance
+        __syncthreads();               // s_w / s_tab are reused by the next instance
     }
 }
 
-// ---- pair classification shared by k_vote_count<kModeFiltered> and k_vote_refine ---------------------------------
+// ---- pair classification shared by k_vote_count<kModeFiltered> and k_vote_exact ----------------------------------
 // cst = {a_s = ey, b_s = -ex, c_s, ct} (c_s NaN: the pixel never votes).  Returns, per lane, whether the reference
 // accepts (pixel, hypothesis): two FMA pairs and two compares decide unless the pair lies between the cones; those
 // lanes (wave-uniform branch, rare) run the reference's own arithmetic on the raw pixel q = {x, y, dx, dy}.
 struct Cones { float kappa1, kappa2; };
 
-template <typename LoadQ>
-__device__ __forceinline__ bool classify_pair(const float4 cst, const Cones k, float gx, float gy, float E, bool wild,
-                                              bool valid, float thresh, LoadQ load_q) {
-    const float ss = fabsf(__builtin_fmaf(cst.x, gx, __builtin_fmaf(cst.y, gy, cst.z)));
-    const float tt = __builtin_fmaf(-cst.y, gx, __builtin_fmaf(cst.x, gy, cst.w));
+// (gxs, gys) = the point minus the instance's origin, cst re-centred on it; (gx, gy) = the point itself.
+__device__ __forceinline__ bool classify_pair(const float4 cst, const float4 q, const Cones k, float gxs, float gys,
+                                              float gx, float gy, float E, bool wild, bool valid, float thresh) {
+    const float ss = fabsf(__builtin_fmaf(cst.x, gxs, __builtin_fmaf(cst.y, gys, cst.z)));
+    const float tt = __builtin_fmaf(-cst.y, gxs, __builtin_fmaf(cst.x, gys, cst.w));
     bool sure = ss <= __builtin_fmaf(k.kappa2, tt, -E);
     bool band = !sure && (ss <= __builtin_fmaf(k.kappa1, tt, E));
     if (wild) { sure = false; band = valid; }                   // wave-uniform: outside the filter's domain
     if (__builtin_amdgcn_ballot_w64(band)) {
         if (band) {
-            const float4 q = load_q();
             const float n1 = sqrtf(q.z * q.z + q.w * q.w);
             sure = pair_is_inlier(q.x, q.y, q.z, q.w, n1, gx, gy, thresh);
         }
     }
-    return sure;
+    return sure && valid;
 }
 
-// ---- k_vote_count ------------------------------------------------------------------
-// Task t -> (instance, pixel block, hypothesis slice).  The slices of one block differ by 8 in t, i.e. they run
-// on one XCD under round-robin dispatch (speed only).  grid-stride; 256 threads.
-// dynamic LDS: [gps * 64] counts of the slice, then the instance's chunk prefix [nch + 1] when lds_table.
-enum { kModeUpper = 0, kModeExact = 1, kModeFiltered = 2 };
+// The pairs between the cones: the reference's own arithmetic for the lanes of `band`, out of line so that the hot
+// loop of k_vote_count stays a run of FMAs and compares.  Returns how many of them are inliers.
+__device__ __attribute__((noinline)) int count_band_pairs(unsigned long long band, float4 q, float n1, float gx, float gy,
+                                                          float thresh) {
+    const int lane = threadIdx.x & (kWave - 1);
+    const bool in = ((band >> lane) & 1ull) && pair_is_inlier(q.x, q.y, q.z, q.w, n1, gx, gy, thresh);
+    return __popcll(__builtin_amdgcn_ballot_w64(in));
+}
 
-template <int MODE>
-__global__ __launch_bounds__(256) void k_vote_count(const float* __restrict__ vertex, int64_t vs_n, int64_t vs_h,
-                                                    int64_t vs_w, int64_t vs_c, int W, int HW, int nch, int n,
-                                                    const int32_t* __restrict__ n_dev, int hn, int hnp, int nb_grid,
-                                                    int S, int gps /* groups of 64 hypotheses per slice */,
-                                                    float kappa1, float kappa2, float efac_ref, float wh, float thresh,
-                                                    int lds_table, const int32_t* __restrict__ chunk_pre,
-                                                    const uint32_t* __restrict__ word_pre,
-                                                    const uint64_t* __restrict__ bits, const int32_t* __restrict__ plan,
-                                                    const float* __restrict__ hx, const float* __restrict__ hy,
-                                                    const float* __restrict__ eg, int32_t* __restrict__ counts,
-                                                    int cstride, float4* __restrict__ list, float4* __restrict__ clist) {
+struct TilePair {                    // one lane's two list entries: filter constants, |vote|, raw pixel
+    float a_s[2], b_s[2], c_s[2], a_t[2], b_t[2], c_t[2], n1[2];
+    float4 q[2];
+};
+
+// ---- k_vote_count ------------------------------------------------------------------
+// EXACT inlier count of every hypothesis.  Task t -> (instance, block of 512 list entries, hypothesis slice).  The
+// slices of one block differ by 8 in t, i.e. they run on one XCD under round-robin dispatch (speed only).
+// grid-stride; 256 threads; a wave owns two 64-entry tiles; lanes hold six constants per entry, the hypotheses arrive
+// in SGPRs (scalar loads).  Per (entry, hypothesis): 5 FMA + 2 compares decide "surely an inlier" / "surely not";
+// the pairs between the cones (wave-uniform branch, a few per 10^4) run the reference's own arithmetic.
+// dynamic LDS: [gps * 32] packed counts of the slice (two hypotheses per word), then the chunk prefix [nch + 1] when lds_table.
+enum { kModeCones = 0, kModeReference = 1 };
+
+template <int MODE, int WAVES /* waves per SIMD the register allocation aims at */>
+__global__ __launch_bounds__(256, WAVES) void k_vote_count(int W, int HW, int nch, int n, const int32_t* __restrict__ n_dev,
+                                                    int hn, int hnp, int nb_grid, int S,
+                                                    int gps /* groups of 64 hypotheses per slice */, float kappa1,
+                                                    float kappa2, float thresh, int max_num, uint64_t seed,
+                                                    const uint8_t* __restrict__ keep, int lds_table,
+                                                    const int32_t* __restrict__ chunk_pre,
+                                                    const int32_t* __restrict__ plan, const float* __restrict__ hx,
+                                                    const float* __restrict__ hy, const float* __restrict__ hxs,
+                                                    const float* __restrict__ hys, const float* __restrict__ eg,
+                                                    int32_t* __restrict__ counts, const float4* __restrict__ list,
+                                                    const float4* __restrict__ clist) {
     extern __shared__ __attribute__((aligned(16))) int s_dyn[];
-    int* s_cnt = s_dyn;                        // [gps * 64]
-    int* s_cpre = s_dyn + gps * kWave;         // [nch + 1]
+    int* s_cnt = s_dyn;                              // [gps * 32]
+    int* s_cpre = s_dyn + gps * (kWave / 2);         // [nch + 1]
     const int n_act = active_instances(n, n_dev);
     const long long units = (long long)n_act * nb_grid;
     const long long total = (units + 7) / 8 * 8 * S;
-    const int lane = threadIdx.x & (kWave - 1);
+    const int lane = threadIdx.x & (kWave - 1), wv = threadIdx.x / kWave;
     const int ngroups = hnp / kWave;
-    const Cones cones{kappa1, kappa2};
+    const float qnan = __builtin_nanf("");
+    // sure  <=>  |s| <= kappa2 t - E  =  r (kappa1 t + E) - (1 + r) E   with r = kappa2 / kappa1: one FMA on the other bound
+    const float ratio = kappa1 > 0.0f ? kappa2 / kappa1 : 0.0f;
     int cached_inst = -1;
     for (long long t = blockIdx.x; t < total; t += gridDim.x) {
         const long long grp = t / (8 * S);
@@ -452,93 +640,127 @@ __global__ __launch_bounds__(256) void k_vote_count(const float* __restrict__ ve
         const long long u = grp * 8 + (rem & 7);
         if (u >= units) continue;
         const int inst = (int)(u / nb_grid), b0 = (int)(u - (long long)inst * nb_grid);
-        const int tn = plan[inst * kPlanI + 1];
+        const int fg = plan[inst * kPlanI + 0], tn = plan[inst * kPlanI + 1];
+        const bool thin = plan[inst * kPlanI + 2] != 0;
+        const float fox = (float)plan[inst * kPlanI + 3], foy = (float)plan[inst * kPlanI + 4];
+        const int nent = tn > 0 ? fg : 0;                           // list entries to visit (all foreground pixels)
         const int g_lo = s * gps, g_hi = min(ngroups, g_lo + gps);
-        if (g_lo >= g_hi || b0 * kBlockPx >= tn) continue;          // uniform
+        if (g_lo >= g_hi || b0 * kBlockPx >= nent) continue;        // uniform
         if (lds_table && cached_inst != inst) {                     // uniform
             __syncthreads();
             for (int i = threadIdx.x; i <= nch; i += blockDim.x) s_cpre[i] = chunk_pre[(size_t)inst * (nch + 1) + i];
             cached_inst = inst;
             __syncthreads();
         }
-        const Lut L{lds_table ? s_cpre : chunk_pre + (size_t)inst * (nch + 1), word_pre + (size_t)inst * nch * kChunkWords,
-                    bits + (size_t)inst * nch * kChunkWords, nch};
-        // an instance normally has at most nb_grid blocks; one that keeps more pixels (an injected selection) wraps around
-        for (int b = b0; b * kBlockPx < tn; b += nb_grid) {
-            // this lane's pixel
-            const int j = b * kBlockPx + threadIdx.x;
-            const bool valid = j < tn;
-            float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
-            float n1 = 0.0f;
-            const float qnan = __builtin_nanf("");
-            float4 cst = make_float4(0.f, 0.f, qnan, qnan);         // NaN: the slot never counts
-            if (valid) {
-                q = gather_pixel(vertex + (int64_t)inst * vs_n, vs_h, vs_w, vs_c, W, lookup_pixel(L, j));
-                n1 = sqrtf(q.z * q.z + q.w * q.w);
-                if (MODE != kModeExact && !below_eps(n1) && n1 <= 3.0e38f) {
-                    const float ex = q.z / n1, ey = q.w / n1;
-                    cst.x = ey; cst.y = -ex;
-                    cst.z = -(q.x * ey - q.y * ex);                 // s = d x e = ey gx - ex gy + cs
-                    cst.w = -(q.x * ex + q.y * ey);                 // t = d . e = ex gx + ey gy + ct
+        const int32_t* tab = lds_table ? s_cpre : chunk_pre + (size_t)inst * (nch + 1);
+        // an instance normally has at most nb_grid blocks (<= max_num pixels unless thinned); a larger one wraps around
+        for (int b = b0; b * kBlockPx < nent; b += nb_grid) {
+            TilePair tp;                                            // this lane's two entries
+            float c_t0[2];
+            bool valid[2];
+#pragma unroll
+            for (int tl = 0; tl < 2; ++tl) {
+                const int e = b * kBlockPx + (wv * 2 + tl) * kWave + lane;
+                valid[tl] = e < nent;
+                float4 cst = make_float4(0.f, 0.f, qnan, qnan);      // NaN: the slot never counts
+                tp.q[tl] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (valid[tl]) {
+                    const size_t slot = (size_t)inst * HW + entry_slot(tab, nch, e);
+                    tp.q[tl] = list[slot];
+                    if (MODE == kModeCones) cst = recentre_constants(clist[slot], tp.q[tl], fox, foy);
+                    if (thin && !entry_kept(tp.q[tl], W, HW, inst, fg, max_num, seed, keep)) {
+                        valid[tl] = false;
+                        cst = make_float4(0.f, 0.f, qnan, qnan);
+                    }
                 }
-                if (s == 0 && list) {
-                    list[(size_t)inst * HW + j] = q;
-                    if (MODE != kModeExact) clist[(size_t)inst * HW + j] = cst;
-                }
+                // folded constants:  s = a_s gx + b_s gy + c_s ;  kappa1 t + E_g = a_t gx + b_t gy + (c_t0 + E_g)
+                tp.a_s[tl] = cst.x; tp.b_s[tl] = cst.y; tp.c_s[tl] = cst.z;
+                tp.a_t[tl] = kappa1 * -cst.y; tp.b_t[tl] = kappa1 * cst.x; c_t0[tl] = kappa1 * cst.w;
+                tp.n1[tl] = sqrtf(tp.q[tl].z * tp.q[tl].z + tp.q[tl].w * tp.q[tl].w);
             }
-            // folded constants of the upper-bound test: |ss| <= (kappa ex) gx + (kappa ey) gy + (kappa ct + E_g)
-            const float a_s = cst.x, b_s = cst.y, c_s = cst.z;
-            const float a_t = kappa1 * -cst.y, b_t = kappa1 * cst.x, c_t0 = kappa1 * cst.w;
-            for (int i = threadIdx.x; i < (g_hi - g_lo) * kWave; i += blockDim.x) s_cnt[i] = 0;
+            for (int i = threadIdx.x; i < (g_hi - g_lo) * (kWave / 2); i += blockDim.x) s_cnt[i] = 0;
             __syncthreads();
 
             for (int G = g_lo; G < g_hi; ++G) {
+                // HX / HY: the points themselves (the reference's arithmetic); HXS / HYS: minus the origin (the cones)
                 const float* HX = static_cast<const float*>(__builtin_assume_aligned(hx + (size_t)inst * hnp + (size_t)G * kWave, 256));
                 const float* HY = static_cast<const float*>(__builtin_assume_aligned(hy + (size_t)inst * hnp + (size_t)G * kWave, 256));
-                const float c_t = c_t0 + eg[(size_t)inst * ngroups + G];
+                const float* HXS = static_cast<const float*>(__builtin_assume_aligned(hxs + (size_t)inst * hnp + (size_t)G * kWave, 256));
+                const float* HYS = static_cast<const float*>(__builtin_assume_aligned(hys + (size_t)inst * hnp + (size_t)G * kWave, 256));
+                // E_g < 0 marks a group with a hypothesis outside the filter's domain: its pairs all take the reference's
+                // arithmetic (the cones are switched off by NaN bounds)
+                const float eg_g = eg[(size_t)inst * ngroups + G];
                 int cntv = 0;
-                // one (64-pixel tile, hypothesis) step: scalar-loaded point, 4 FMA + 1 compare, ballot + s_bcnt1, and the
-                // count dropped into lane g of cntv by v_writelane (no builtin for it in ROCm 7.2's clang; the lane select is
-                // an immediate, the count an SGPR written by SALU: no wait states required)
-#define FPC_VOTE_STEP(g)                                                                                               \
-                {                                                                                                      \
-                    const float gx = HX[(g)], gy = HY[(g)];                                                            \
-                    bool in;                                                                                           \
-                    if (MODE == kModeExact) {                                                                          \
-                        in = valid && pair_is_inlier(q.x, q.y, q.z, q.w, n1, gx, gy, thresh);                          \
-                    } else if (MODE == kModeFiltered) {                                                                \
-                        const float sabs = fabsf(gx) + fabsf(gy);                                                      \
-                        const bool wild = !(sabs <= 1e18f);                                                            \
-                        in = classify_pair(cst, cones, gx, gy, efac_ref * (sabs + wh), wild, valid, thresh,            \
-                                           [&]() { return q; });                                                       \
-                    } else {                                                                                           \
-                        const float ss = __builtin_fmaf(a_s, gx, __builtin_fmaf(b_s, gy, c_s));                        \
-                        const float th = __builtin_fmaf(a_t, gx, __builtin_fmaf(b_t, gy, c_t));                        \
-                        in = fabsf(ss) <= th;                                                                          \
-                    }                                                                                                  \
-                    const int c = __popcll(__builtin_amdgcn_ballot_w64(in));                                           \
-                    asm("v_writelane_b32 %0, %1, %2" : "+v"(cntv) : "s"(c), "n"(g));                                   \
+                if (MODE != kModeCones || !(eg_g >= 0.0f)) {                        // uniform: every pair by the reference's arithmetic
+                    for (int g = 0; g < kWave; ++g) {
+                        const float gx = HX[g], gy = HY[g];
+                        int c = 0;
+#pragma unroll
+                        for (int tl = 0; tl < 2; ++tl)
+                            c += __popcll(__builtin_amdgcn_ballot_w64(
+                                valid[tl] && pair_is_inlier(tp.q[tl].x, tp.q[tl].y, tp.q[tl].z, tp.q[tl].w, tp.n1[tl], gx, gy, thresh)));
+                        if (lane == (g >> 1)) cntv |= c << ((g & 1) * 16);
+                    }
+                    if (lane < kWave / 2) atomicAdd(&s_cnt[(G - g_lo) * (kWave / 2) + lane], cntv);
+                    continue;
                 }
-#define FPC_VOTE_STEP4(g) FPC_VOTE_STEP(g) FPC_VOTE_STEP((g) + 1) FPC_VOTE_STEP((g) + 2) FPC_VOTE_STEP((g) + 3)
-#define FPC_VOTE_STEP16(g) FPC_VOTE_STEP4(g) FPC_VOTE_STEP4((g) + 4) FPC_VOTE_STEP4((g) + 8) FPC_VOTE_STEP4((g) + 12)
-                FPC_VOTE_STEP16(0) FPC_VOTE_STEP16(16) FPC_VOTE_STEP16(32) FPC_VOTE_STEP16(48)
-#undef FPC_VOTE_STEP16
-#undef FPC_VOTE_STEP4
-#undef FPC_VOTE_STEP
-                atomicAdd(&s_cnt[(G - g_lo) * kWave + lane], cntv);   // LDS: the four waves' tiles of this block
+                tp.c_t[0] = c_t0[0] + eg_g; tp.c_t[1] = c_t0[1] + eg_g;
+                const float e2 = (1.0f + ratio) * eg_g;
+                // one (hypothesis, two 64-entry tiles) step; two hypotheses' counts (<= 128 each) share one SGPR, dropped into
+                // lane g/2 of cntv by v_writelane (no builtin for it in ROCm 7.2's clang; the lane select is an immediate,
+                // the value an SGPR written by SALU: no wait states required)
+#define FPC_VOTE_HYP(g, j, c)                                                                                          \
+                {                                                                                                      \
+                    const float gxs = GXS[(j)], gys = GYS[(j)];                                                        \
+                    unsigned long long band[2];                                                                        \
+                    _Pragma("unroll") for (int tl = 0; tl < 2; ++tl) {                                                 \
+                        const float ss = fabsf(__builtin_fmaf(tp.a_s[tl], gxs, __builtin_fmaf(tp.b_s[tl], gys, tp.c_s[tl]))); \
+                        const float u1 = __builtin_fmaf(tp.a_t[tl], gxs, __builtin_fmaf(tp.b_t[tl], gys, tp.c_t[tl])); \
+                        const unsigned long long sure = __builtin_amdgcn_ballot_w64(ss <= __builtin_fmaf(ratio, u1, -e2)); \
+                        band[tl] = __builtin_amdgcn_ballot_w64(ss <= u1) & ~sure;                                      \
+                        c += __popcll(sure);                                                                           \
+                    }                                                                                                  \
+                    if (__builtin_expect((band[0] | band[1]) != 0ull, 0)) {      /* a few % of the steps */            \
+                        const float gx = HX[(g)], gy = HY[(g)];                                                        \
+                        if (band[0]) c += __builtin_amdgcn_readfirstlane(count_band_pairs(band[0], tp.q[0], tp.n1[0], gx, gy, thresh)); \
+                        if (band[1]) c += __builtin_amdgcn_readfirstlane(count_band_pairs(band[1], tp.q[1], tp.n1[1], gx, gy, thresh)); \
+                    }                                                                                                  \
+                }
+#define FPC_VOTE_PAIR(g2, j2)                                                                                          \
+                {                                                                                                      \
+                    int c0 = 0, c1 = 0;                                                                                \
+                    FPC_VOTE_HYP(2 * (g2), 2 * (j2), c0) FPC_VOTE_HYP(2 * (g2) + 1, 2 * (j2) + 1, c1)                  \
+                    const int pk = c0 | (c1 << 16);                                                                    \
+                    asm("v_writelane_b32 %0, %1, %2" : "+v"(cntv) : "s"(pk), "n"(g2));                                 \
+                }
+                // eight hypotheses per scalar-load batch: the points are fetched before the run of steps (the rare branch
+                // to the band handler ends a basic block, and the compiler does not batch scalar loads across blocks)
+#define FPC_VOTE_OCT(o)                                                                                                \
+                {                                                                                                      \
+                    float GXS[8], GYS[8];                                                                              \
+                    _Pragma("unroll") for (int i = 0; i < 8; ++i) { GXS[i] = HXS[8 * (o) + i]; GYS[i] = HYS[8 * (o) + i]; } \
+                    FPC_VOTE_PAIR(4 * (o), 0) FPC_VOTE_PAIR(4 * (o) + 1, 1) FPC_VOTE_PAIR(4 * (o) + 2, 2) FPC_VOTE_PAIR(4 * (o) + 3, 3) \
+                }
+                FPC_VOTE_OCT(0) FPC_VOTE_OCT(1) FPC_VOTE_OCT(2) FPC_VOTE_OCT(3) FPC_VOTE_OCT(4) FPC_VOTE_OCT(5) FPC_VOTE_OCT(6) FPC_VOTE_OCT(7)
+#undef FPC_VOTE_OCT
+#undef FPC_VOTE_PAIR
+#undef FPC_VOTE_HYP
+                if (lane < kWave / 2) atomicAdd(&s_cnt[(G - g_lo) * (kWave / 2) + lane], cntv);   // fields <= 512: no carry
             }
             __syncthreads();
-            // one integer atomic per (block, hypothesis) with any count: 256-byte wave rows, order-independent result
-            for (int i = threadIdx.x; i < (g_hi - g_lo) * kWave; i += blockDim.x) {
-                const int h = g_lo * kWave + i, v = s_cnt[i];
-                if (v && h < hn) atomicAdd(&counts[(size_t)inst * cstride + h], v);
+            // one integer atomic per (block, hypothesis) with any count: order-independent result
+            for (int i = threadIdx.x; i < (g_hi - g_lo) * (kWave / 2); i += blockDim.x) {
+                const int h = g_lo * kWave + 2 * i, pk = s_cnt[i];
+                const int lo = pk & 0xffff, hi = (int)((unsigned)pk >> 16);
+                if (lo && h < hn) atomicAdd(&counts[(size_t)inst * hnp + h], lo);
+                if (hi && h + 1 < hn) atomicAdd(&counts[(size_t)inst * hnp + h + 1], hi);
             }
             __syncthreads();
         }
     }
 }
 
-// ---- k_vote_refine -----------------------------------------------------------------
+// ---- k_vote_final ------------------------------------------------------------------
 // b_inv (RV/ransac_voting_gpu.py:503-516): inverse when regular, pseudo-inverse when singular.
 __device__ __forceinline__ void solve2_sym(double a00, double a01, double a11, double b0, double b1, double& x0,
                                            double& x1) {
@@ -556,202 +778,158 @@ __device__ __forceinline__ void solve2_sym(double a00, double a01, double a11, d
     }
 }
 
-constexpr int kRefThreads = 1024;
-constexpr int kRefWaves = kRefThreads / kWave;
-constexpr int kRefK = 4;             // candidates counted exactly per pass over the pixels
+constexpr int kFinWaves = 4;         // 256-thread workgroups
 
-// block-wide (max value, lowest index) over s_u[0..hn); entries < 0 are consumed.  Result in every thread.
-__device__ __forceinline__ void block_argmax_lds(const int* s_u, int hn, int* s_red, int& bc, int& bi) {
-    bc = -1; bi = 0x7fffffff;
-    for (int h = threadIdx.x; h < hn; h += blockDim.x) {
-        const int c = s_u[h];
-        if (c > bc) { bc = c; bi = h; }                               // ascending h: first maximum kept
-    }
-#pragma unroll
-    for (int o = kWave / 2; o > 0; o >>= 1) {
-        const int oc = __shfl_xor(bc, o, kWave), oi = __shfl_xor(bi, o, kWave);
-        if (oc > bc || (oc == bc && oi < bi)) { bc = oc; bi = oi; }
-    }
-    const int lane = threadIdx.x & (kWave - 1), w = threadIdx.x / kWave;
-    __syncthreads();
-    if (lane == 0) { s_red[w] = bc; s_red[kRefWaves + w] = bi; }
-    __syncthreads();
-    bc = s_red[0]; bi = s_red[kRefWaves];
-    for (int i = 1; i < kRefWaves; ++i) {
-        const int oc = s_red[i], oi = s_red[kRefWaves + i];
-        if (oc > bc || (oc == bc && oi < bi)) { bc = oc; bi = oi; }
-    }
-}
+typedef unsigned long long __attribute__((address_space(1))) gu64;
 
-// FAST: the two-cone classification (threshold inside the filter's domain); otherwise the reference's arithmetic only.
-template <bool FAST>
-__global__ __launch_bounds__(kRefThreads) void k_vote_refine(int HW, int n, const int32_t* __restrict__ n_dev, int hn,
-                                                             int hnp, float thresh, float kappa1, float kappa2,
-                                                             float efac_ref, float wh, const int32_t* __restrict__ plan,
-                                                             const float* __restrict__ hyp,
-                                                             const int32_t* __restrict__ upper,
-                                                             const float4* __restrict__ list,
-                                                             const float4* __restrict__ clist,
-                                                             float* __restrict__ out_xy, int32_t* __restrict__ out_tn,
-                                                             int32_t* __restrict__ out_win_idx,
-                                                             int32_t* __restrict__ out_win_count,
-                                                             int32_t* __restrict__ out_inl,
-                                                             int32_t* __restrict__ out_upper,
-                                                             int32_t* __restrict__ out_evals) {
-    extern __shared__ __attribute__((aligned(16))) int s_u[];           // [hnp]
-    __shared__ int s_red[2 * kRefWaves * kRefK];
-    __shared__ double s_sum[kRefWaves][5];
+// Winner (largest count, lowest index: torch.max, RV/ransac_voting_gpu.py:567), its inliers voted again (:583-589), the
+// fp64 normal equations and the 2x2 solve (:592-599).  Task = (instance, block b0 of 512 list entries); every instance
+// has nb_grid tasks, whatever its size, and the one whose arrival ticket comes last combines their records
+// (cdna_hip_programming.md Guideline 16, counter form: records stored write-through (sc1), the storing wave drained,
+// one agent-scope add per workgroup; the last arriver reads them back with sc1 loads, in task order: bit-reproducible).
+// dynamic LDS: the chunk prefix [nch + 1] when lds_table.
+template <int MODE>
+__global__ __launch_bounds__(256) void k_vote_final(int W, int HW, int nch, int n, const int32_t* __restrict__ n_dev,
+                                                    int hn, int hnp, int nb_grid, int nbx, float thresh, float kappa1,
+                                                    float kappa2, float efac_ref, int max_num, uint64_t seed,
+                                                    const uint8_t* __restrict__ keep, int lds_table,
+                                                    const int32_t* __restrict__ chunk_pre,
+                                                    const int32_t* __restrict__ plan, const float* __restrict__ hyp,
+                                                    const int32_t* __restrict__ counts, const float4* __restrict__ list,
+                                                    const float4* __restrict__ clist, int32_t* __restrict__ tickets,
+                                                    double* __restrict__ partial, float* __restrict__ out_xy,
+                                                    int32_t* __restrict__ out_tn, int32_t* __restrict__ out_win_idx,
+                                                    int32_t* __restrict__ out_win_count, int32_t* __restrict__ out_inl) {
+    extern __shared__ __attribute__((aligned(16))) int s_cpre[];      // [nch + 1]
+    __shared__ int s_red[2 * kFinWaves];
+    __shared__ int s_last;
+    __shared__ double s_part[kFinWaves][kRec];
     const int n_act = active_instances(n, n_dev);
-    const int lane = threadIdx.x & (kWave - 1), w = threadIdx.x / kWave;
+    const int lane = threadIdx.x & (kWave - 1), wv = threadIdx.x / kWave;
     const Cones cones{kappa1, kappa2};
-    for (int inst = blockIdx.x; inst < n_act; inst += gridDim.x) {
-        const int tn = plan[inst * kPlanI + 1];
+    const long long total = (long long)n_act * nb_grid;
+    for (long long t = blockIdx.x; t < total; t += gridDim.x) {
+        const int inst = (int)(t / nb_grid), b0 = (int)(t - (long long)inst * nb_grid);
+        const int fg = plan[inst * kPlanI + 0], tn = plan[inst * kPlanI + 1];
+        const bool thin = plan[inst * kPlanI + 2] != 0;
         if (tn == 0) {                                                 // uniform; RV/ransac_voting_gpu.py:536-539
-            if (threadIdx.x == 0) {
+            if (b0 == 0 && threadIdx.x == 0) {
                 out_xy[inst * 2] = 0.0f; out_xy[inst * 2 + 1] = 0.0f;
                 if (out_tn) out_tn[inst] = 0;
                 if (out_win_idx) out_win_idx[inst] = -1;
                 if (out_win_count) out_win_count[inst] = 0;
                 if (out_inl) out_inl[inst] = 0;
-                if (out_evals) out_evals[inst] = 0;
             }
-            if (out_upper) for (int h = threadIdx.x; h < hn; h += blockDim.x) out_upper[(size_t)inst * hn + h] = 0;
             continue;
         }
+        const int nent = fg;
+        const float fox = (float)plan[inst * kPlanI + 3], foy = (float)plan[inst * kPlanI + 4];
+        const float frad = (float)plan[inst * kPlanI + 5];
+        // winner: every task of the instance finds the same one
+        int wc = -1, wi = 0x7fffffff;
+        for (int h = threadIdx.x; h < hn; h += blockDim.x) {
+            const int c = counts[(size_t)inst * hnp + h];
+            if (c > wc) { wc = c; wi = h; }                            // ascending h: first maximum kept
+        }
+#pragma unroll
+        for (int o = kWave / 2; o > 0; o >>= 1) {
+            const int oc = __shfl_xor(wc, o, kWave), oi = __shfl_xor(wi, o, kWave);
+            if (oc > wc || (oc == wc && oi < wi)) { wc = oc; wi = oi; }
+        }
+        __syncthreads();                                               // LDS of the previous task is free
+        if (lane == 0) { s_red[wv] = wc; s_red[kFinWaves + wv] = wi; }
+        if (lds_table)
+            for (int i = threadIdx.x; i <= nch; i += blockDim.x) s_cpre[i] = chunk_pre[(size_t)inst * (nch + 1) + i];
+        __syncthreads();
+        wc = s_red[0]; wi = s_red[kFinWaves];
+#pragma unroll
+        for (int i = 1; i < kFinWaves; ++i) {
+            const int oc = s_red[i], oi = s_red[kFinWaves + i];
+            if (oc > wc || (oc == wc && oi < wi)) { wc = oc; wi = oi; }
+        }
+        // no hypothesis with an inlier: all_win_pts stays (0,0) (:571-574) and the refinement votes for (0,0)
         const float* hp = hyp + (size_t)inst * hn * 2;
-        for (int h = threadIdx.x; h < hnp; h += blockDim.x) {
-            int u = -1;
-            if (h < hn) {
-                u = upper[(size_t)inst * hnp + h];
-                if (FAST) {                                            // outside the filter's domain: trivial bound
-                    const float sabs = fabsf(hp[2 * h]) + fabsf(hp[2 * h + 1]);
-                    if (!(sabs <= 1e18f)) u = tn;
+        float wx = 0.0f, wy = 0.0f;
+        if (wc > 0) { wx = hp[2 * wi]; wy = hp[2 * wi + 1]; } else { wi = -1; wc = 0; }
+        const float wxs = wx - fox, wys = wy - foy;
+        const bool wwild = !(fabsf(wx) + fabsf(wy) <= 1e18f);
+        const float wE = efac_ref * (fabsf(wxs) + fabsf(wys) + frad);
+        const int32_t* tab = lds_table ? s_cpre : chunk_pre + (size_t)inst * (nch + 1);
+
+        double v[kRec] = {0, 0, 0, 0, 0, 0};                            // inliers, a00, a01, a11, b0, b1
+        for (int b = b0; b * kBlockPx < nent; b += nb_grid) {
+#pragma unroll
+            for (int tl = 0; tl < 2; ++tl) {
+                const int e = b * kBlockPx + (wv * 2 + tl) * kWave + lane;
+                bool valid = e < nent;
+                const size_t slot = (size_t)inst * HW + (valid ? entry_slot(tab, nch, e) : 0);
+                const float4 q = list[slot];
+                if (valid && thin) valid = entry_kept(q, W, HW, inst, fg, max_num, seed, keep);
+                bool in;
+                if (MODE == kModeCones)
+                    in = classify_pair(recentre_constants(clist[slot], q, fox, foy), q, cones, wxs, wys, wx, wy, wE, wwild,
+                                       valid, thresh);
+                else
+                    in = valid && pair_is_inlier(q.x, q.y, q.z, q.w, sqrtf(q.z * q.z + q.w * q.w), wx, wy, thresh);
+                if (in) {
+                    const double nx = (double)q.w, ny = -(double)q.z;  // normal = (dy, -dx) :584-586
+                    const double bb = nx * (double)q.x + ny * (double)q.y;
+                    v[0] += 1.0; v[1] += nx * nx; v[2] += nx * ny; v[3] += ny * ny; v[4] += nx * bb; v[5] += ny * bb;
                 }
-                if (out_upper) out_upper[(size_t)inst * hn + h] = u;
             }
-            s_u[h] = u;
+        }
+#pragma unroll
+        for (int a = 0; a < kRec; ++a) {
+            const double r = wave_reduce_add(v[a]);
+            if (lane == 0) s_part[wv][a] = r;
         }
         __syncthreads();
-
-        const float4* P = list + (size_t)inst * HW;
-        const float4* C = clist + (size_t)inst * HW;
-        // exact inlier decision of pixel j for point (gx, gy)
-        auto accepts = [&](int j, float gx, float gy, float E, bool wild) -> bool {
-            if (FAST) return classify_pair(C[j], cones, gx, gy, E, wild, true, thresh, [&]() { return P[j]; });
-            const float4 q = P[j];
-            return pair_is_inlier(q.x, q.y, q.z, q.w, sqrtf(q.z * q.z + q.w * q.w), gx, gy, thresh);
-        };
-
-        // candidates in order (U desc, index asc), kRefK per pass, counted exactly until none left can win:
-        // torch.max's winner (largest count, first index, RV/ransac_voting_gpu.py:567)
-        int best_c = -1, best_i = 0x7fffffff, evals = 0;
-        for (;;) {
-            int cand[kRefK], nc = 0;
-#pragma unroll
-            for (int k = 0; k < kRefK; ++k) {
-                cand[k] = -1;
-                if (nc == k) {                                         // uniform
-                    int uc, ui;
-                    block_argmax_lds(s_u, hn, s_red, uc, ui);
-                    if (uc >= 0 && (best_c < 0 || uc > best_c || (uc == best_c && ui < best_i))) {
-                        cand[k] = ui; nc = k + 1;
-                        __syncthreads();
-                        if (threadIdx.x == 0) s_u[ui] = -1;            // consumed
-                        __syncthreads();
-                    }
-                }
-            }
-            if (nc == 0) break;
-            float gx[kRefK], gy[kRefK], E[kRefK];
-            bool wild[kRefK];
-            int cnt[kRefK];
-#pragma unroll
-            for (int k = 0; k < kRefK; ++k) {
-                const int ci = cand[k] < 0 ? cand[0] : cand[k];
-                gx[k] = hp[2 * ci]; gy[k] = hp[2 * ci + 1];
-                const float sabs = fabsf(gx[k]) + fabsf(gy[k]);
-                wild[k] = !(sabs <= 1e18f);
-                E[k] = efac_ref * (sabs + wh);
-                cnt[k] = 0;
-            }
-            // whole waves run the loop (the classification ballots): the tail lanes carry an inert slot
-            for (int j0 = w * kWave; j0 < tn; j0 += kRefThreads) {
-                const int j = j0 + lane;
-                const bool valid = j < tn;
-                const int jj = valid ? j : tn - 1;
-#pragma unroll
-                for (int k = 0; k < kRefK; ++k)
-                    if (k < nc) cnt[k] += (accepts(jj, gx[k], gy[k], E[k], wild[k]) && valid) ? 1 : 0;
-            }
-#pragma unroll
-            for (int k = 0; k < kRefK; ++k) {
-#pragma unroll
-                for (int o = kWave / 2; o > 0; o >>= 1) cnt[k] += __shfl_xor(cnt[k], o, kWave);
-            }
-            __syncthreads();
-            if (lane == 0) {
-#pragma unroll
-                for (int k = 0; k < kRefK; ++k) s_red[k * kRefWaves + w] = cnt[k];
-            }
-            __syncthreads();
-#pragma unroll
-            for (int k = 0; k < kRefK; ++k) {
-                if (k >= nc) continue;
-                int tot = 0;
-                for (int i = 0; i < kRefWaves; ++i) tot += s_red[k * kRefWaves + i];
-                if (tot > best_c || (tot == best_c && cand[k] < best_i)) { best_c = tot; best_i = cand[k]; }
-            }
-            evals += nc;
-            __syncthreads();
+        if (b0 * kBlockPx < nent && threadIdx.x < kRec) {               // a task without entries publishes nothing
+            const double r = s_part[0][threadIdx.x] + s_part[1][threadIdx.x] + s_part[2][threadIdx.x] + s_part[3][threadIdx.x];
+            __hip_atomic_store((gu64*)(partial + ((size_t)inst * nbx + b0) * kRec + threadIdx.x),
+                               __builtin_bit_cast(unsigned long long, r), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
-
-        // vote again with the winner, least squares over its inliers (RV/ransac_voting_gpu.py:583-599).  No hypothesis
-        // with an inlier: all_win_pts stays (0,0) (:571-574) and the refinement votes for (0,0).
-        float wx = 0.0f, wy = 0.0f;
-        if (best_c > 0) { wx = hp[2 * best_i]; wy = hp[2 * best_i + 1]; } else { best_i = -1; best_c = 0; }
-        const float wabs = fabsf(wx) + fabsf(wy);
-        const bool wwild = !(wabs <= 1e18f);
-        const float wE = efac_ref * (wabs + wh);
-        int inl = 0;
-        double v[5] = {0, 0, 0, 0, 0};                                 // a00, a01, a11, b0, b1
-        for (int j0 = w * kWave; j0 < tn; j0 += kRefThreads) {
-            const int j = j0 + lane;
-            const bool valid = j < tn;
-            const int jj = valid ? j : tn - 1;
-            if (accepts(jj, wx, wy, wE, wwild) && valid) {
-                const float4 q = P[jj];
-                const double nx = (double)q.w, ny = -(double)q.z;      // normal = (dy, -dx) :584-586
-                const double bb = nx * (double)q.x + ny * (double)q.y;
-                ++inl; v[0] += nx * nx; v[1] += nx * ny; v[2] += ny * ny; v[3] += nx * bb; v[4] += ny * bb;
-            }
-        }
-#pragma unroll
-        for (int o = kWave / 2; o > 0; o >>= 1) inl += __shfl_xor(inl, o, kWave);
-#pragma unroll
-        for (int a = 0; a < 5; ++a) {
-            const double r = wave_reduce_add(v[a]);
-            if (lane == 0) s_sum[w][a] = r;
-        }
-        if (lane == 0) s_red[w] = inl;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // the storing wave drains its sc1 stores
         __syncthreads();
         if (threadIdx.x == 0) {
-            double t[5] = {0, 0, 0, 0, 0};
-            int it = 0;
-            for (int i = 0; i < kRefWaves; ++i) {                      // fixed order: bit-reproducible
-                it += s_red[i];
-                for (int a = 0; a < 5; ++a) t[a] += s_sum[i][a];
-            }
-            double x0, x1;
-            solve2_sym(t[0], t[1], t[2], t[3], t[4], x0, x1);
-            out_xy[inst * 2] = (float)x0;
-            out_xy[inst * 2 + 1] = (float)x1;
-            if (out_tn) out_tn[inst] = tn;
-            if (out_win_idx) out_win_idx[inst] = best_i;
-            if (out_win_count) out_win_count[inst] = best_c;
-            if (out_inl) out_inl[inst] = it;
-            if (out_evals) out_evals[inst] = evals;
+            const int tk = __hip_atomic_fetch_add(&tickets[inst], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            s_last = (tk == nb_grid - 1);
         }
         __syncthreads();
+        if (!s_last) continue;                                         // uniform
+
+        // last arriver of the instance: the records in task order (independent sc1 loads, four in flight per lane)
+        if (wv == 0) {
+            const int nrec = min(nb_grid, (nent + kBlockPx - 1) / kBlockPx);
+            double tot[kRec] = {0, 0, 0, 0, 0, 0};
+            // lane = (record slot r8 = lane / 8, value a = lane % 8): eight records per sweep, then a fixed-order lane tree
+            const int a = lane & 7, r8 = lane >> 3;
+            double acc = 0.0;
+            for (int b = r8; b < nrec; b += 32) {
+                unsigned long long x[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    x[i] = (a < kRec && b + 8 * i < nrec)
+                               ? __hip_atomic_load((gu64*)(partial + ((size_t)inst * nbx + b + 8 * i) * kRec + a), __ATOMIC_RELAXED,
+                                                   __HIP_MEMORY_SCOPE_AGENT)
+                               : 0ull;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) acc += __builtin_bit_cast(double, x[i]);
+            }
+            acc += __shfl_xor(acc, 8, kWave); acc += __shfl_xor(acc, 16, kWave); acc += __shfl_xor(acc, 32, kWave);
+#pragma unroll
+            for (int i = 0; i < kRec; ++i) tot[i] = __shfl(acc, i, kWave);
+            if (lane == 0) {
+                double x0, x1;
+                solve2_sym(tot[1], tot[2], tot[3], tot[4], tot[5], x0, x1);
+                out_xy[inst * 2] = (float)x0;
+                out_xy[inst * 2 + 1] = (float)x1;
+                if (out_tn) out_tn[inst] = tn;
+                if (out_win_idx) out_win_idx[inst] = wi;
+                if (out_win_count) out_win_count[inst] = wc;
+                if (out_inl) out_inl[inst] = (int)tot[0];
+            }
+        }
     }
 }
 
@@ -792,8 +970,7 @@ extern "C" int fpc_ransac_voting_v3(const float* mask, const float* vertex, int6
                                     const int32_t* idxs, const uint8_t* keep, uint64_t seed, float inlier_thresh,
                                     int min_num, int max_num, float* out_xy, int32_t* out_tn, int32_t* out_win_idx,
                                     int32_t* out_win_count, int32_t* out_inl_count, float* out_hyp,
-                                    int32_t* out_counts, int32_t* out_upper, int32_t* out_evals, void* ws,
-                                    size_t ws_bytes, fpc_stream_t stream) {
+                                    int32_t* out_counts, void* ws, size_t ws_bytes, fpc_stream_t stream) {
     if (n < 0 || H < 1 || W < 1 || hn < 1 || hn > kMaxHn || max_num < 1) return FPC_EINVAL;
     if ((int64_t)H * W > (1 << 30)) return FPC_EINVAL;
     if (n == 0) return FPC_OK;
@@ -806,13 +983,16 @@ extern "C" int fpc_ransac_voting_v3(const float* mask, const float* vertex, int6
     hipStream_t s = (hipStream_t)stream;
     const int HW = H * W;
 
-    // 1. mask planes -> bit image (the only pass over the masks)
+    // 1. mask planes -> bit image + per-chunk compacted pixel lists (the only pass over the masks and the vote planes)
     const bool vec4 = (HW % 4 == 0) && (((uintptr_t)mask & 15) == 0);
-    const int scan_grid = (int)std::min<long long>((long long)n * w.nch, 4096);
-    if (vec4)
-        hipLaunchKernelGGL(k_vote_scan<true>, dim3(scan_grid), dim3(256), 0, s, mask, HW, w.nch, n, n_dev, w.bits, w.word_pre, w.chunk_fg);
-    else
-        hipLaunchKernelGGL(k_vote_scan<false>, dim3(scan_grid), dim3(256), 0, s, mask, HW, w.nch, n, n_dev, w.bits, w.word_pre, w.chunk_fg);
+    const bool vg4 = vec4 && W % 4 == 0 && vs_w == 1 && vs_h % 4 == 0 && vs_n % 4 == 0 && vs_c % 4 == 0 &&
+                     (((uintptr_t)vertex & 15) == 0);
+    const int scan_grid = (int)std::min<long long>((long long)n * w.nch, 8192);
+#define FPC_LAUNCH_SCAN(A, B)                                                                                            \
+    hipLaunchKernelGGL((k_vote_scan<A, B>), dim3(scan_grid), dim3(256), 0, s, mask, vertex, vs_n, vs_h, vs_w, vs_c, W, HW,  \
+                       w.nch, n, n_dev, w.bits, w.word_pre, w.chunk_fg, w.chunk_box, w.list, w.clist)
+    if (vg4) FPC_LAUNCH_SCAN(true, true); else if (vec4) FPC_LAUNCH_SCAN(true, false); else FPC_LAUNCH_SCAN(false, false);
+#undef FPC_LAUNCH_SCAN
 
     // the cones need th' = th - 1e-6 > 0; otherwise every pair takes the reference's arithmetic
     const bool fast = inlier_thresh > 2e-6f && inlier_thresh < 3.0e38f;
@@ -823,63 +1003,60 @@ extern "C" int fpc_ransac_voting_v3(const float* mask, const float* vertex, int6
         kappa1 = (float)((k1 > 0.0 ? sqrt(k1) : 0.0) / th1) * (1.0f + 1e-6f);                       // wider
         kappa2 = (th2 < 1.0 && k2 > 0.0) ? (float)(sqrt(k2) / th2) * (1.0f - 1e-6f) : 0.0f;        // narrower (0: no "sure")
     }
-    const float efac_cnt = 1e-6f * (1.0f + kappa1), efac_ref = 2e-6f * (1.0f + kappa1);
-    const float wh = (float)(W + H);
-    const int lds_table = w.nch + 1 <= 4096 ? 1 : 0;              // chunk prefix of an instance in LDS (16 KB)
+    // rounding allowance of the cones per unit of magnitude M = |gx - ox| + |gy - oy| + radius (header comment)
+    const float efac = 2e-6f * (1.0f + kappa1);
+    const int lds_table = w.nch + 1 <= 2048 ? 1 : 0;              // chunk prefix of an instance in LDS (8 KB; two in the plan)
     const size_t table_lds = lds_table ? (size_t)(w.nch + 1) * sizeof(int) : 0;
 
-    // 2. per instance: prefix, thinning, hypotheses, zeroed count row
-    hipLaunchKernelGGL(k_vote_plan, dim3(std::min(n, 2048)), dim3(1024), table_lds, s, vertex, vs_n, vs_h, vs_w, vs_c, keep, W,
-                       HW, w.nch, n, n_dev, hn, w.hnp, idxs, seed, min_num, max_num, efac_cnt, wh, lds_table, w.chunk_fg,
-                       w.chunk_pre, w.word_pre, w.bits, w.plan, w.hx, w.hy, w.eg, w.hyp, w.upper);
+    // 2. per instance: prefix, thinning, origin, hypotheses, zeroed count row and arrival ticket
+    hipLaunchKernelGGL(k_vote_plan, dim3(std::min(n, 2048)), dim3(1024), 2 * table_lds, s, keep, W, HW, w.nch, n, n_dev, hn, w.hnp,
+                       idxs, seed, min_num, max_num, efac, lds_table, w.chunk_fg, w.chunk_box, w.chunk_pre, w.word_pre, w.bits,
+                       w.chunk_preK, w.word_preK, w.bitsK, w.list, w.plan, w.hx, w.hy, w.hxs, w.hys, w.eg, w.hyp, w.upper,
+                       w.tickets);
 
-    // 3. upper bounds (exact counts when the threshold has no cone)
-    const int nb_launch = std::min(cdiv(HW, kBlockPx), cdiv(std::min(HW, max_num), kBlockPx) + 2);   // blocks per instance in the task grid
+    // 3. exact inlier counts of every hypothesis
+    const int nb_launch = std::min(w.nbx, cdiv(std::min(HW, max_num), kBlockPx) + 1);   // blocks per instance in the task grids
     const int ngroups = w.hnp / kWave;
-    // hypothesis slices: enough waves to fill the chip when there are few instances (an instance typically fills
+    // hypothesis slices: enough waves to fill the chip evenly when there are few instances (an instance typically fills
     // half of its blocks; with a device-side count the capacity n over-states the instances by ~8x)
     const long long waves_per_slice = std::max<long long>(1, (long long)(n_dev ? std::max(1, n / 8) : n) * nb_launch * 2);
-    const int s_needed = (int)std::min<long long>(ngroups, std::max<long long>(1, (6144 + waves_per_slice - 1) / waves_per_slice));
+    const int s_needed = (int)std::min<long long>(ngroups, std::max<long long>(1, (12288 + waves_per_slice - 1) / waves_per_slice));
     const int gps = cdiv(ngroups, s_needed);
     const int S = cdiv(ngroups, gps);
     const long long tasks = ((long long)n * nb_launch + 7) / 8 * 8 * S;
     const int count_grid = (int)std::min<long long>(tasks, 8192);            // a multiple of 8 either way
-    const size_t count_lds = (size_t)gps * kWave * sizeof(int) + table_lds;
-    auto launch_count = [&](int mode, int32_t* counts, int cstride, bool lists) {
+    const size_t count_lds = (size_t)gps * (kWave / 2) * sizeof(int) + table_lds;
+    static const int count_waves = getenv("FPC_COUNT_WAVES") ? atoi(getenv("FPC_COUNT_WAVES")) : 4;      // tuning aid
 #define FPC_LAUNCH_COUNT(M)                                                                                              \
-        hipLaunchKernelGGL(k_vote_count<M>, dim3(count_grid), dim3(256), count_lds, s, vertex, vs_n, vs_h, vs_w, vs_c, W, HW,  \
-                           w.nch, n, n_dev, hn, w.hnp, nb_launch, S, gps, kappa1, kappa2, efac_ref, wh, inlier_thresh, lds_table, \
-                           w.chunk_pre, w.word_pre, w.bits, w.plan, w.hx, w.hy, w.eg, counts, cstride,                    \
-                           lists ? w.list : nullptr, w.clist)
-        if (mode == kModeUpper) FPC_LAUNCH_COUNT(kModeUpper);
-        else if (mode == kModeExact) FPC_LAUNCH_COUNT(kModeExact);
-        else FPC_LAUNCH_COUNT(kModeFiltered);
+    if (count_waves >= 6) FPC_LAUNCH_COUNT2(M, 6); else if (count_waves == 5) FPC_LAUNCH_COUNT2(M, 5); else FPC_LAUNCH_COUNT2(M, 4)
+#define FPC_LAUNCH_COUNT2(M, WV)                                                                                         \
+    hipLaunchKernelGGL((k_vote_count<M, WV>), dim3(count_grid), dim3(256), count_lds, s, W, HW, w.nch, n, n_dev, hn, w.hnp,   \
+                       nb_launch, S, gps, kappa1, kappa2, inlier_thresh, max_num, seed, keep, lds_table, w.chunk_pre, w.plan,  \
+                       w.hx, w.hy, w.hxs, w.hys, w.eg, w.upper, w.list, w.clist)
+    if (fast) { FPC_LAUNCH_COUNT(kModeCones); } else { FPC_LAUNCH_COUNT(kModeReference); }
 #undef FPC_LAUNCH_COUNT
-    };
-    launch_count(fast ? kModeUpper : kModeExact, w.upper, w.hnp, true);
+#undef FPC_LAUNCH_COUNT2
 
-    // 4. winner + refinement
-    const size_t ref_lds = (size_t)w.hnp * sizeof(int);
-    if (fast)
-        hipLaunchKernelGGL(k_vote_refine<true>, dim3(std::min(n, 2048)), dim3(kRefThreads), ref_lds, s, HW, n, n_dev, hn, w.hnp,
-                           inlier_thresh, kappa1, kappa2, efac_ref, wh, w.plan, w.hyp, w.upper, w.list, w.clist, out_xy, out_tn,
-                           out_win_idx, out_win_count, out_inl_count, out_upper, out_evals);
-    else
-        hipLaunchKernelGGL(k_vote_refine<false>, dim3(std::min(n, 2048)), dim3(kRefThreads), ref_lds, s, HW, n, n_dev, hn, w.hnp,
-                           inlier_thresh, kappa1, kappa2, efac_ref, wh, w.plan, w.hyp, w.upper, w.list, w.clist, out_xy, out_tn,
-                           out_win_idx, out_win_count, out_inl_count, out_upper, out_evals);
+    // 4. winner, its inliers, refinement
+    const long long fin_tasks = (long long)n * nb_launch;
+    const int fin_grid = (int)std::min<long long>(fin_tasks, 8192);
+#define FPC_LAUNCH_FINAL(M)                                                                                              \
+    hipLaunchKernelGGL(k_vote_final<M>, dim3(fin_grid), dim3(256), table_lds, s, W, HW, w.nch, n, n_dev, hn, w.hnp, nb_launch,  \
+                       w.nbx, inlier_thresh, kappa1, kappa2, efac, max_num, seed, keep, lds_table, w.chunk_pre, w.plan, w.hyp, \
+                       w.upper, w.list, w.clist, w.tickets, w.partial, out_xy, out_tn, out_win_idx, out_win_count,         \
+                       out_inl_count)
+    if (fast) FPC_LAUNCH_FINAL(kModeCones); else FPC_LAUNCH_FINAL(kModeReference);
+#undef FPC_LAUNCH_FINAL
 
-    // diagnostics (never on the product path)
+    // diagnostics (never on the product path): copies of the hypotheses and of the count rows
     if (out_hyp) {
         hipError_t e = hipMemcpyAsync(out_hyp, w.hyp, sizeof(float) * (size_t)n * hn * 2, hipMemcpyDeviceToDevice, s);
         if (e != hipSuccess) { set_hip_error(e); return FPC_ELAUNCH; }
     }
     if (out_counts) {
-        // the exact count of EVERY hypothesis, by the same two-cone classification the refinement uses
-        // (rows past a device-side instance count are zeroed too)
-        hipError_t e = hipMemsetAsync(out_counts, 0, sizeof(int32_t) * (size_t)n * hn, s);
+        hipError_t e = hipMemcpy2DAsync(out_counts, sizeof(int32_t) * (size_t)hn, w.upper, sizeof(int32_t) * (size_t)w.hnp,
+                                        sizeof(int32_t) * (size_t)hn, (size_t)n, hipMemcpyDeviceToDevice, s);
         if (e != hipSuccess) { set_hip_error(e); return FPC_ELAUNCH; }
-        launch_count(fast ? kModeFiltered : kModeExact, out_counts, hn, false);
     }
     return check_launch();
 }

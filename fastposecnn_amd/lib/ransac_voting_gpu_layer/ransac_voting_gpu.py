@@ -13,7 +13,7 @@ Keyword-only extensions (not in the reference): `idxs` (i32 [b,hn,vn,2]) injects
 pairs, `keep` (u8/bool [b,h,w]) injects the > max_num thinning selection, `seed` fixes the
 built-in counter-based sampler (include/fpc_rng.h; default: drawn from torch's CPU generator,
 so torch.manual_seed() makes runs repeatable), `return_debug` also returns per-instance
-diagnostics (tn, win_idx, win_count, inlier_count, hyp, counts, upper, evals), `n_dev` (device i32[1]) limits the work
+diagnostics (tn, win_idx, win_count, inlier_count, hyp, counts), `n_dev` (device i32[1]) limits the work
 to the first n_dev instances of a capacity-sized batch without a host read (rows past it are left
 uninitialised).
 """
@@ -77,16 +77,13 @@ def ransac_voting_layer_v3(mask, vertex, round_hyp_num, inlier_thresh=0.999, con
                          win_count=torch.empty(b, dtype=torch.int32, device=dev),
                          inlier_count=torch.empty(b, dtype=torch.int32, device=dev),
                          hyp=torch.empty((b, hn, 2), dtype=torch.float32, device=dev),
-                         counts=torch.empty((b, hn), dtype=torch.int32, device=dev),
-                         upper=torch.empty((b, hn), dtype=torch.int32, device=dev),
-                         evals=torch.empty(b, dtype=torch.int32, device=dev))
+                         counts=torch.empty((b, hn), dtype=torch.int32, device=dev))
             nat.check(L.fpc_ransac_voting_v3(
                 nat.ptr(mask), v.data_ptr(), sn, sh, sw, sc, b, nat.ptr(n_dev), h, w, hn, nat.ptr(ii), nat.ptr(keep),
                 (seed + vi) & (2 ** 64 - 1), float(inlier_thresh), int(min_num), int(max_num), nat.ptr(xy),
                 nat.ptr(d["tn"]) if d else None, nat.ptr(d["win_idx"]) if d else None,
                 nat.ptr(d["win_count"]) if d else None, nat.ptr(d["inlier_count"]) if d else None,
                 nat.ptr(d["hyp"]) if d else None, nat.ptr(d["counts"]) if d else None,
-                nat.ptr(d["upper"]) if d else None, nat.ptr(d["evals"]) if d else None,
                 nat.ptr(ws), ws.numel(), nat.stream()), "fpc_ransac_voting_v3")
             if vn != 1:
                 out[:, vi, :] = xy

@@ -70,17 +70,16 @@ int fpc_voting_for_hypothesis(const float* direct, const float* coords, const fl
  * idxs    i32 [n,hn,2] injected pair indices, or NULL -> include/fpc_rng.h stream(seed)
  * keep    u8 [n,H,W] injected thinning selection (used only where fg > max_num), or NULL
  * out_xy  f32 [n,2]
- * optional diagnostics (NULL to skip): out_tn, out_win_idx, out_win_count,
- *         out_inl_count i32 [n]; out_hyp f32 [n,hn,2]; out_counts i32 [n,hn] (the exact inlier count of EVERY
- *         hypothesis: one extra exhaustive pass, never needed for the result); out_upper i32 [n,hn] (the filter's
- *         upper bound of each count, csrc/ransac.hip); out_evals i32 [n] (hypotheses the refinement counted exactly).
- * n_dev   NULL, or DEVICE i32[1]: only the first min(n, *n_dev) instances are processed (rows past it are
+ * optional diagnostics (NULL to skip): out_tn, out_win_idx, out_win_count, out_inl_count i32 [n];
+ *         out_hyp f32 [n,hn,2]; out_counts i32 [n,hn] (the exact inlier count of every hypothesis — the path
+ *         computes all of them; the diagnostics are copies).
+ * n_dev   NULL, or DEVICE i32[1]: only the first min(n, *n_dev) instances are processed (output rows past it are
  *         left untouched).  Lets a caller size buffers by a capacity `n` and enqueue the vote behind
  *         fpc_cc_label without reading the instance count back to the host.
- * hn      1 .. 8192.
- * ws      device workspace of at least fpc_ransac_workspace_bytes(n,H,W,hn) bytes,
- *         256-byte aligned.  Contents are scratch: nothing has to survive between calls (four stateless launches:
- *         mask scan -> per-instance plan -> upper bounds -> exact winner + refinement). */
+ * hn      1 .. 65536.
+ * ws      device workspace of at least fpc_ransac_workspace_bytes(n,H,W,hn) bytes, 256-byte aligned.  Contents
+ *         are scratch: nothing has to survive between calls (four stateless launches: mask scan + pixel lists ->
+ *         per-instance plan -> exact counts -> winner + refinement; csrc/ransac.hip). */
 size_t fpc_ransac_workspace_bytes(int n, int H, int W, int hn);
 int fpc_ransac_voting_v3(const float* mask, const float* vertex,
                          int64_t vs_n, int64_t vs_h, int64_t vs_w, int64_t vs_c,
@@ -89,7 +88,7 @@ int fpc_ransac_voting_v3(const float* mask, const float* vertex,
                          float inlier_thresh, int min_num, int max_num,
                          float* out_xy, int32_t* out_tn, int32_t* out_win_idx,
                          int32_t* out_win_count, int32_t* out_inl_count,
-                         float* out_hyp, int32_t* out_counts, int32_t* out_upper, int32_t* out_evals,
+                         float* out_hyp, int32_t* out_counts,
                          void* ws, size_t ws_bytes, fpc_stream_t stream);
 
 /* ---- class compression ------------------------------------------------------

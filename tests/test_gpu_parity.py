@@ -98,18 +98,7 @@ def _run_v3(lib, dev, mask, vertex, hn, **kw):
     return out.cpu().numpy(), [{k: v.cpu().numpy() for k, v in d.items()} for d in dbg]
 
 
-def _assert_bound(d, exact=False):
-    """The count kernel's per-hypothesis figure is an UPPER bound of the exact inlier count (csrc/ransac.hip);
-    with a threshold outside the filter's domain it is the count itself.  The refinement counts few hypotheses."""
-    live = d["tn"] > 0
-    assert (d["upper"][live] >= d["counts"][live]).all()
-    if exact:
-        assert np.array_equal(d["upper"][live], d["counts"][live])
-    assert (d["evals"][live] >= 1).all() and (d["evals"][~live] == 0).all()
-
-
-def _assert_v3_equal(out, dbg, want, wdbg, exact=False):
-    _assert_bound(dbg[0], exact)
+def _assert_v3_equal(out, dbg, want, wdbg):
     for k in ("tn", "win_idx", "win_count", "inlier_count"):
         assert np.array_equal(dbg[0][k], wdbg[0][k]), k
     assert np.array_equal(dbg[0]["hyp"], wdbg[0]["hyp"])       # same divisions, bit for bit
@@ -352,11 +341,6 @@ def test_fullsize_vote_bench_frame(lib, oracle, dev):
         assert np.array_equal(d[k], wdbg[0][k]), k
     assert np.array_equal(d["hyp"], wdbg[0]["hyp"])
     np.testing.assert_allclose(out.cpu().numpy(), want, atol=1e-4, rtol=0)
-    # the bound is tight on realistic votes: a handful of exact recounts per instance, a few pixels of slack
-    _assert_bound(d)
-    assert d["evals"].max() <= 16, d["evals"]
-    top = d["upper"][np.arange(len(d["tn"])), np.maximum(d["win_idx"], 0)] - d["win_count"]
-    assert (top >= 0).all() and top.max() <= 64, top
     # size-independent cross-check through the B1 path for the largest instance
     i = int(np.argmax(d["tn"]))
     m = agg["instance_masks"][i].bool()
@@ -378,8 +362,9 @@ def test_fullsize_vote_bench_frame(lib, oracle, dev):
 @pytest.mark.parametrize("case", ["perfect", "noise", "scaled", "parallel_mix"])
 @pytest.mark.parametrize("thresh", [0.5, 0.999, 0.99999])
 def test_v3_filter_never_changes_the_answer(lib, oracle, dev, case, thresh):
-    """k_vote_count only bounds the counts; k_vote_refine must still return exactly the winner of the
-    exhaustive vote (lowest index on ties), also on tie-heavy and ill-conditioned inputs."""
+    """The two cones of k_vote_count decide almost every pair without the reference's sqrt / divide; every count
+    (hence the winner, lowest index on ties) must still be that of the exhaustive vote, also on tie-heavy and
+    ill-conditioned inputs."""
     rng = np.random.default_rng(hash((case, thresh)) % 2 ** 32)
     H, W, n, hn = 72, 88, 3, 160
     yy, xx = np.mgrid[0:H, 0:W].astype(np.float32)
@@ -400,7 +385,6 @@ def test_v3_filter_never_changes_the_answer(lib, oracle, dev, case, thresh):
     out, dbg = _run_v3(lib, dev, mask, vertex, hn, seed=5, inlier_thresh=thresh)
     want, wdbg = oracle.ransac_voting_layer_v3(mask, xy.transpose(0, 2, 3, 1)[:, :, :, None, :], hn, seed=5,
                                                inlier_thresh=thresh, return_debug=True)
-    _assert_bound(dbg[0])
     for k in ("tn", "win_idx", "win_count", "inlier_count", "counts"):
         assert np.array_equal(dbg[0][k], wdbg[0][k]), k
     assert np.array_equal(dbg[0]["hyp"], wdbg[0]["hyp"], equal_nan=True)
@@ -414,7 +398,7 @@ def test_v3_exact_mode_for_nonpositive_threshold(lib, oracle, dev):
         out, dbg = _run_v3(lib, dev, g["mask"], vertex, 64, seed=3, inlier_thresh=th)
         want, wdbg = oracle.ransac_voting_layer_v3(g["mask"], g["xy"].transpose(0, 2, 3, 1)[:, :, :, None, :], 64,
                                                    seed=3, inlier_thresh=th, return_debug=True)
-        _assert_v3_equal(out, dbg, want, wdbg, exact=True)
+        _assert_v3_equal(out, dbg, want, wdbg)
 
 
 # ----------------------------------------------------------------------------- deferred post-network path

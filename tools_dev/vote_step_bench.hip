@@ -70,6 +70,18 @@ __global__ __launch_bounds__(256) void probe(const float* __restrict__ hx, const
                     }
                 }
                 total += acc[0];
+            } else if (KIND == 5) {
+                int cntv = 0;
+#define MF1(g, sh) { const float gx = HX[(g)], gy = HY[(g)]; int c = 0; _Pragma("unroll") for (int t = 0; t < T; ++t) { \
+                const float ss = __builtin_fmaf(a_s[t], gx, __builtin_fmaf(b_s[t], gy, c_s[t])); \
+                const float th = __builtin_fmaf(a_t[t], gx, __builtin_fmaf(b_t[t], gy, c_t[t])); \
+                c += __popcll(__builtin_amdgcn_ballot_w64(fabsf(ss) <= th)); } pk |= c << (sh); }
+#define MF(g2) { int pk = 0; MF1(2 * (g2), 0) MF1(2 * (g2) + 1, 16) \
+                asm("v_writelane_b32 %0, %1, %2" : "+v"(cntv) : "s"(pk), "n"(g2)); }
+                STEP16(MF, 0) STEP16(MF, 16)
+#undef MF
+#undef MF1
+                total += cntv;
             } else if (KIND == 3) {
                 float f = 0.f;
 #define MD(g) { const float gx = HX[(g)], gy = HY[(g)]; const float ss = __builtin_fmaf(a_s[0], gx, __builtin_fmaf(b_s[0], gy, c_s[0])); \
@@ -112,6 +124,8 @@ int main() {
         run<4, 1>("E  4 FMA + cmp->sgpr + bcnt + s_add", w, hx, hy, out);
         run<0, 1>("A  ... + v_writelane per step", w, hx, hy, out);
         run<1, 1>("B  packed x4, v_writelane per 4 steps", w, hx, hy, out);
+        run<5, 2>("F2 2 tiles/lane, cmp->sgpr, packed x2 writelane", w, hx, hy, out);
+        run<5, 4>("F4 4 tiles/lane, cmp->sgpr, packed x2 writelane", w, hx, hy, out);
         if (w <= 5) { run<2, 2>("C2 per-lane counters, 2 tiles + wave transpose", w, hx, hy, out);
                       run<2, 4>("C4 per-lane counters, 4 tiles + wave transpose", w, hx, hy, out); }
     }
