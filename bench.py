@@ -2,57 +2,63 @@
 """bench.py — end-to-end 640x480 inference throughput (img/s) + hough-vote kernel roofline.
 
     python bench.py --gpus N --steps K --warmup W
-    (N > 1: launched by the driver as `python -m torch.distributed.run --nproc-per-node N ... bench.py ...`)
 
-Workload (BASELINE.json configs[1]): ResNet18-FPN + all four heads, batch = 1 frame of 640x480
-per GPU per step, HV_NUM_OF_HYPOTHESES = 1000 (config.INFERENCE), random-init weights
-(torch.manual_seed(0)), synthetic data, f32 throughout.  One step is one pass of the hot path over
-one frame:
+N > 1: one process per GPU.  Started plainly (`python bench.py --gpus 8`) the script spawns its N ranks itself
+(fresh child processes with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set; the parent never touches a GPU and relays
+rank 0's JSON line); started under `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N` it is
+a rank.  RCCL ("nccl") carries the one collective of the path: the all-gather of per-instance pose records.
+
+Workload of the headline line (BASELINE.json configs[1]): ResNet18-FPN + all four heads, batch = 1 frame of 640x480
+per GPU per step, HV_NUM_OF_HYPOTHESES = 1000 (config.INFERENCE), random-init weights (torch.manual_seed(0)),
+synthetic data, f32 throughout.  One step is one pass of the hot path over one frame:
 
     image -> native engine (fpc_net_forward): encoder -> 4 FPN decoders -> 4 heads -> x4 upsample
              -> class compression                                           (on the synthetic image)
           -> aggregation (CC + per-instance means) -> RANSAC hough voting -> RT (on the synthetic
              post-network "vote bench" frame: 6 elliptical instances — random-init weights give no
-             usable instances)
+             usable instances; SURVEY.md 8d sanctions the fixture)
           -> [N > 1] RCCL all-gather of the per-instance pose records
 
 All inputs are resident in HBM before the timed region.  Frames are streamed with five in flight
-(fastposecnn_amd/streaming.py: consecutive frames go round-robin to four native plans on their own HIP
-streams — one per hardware compute pipe — each frame's post-network stages follow on the same stream;
-every frame completes all of its work, it is only collected four submissions later) — `--no-pipeline`
-finishes each frame before starting the next and `config.ms_per_frame_one_in_flight` reports that latency.  Weak scaling: every rank runs its own
-frame per step; `value` = N * K / max-over-ranks(time).
+(fastposecnn_amd/streaming.py: consecutive frames go round-robin to four native plans on their own HIP streams, each
+frame's post-network stages follow on the same stream; every frame completes all of its work, it is only collected
+four submissions later); `config.ms_per_frame_one_in_flight` is the latency with one frame in flight.  Weak scaling:
+every rank runs its own frames; `value` = N * B * K / max-over-ranks(time).
 
 Extra objects on the JSON line:
-  roofline      the hough-vote launch sequence (fpc_ransac_voting_v3): algorithmic bytes
-                n_instances * 12*H*W per call / HIP-event time of the call on its stream,
-                against the 8 TB/s HBM peak of MI355X_MICROARCH.md; `traffic` = PMC-measured HBM bytes
-                per launch (profiles/r01_vote_traffic.json: FETCH_SIZE doubled per the guide + WRITE_SIZE)
-  backbone      the network part: algorithmic f32 FLOP of the direct convolutions (100.1 GFLOP/frame,
-                ResNet18) / HIP-event time, against the 157.3 TFLOP/s f32 matrix-core peak
-  cpu_baseline  the same step on the host: torch-CPU backbone + the C oracle's post-network path
+  roofline          the hough-vote launch sequence (fpc_ransac_voting_v3) at the headline config: algorithmic bytes
+                    n_instances * 12*H*W per call / HIP-event time of the call on its stream, against the 8 TB/s HBM peak of
+                    MI355X_MICROARCH.md; `traffic` = PMC-measured HBM bytes per launch (profiles/r02_vote_traffic.json);
+                    `valu` = the bound that actually binds at hn = 1000: vector wave-instructions per second of the
+                    sequence (PMC SQ_INSTS_VALU of the same profile / the live time) against 1024 SIMDs x 2.4 GHz / 2
+  roofline_hn128    the same sequence at the training value hn = 128 (F/config.py:93) on a 32-frame batch (192 instances)
+  backbone          the network part: executed f32 multiply-add FLOP of the engine's plans (Winograd sites count 1/2.25)
+                    and the direct-convolution equivalent / HIP-event time, against the 157.3 TFLOP/s f32 matrix peak
+  configs.config3   BASELINE.json configs[2]: ResNet34, batch 32 per step, same pipeline (shorter timed region)
+  cpu_baseline      the same step on the host: torch-CPU backbone + the C oracle's post-network path (1 thread and all
+                    cores), three samples each
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")   # 4 frame streams + null stream, before HIP initialises (streaming.py)
 
-import torch
-
 REPO = os.path.dirname(os.path.abspath(__file__))
 if REPO not in sys.path:
     sys.path.insert(0, REPO)
 
-HBM_PEAK_GBPS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured float4 copy)
-MFMA_F32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: f32-input MFMA = f32 vector peak (155 measured)
-BACKBONE_GFLOP = {"resnet18": 2 * (11.10 + 4 * 9.70 + 0.16), "resnet34": 2 * (22.43 + 4 * 9.70 + 0.16)}   # SURVEY 7.1-6
+HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured float4 copy)
+MFMA_F32_PEAK_TFLOPS = 157.3    # MI355X_MICROARCH.md: f32-input MFMA = f32 vector peak (155 measured)
+VALU_PEAK_WAVE_INSTR_PER_S = 1024 * 2.4e9 / 2      # 1024 SIMD-32 units, a wave64 instruction issues over 2 cycles
 H, W = 480, 640
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=300)
@@ -61,71 +67,143 @@ def parse():
     ap.add_argument("--encoder", default="resnet18")
     ap.add_argument("--batch", type=int, default=1, help="frames per GPU per step (1 = BASELINE.json configs[1]; 32 = configs[2]/[3])")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-config3", action="store_true", help="skip the ResNet34 batch-32 section (configs[2])")
+    ap.add_argument("--no-hn128", action="store_true", help="skip the hn=128 / 32-frame vote roofline")
     ap.add_argument("--vote-only", action="store_true", help="time only the post-network stages (profiling aid)")
     ap.add_argument("--tune-mode", type=int, default=0, help="conv autotune objective: 0 latency, 1 latency x sqrt(chip share)")
     ap.add_argument("--net-streams", type=int, default=4, help="frame streams: native plans on their own HIP streams that take consecutive frames")
     ap.add_argument("--post-stream", action="store_true", help="run the post-network stages of all frames on one extra stream instead of the frame's own")
     ap.add_argument("--no-pipeline", action="store_true", help="finish every frame before starting the next (latency mode)")
-    return ap.parse_args()
+    ap.add_argument("--train", action="store_true", help="BASELINE.json configs[4]: train step (fwd + losses + bwd + gradient all-reduce)")
+    return ap.parse_args(argv)
 
 
-def cpu_baseline(model_cpu, image, cat_cpu, hn, inv_k):
-    """One frame on the host: torch CPU backbone (+class compression) and the oracle's C
-    restatement of aggregation / voting / RT.  Bounded: one frame, a few seconds."""
+# --------------------------------------------------------------------------------------------------- launcher
+
+def launch_ranks(n, argv):
+    """Spawn n fresh child processes (one per GPU) of this script and relay rank 0's output.  The parent has not
+    touched the GPU (no torch import yet), and nothing is exec'ed over an initialised process."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), *argv], env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    for p in procs:
+        rc = max(rc, p.wait())
+    return rc
+
+
+# --------------------------------------------------------------------------------------------------- pieces
+
+def median(xs):
+    xs = sorted(xs)
+    return xs[len(xs) // 2]
+
+
+def cpu_baseline(model_cpu, image, cat_cpu, hn, inv_k, encoder):
+    """One frame on the host, three samples each: torch CPU backbone (+ class compression) on all cores, and the
+    oracle's C restatement of aggregation / voting / RT on 1 thread (the scalar port) and on all cores (OpenMP over the
+    hypotheses).  Bounded: ~10 s."""
+    import torch
     from oracle import oracle as orc
     orc.build()
     threads = torch.get_num_threads()
+    net = []
     with torch.no_grad():
-        t0 = time.perf_counter()
-        logits = model_cpu.pure_model_forward(image)
-        model_cpu.class_compression(logits)
-        t_net = time.perf_counter() - t0
+        for _ in range(3):
+            t0 = time.perf_counter()
+            logits = model_cpu.pure_model_forward(image)
+            model_cpu.class_compression(logits)
+            net.append(time.perf_counter() - t0)
     cat_np = {k: v.numpy() for k, v in cat_cpu.items()}
-    t0 = time.perf_counter()
-    agg = orc.aggregate(cat_np)
-    vertex = agg["xy"].transpose(0, 2, 3, 1)[:, :, :, None, :]
-    xy = orc.ransac_voting_layer_v3(agg["instance_masks"], vertex, hn, seed=1)
-    orc.pose_rt(agg["quaternion"], xy[:, 0], agg["z"], inv_k)
-    t_post = time.perf_counter() - t0
-    return {"value": round(1.0 / (t_net + t_post), 4), "unit": "img/s", "cores": threads, "kind": "port",
-            "sample": f"1 frame: torch-CPU ResNet18-FPN forward + class compression on {threads} threads "
-                      f"({t_net * 1e3:.0f} ms) + oracle/fpc_oracle.c aggregation, hn={hn} voting and RT on 1 thread "
-                      f"({t_post * 1e3:.0f} ms); host has {os.cpu_count()} logical CPUs",
-            "net_ms": round(t_net * 1e3, 1), "post_ms": round(t_post * 1e3, 1)}
+
+    def post():
+        agg = orc.aggregate(cat_np)
+        vertex = agg["xy"].transpose(0, 2, 3, 1)[:, :, :, None, :]
+        xy = orc.ransac_voting_layer_v3(agg["instance_masks"], vertex, hn, seed=1)
+        orc.pose_rt(agg["quaternion"], xy[:, 0], agg["z"], inv_k)
+
+    post_t = {}
+    for label, nthr in (("1", 1), ("all", 0)):
+        used = orc.set_threads(nthr)
+        ts = []
+        for _ in range(3):
+            t0 = time.perf_counter()
+            post()
+            ts.append(time.perf_counter() - t0)
+        post_t[label] = (used, ts)
+    orc.set_threads(1)
+    t_net, t_post1, t_postn = median(net), median(post_t["1"][1]), median(post_t["all"][1])
+    return {"value": round(1.0 / (t_net + t_postn), 4), "unit": "img/s", "cores": max(threads, post_t["all"][0]), "kind": "port",
+            "sample": f"1 frame x 3 samples (medians): torch-CPU {encoder}-FPN forward + class compression on {threads} threads "
+                      f"({t_net * 1e3:.0f} ms) + oracle/fpc_oracle.c aggregation, hn={hn} voting and RT on {post_t['all'][0]} threads "
+                      f"({t_postn * 1e3:.0f} ms; 1 thread: {t_post1 * 1e3:.0f} ms); host has {os.cpu_count()} logical CPUs",
+            "net_ms": [round(t * 1e3, 1) for t in net], "post_ms_1_thread": [round(t * 1e3, 1) for t in post_t["1"][1]],
+            "post_ms_all_threads": [round(t * 1e3, 1) for t in post_t["all"][1]],
+            "value_1_thread_post": round(1.0 / (t_net + t_post1), 4)}
 
 
-def main():
-    args = parse()
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch N>1 with `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N`")
-        raise SystemExit(f"--gpus {args.gpus} does not match WORLD_SIZE {world}")
-    dev = torch.device("cuda", local_rank % max(1, torch.cuda.device_count()))    # (several ranks on one GPU only in tests)
-    torch.cuda.set_device(dev)
+def vote_roofline(model_gpu, cat, n_inst, reps, label):
+    """HIP events on the launch stream around the hough-voting call alone (its inputs produced just before)."""
+    import torch
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+    ms = []
+    for _ in range(reps):
+        with torch.no_grad():
+            agg = model_gpu.aggregate(cat)
+            ev[0].record()
+            model_gpu.hough_voting(agg)
+            ev[1].record()
+        ev[1].synchronize()
+        ms.append(ev[0].elapsed_time(ev[1]))
+    t = median(ms) * 1e-3
+    alg = n_inst * 12 * H * W
+    ach = alg / t / 1e9
+    return {"bound": "hbm", "achieved": round(ach, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBPS, 5),
+            "traffic": None, "kernel": "fpc_ransac_voting_v3 launch sequence (k_vote_scan, k_vote_plan, k_vote_count, k_vote_final)",
+            "workload": label, "algorithmic_bytes_per_launch": alg, "launch_ms": round(t * 1e3, 4)}
+
+
+def measure_copy_ceiling(dev):
+    import torch
+    try:
+        src = torch.empty(256 << 20, dtype=torch.uint8, device=dev); dst = torch.empty_like(src)
+        for _ in range(2):
+            dst.copy_(src)
+        c0, c1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        c0.record()
+        for _ in range(10):
+            dst.copy_(src)
+        c1.record(); c1.synchronize()
+        return round(10 * 2 * src.numel() / (c0.elapsed_time(c1) * 1e-3) / 1e9, 1)
+    except Exception:
+        return None
+
+
+def run_inference(args, encoder, Bq, hn, steps, warmup, world, rank, dev, want_backbone=True):
+    """The timed hot path for one (encoder, batch) configuration.  Returns a dict of measurements and the objects
+    later sections reuse."""
+    import torch
     import torch.distributed as dist
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        backend = os.environ.get("FPC_BENCH_BACKEND", "nccl")        # "gloo": lets two ranks share one GPU in a smoke test
-        dist.init_process_group(backend, **({"device_id": dev} if backend == "nccl" else {}))
-
     import fastposecnn_amd.lib as L
-    from fastposecnn_amd import config, synth, parallel, _native
-    _native.lib()      # fail loudly if the HIP library is missing
+    from fastposecnn_amd import config, synth, parallel
+    from fastposecnn_amd.streaming import FrameStreamer
 
     hp = config.INFERENCE()
     hp.RUNTIME_TIMING = False
-    hp.HV_NUM_OF_HYPOTHESES = args.hn
-    hp.ENCODER = args.encoder
+    hp.HV_NUM_OF_HYPOTHESES = hn
+    hp.ENCODER = encoder
     hp.ENGINE_TUNE_MODE = args.tune_mode
-    hp.ENGINE_SPLIT_PRECISION = bool(int(os.environ.get('FPC_SPLIT_PRECISION', '0')))      # opt-in experiment (DESIGN.md 6b)
+    hp.ENGINE_SPLIT_PRECISION = bool(int(os.environ.get('FPC_SPLIT_PRECISION', '0')))      # opt-in experiment (DESIGN.md)
     hp.ENGINE_GRAPH = bool(int(os.environ.get('FPC_ENGINE_GRAPH', '1')))      # HIP graph replay of the frame-invariant launches
     torch.manual_seed(0)
     model = L.pose_regressor.MODELS[hp.MODEL].load_from_ckpt(None, hp).eval()
     model_gpu = model.to(dev)
-    Bq = args.batch
     image = torch.stack([synth.make_image(rank * Bq + i) for i in range(Bq)])      # per-rank frames (weak scaling)
     cat_cpu, _ = synth.make_vote_batch(range(rank * Bq, rank * Bq + Bq))
     x = image.to(dev)
@@ -133,14 +211,6 @@ def main():
     n_inst = 6 * Bq                                           # vote-bench fixture: 6 instances per frame
     cap = 64 * Bq
 
-    ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
-    vote_ms = []
-
-    # Frame-streaming runtime (fastposecnn_amd/streaming.py): consecutive frames go round-robin to
-    # `--net-streams` native plans on their own HIP streams (network + post-network stages of a frame in order).
-    # Every frame does all of its work and is complete (instance count read back, tensors trimmed) when it
-    # is collected, `depth` submissions later.
-    from fastposecnn_amd.streaming import FrameStreamer
     streamer = FrameStreamer(model_gpu, net_streams=1 if args.no_pipeline else args.net_streams,
                              post_inline=not args.post_stream)
     s_net = streamer.net_streams[0]
@@ -170,15 +240,6 @@ def main():
         while pending:
             finish(pending.pop(0))
 
-    def vote_probe():
-        """HIP events around the hough-voting enqueue alone (its inputs produced just before)."""
-        with torch.no_grad():
-            agg = model_gpu.aggregate(cat)
-            ev[0].record()
-            agg = model_gpu.hough_voting(agg)
-            ev[1].record()
-        return agg
-
     def barrier():
         if world > 1:
             dist.barrier()
@@ -190,12 +251,12 @@ def main():
     for _ in range(2 * (depth + 1)):       # ... and every stream's allocator pool has seen a full pipeline of frames
         step()
     drain()
-    for _ in range(args.warmup):
+    for _ in range(warmup):
         step()
     drain()
     barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(steps):
         step()
     drain()
     barrier()
@@ -206,7 +267,7 @@ def main():
         dt = float(t.item())
 
     # per-frame latency with ONE frame in flight (not the headline number)
-    nlat = max(5, min(args.steps, 20))
+    nlat = max(5, min(steps, 20))
     torch.cuda.synchronize()
     t1 = time.perf_counter()
     for _ in range(nlat):
@@ -214,11 +275,17 @@ def main():
     torch.cuda.synchronize()
     latency_ms = (time.perf_counter() - t1) / nlat * 1e3
 
+    res = {"value": round(world * Bq * steps / dt, 3), "ms_per_step": round(dt / steps * 1e3, 4), "steps": steps, "warmup": warmup,
+           "workload": f"{encoder}-FPN + all heads, batch={Bq} 640x480 per GPU per step, {1 + depth} frames in flight on "
+                       f"{len(streamer.models)} streams, hn={hn}, {n_inst} instances per step (vote-bench fixture), random-init weights",
+           "global_batch": world * Bq, "frames_in_flight": 1 + depth, "net_streams": len(streamer.models),
+           "ms_per_frame_one_in_flight": round(latency_ms, 4)}
+
     # backbone alone: HIP events around the engine call on its stream
-    net_ms = []
-    if not args.vote_only:
+    if want_backbone and not args.vote_only:
+        net_ms = []
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        for _ in range(max(5, min(args.steps, 30))):
+        for _ in range(max(5, min(steps, 30))):
             with torch.no_grad(), torch.cuda.stream(s_net):
                 e0.record()
                 logits = model_gpu.pure_model_forward(x)
@@ -226,70 +293,134 @@ def main():
                 e1.record()
             e1.synchronize()
             net_ms.append(e0.elapsed_time(e1))
-        net_ms.sort()
+        t_net = median(net_ms) * 1e-3
+        eng = next(iter(model_gpu._engines.values()), None)
+        direct, executed, wino_share = eng.flops() if eng is not None else (0.0, 0.0, 0.0)
+        tf_exec, tf_direct = executed / t_net / 1e12, direct / t_net / 1e12
+        res["backbone"] = {"bound": "mfma", "achieved": round(tf_exec, 2), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                           "frac": round(tf_exec / MFMA_F32_PEAK_TFLOPS, 4), "ms": round(t_net * 1e3, 4),
+                           "achieved_executed": round(tf_exec, 2), "achieved_direct_equiv": round(tf_direct, 2),
+                           "executed_gflop_per_step": round(executed / 1e9, 2), "direct_gflop_per_step": round(direct / 1e9, 2),
+                           "winograd_share_of_direct_flop": round(wino_share, 3),
+                           "note": "`achieved` / `frac` price the multiply-adds the engine's current plans execute (a Winograd "
+                                   "F(2x2,3x3) site does 1/2.25 of the direct convolution's); achieved_direct_equiv divides "
+                                   "the direct-convolution FLOP by the same time"}
+    return res, dict(model=model, model_gpu=model_gpu, image=image, cat_cpu=cat_cpu, cat=cat, n_inst=n_inst, hp=hp)
 
-    # vote roofline: separate, untimed-for-throughput loop with HIP events around the vote call
-    for _ in range(max(5, min(args.steps, 30))):
-        vote_probe()
-        ev[1].synchronize()
-        vote_ms.append(ev[0].elapsed_time(ev[1]))
-    vote_ms.sort()
-    vote_t = vote_ms[len(vote_ms) // 2] * 1e-3
-    alg_bytes = n_inst * 12 * H * W
-    achieved = alg_bytes / vote_t / 1e9
-    traffic = None
-    tpath = os.path.join(REPO, "profiles", "r01_vote_traffic.json")
-    if os.path.exists(tpath) and args.hn == 1000:
-        with open(tpath) as f:
-            traffic = json.load(f).get("traffic_bytes_per_launch")
 
-    # measured device-to-device copy ceiling on this GPU (read + write bytes), beside the 8 TB/s spec
-    copy_gbps = None
-    try:
-        src = torch.empty(256 << 20, dtype=torch.uint8, device=dev); dst = torch.empty_like(src)
-        for _ in range(2):
-            dst.copy_(src)
-        c0, c1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        c0.record()
-        for _ in range(10):
-            dst.copy_(src)
-        c1.record(); c1.synchronize()
-        copy_gbps = round(10 * 2 * src.numel() / (c0.elapsed_time(c1) * 1e-3) / 1e9, 1)
-        del src, dst
-    except Exception:
-        pass
+def load_profile_json(name):
+    path = os.path.join(REPO, "profiles", name)
+    if os.path.exists(path):
+        with open(path) as f:
+            return json.load(f)
+    return None
 
+
+def main():
+    args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
+    if args.train:
+        from fastposecnn_amd import train_bench
+        return train_bench.main(args)
+
+    import torch
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} does not match WORLD_SIZE {world}")
+    if os.environ.get("FPC_BENCH_DRYRUN"):
+        # launch-path check without a GPU (tests/test_host_logic.py): rendezvous over gloo, one collective, rank 0 reports
+        import torch.distributed as dist
+        if world > 1:
+            dist.init_process_group("gloo")
+            t = torch.tensor([float(rank + 1)])
+            dist.all_reduce(t)
+            dist.barrier()
+            total = float(t.item())
+            dist.destroy_process_group()
+        else:
+            total = 1.0
+        if rank == 0:
+            print(json.dumps({"dryrun": True, "n_gpus": world, "rank_sum": total, "local_rank": local_rank,
+                              "master": os.environ.get("MASTER_ADDR")}), flush=True)
+        return
+    dev = torch.device("cuda", local_rank % max(1, torch.cuda.device_count()))    # (several ranks on one GPU only in tests)
+    torch.cuda.set_device(dev)
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        backend = os.environ.get("FPC_BENCH_BACKEND", "nccl")        # "gloo": lets two ranks share one GPU in a smoke test
+        dist.init_process_group(backend, **({"device_id": dev} if backend == "nccl" else {}))
+
+    from fastposecnn_amd import synth, _native
+    _native.lib()      # fail loudly if the HIP library is missing
+
+    res, ctx = run_inference(args, args.encoder, args.batch, args.hn, args.steps, args.warmup, world, rank, dev)
+
+    line = None
     if rank == 0:
+        roof = vote_roofline(ctx["model_gpu"], ctx["cat"], ctx["n_inst"], max(5, min(args.steps, 30)),
+                             f"batch {args.batch}, hn {args.hn}, {ctx['n_inst']} instances")
+        roof["measured_copy_GBps"] = measure_copy_ceiling(dev)
+        prof = load_profile_json("r02_vote_traffic.json") if (args.hn == 1000 and args.batch == 1) else None
+        if prof:
+            roof["traffic"] = prof.get("traffic_bytes_per_launch")
+            vinst = prof.get("valu_wave_instructions_per_launch")
+            if vinst:
+                rate = vinst / (roof["launch_ms"] * 1e-3)
+                roof["valu"] = {"bound": "valu", "achieved": round(rate / 1e9, 2), "peak": round(VALU_PEAK_WAVE_INSTR_PER_S / 1e9, 1),
+                                "unit": "G wave-instr/s", "frac": round(rate / VALU_PEAK_WAVE_INSTR_PER_S, 4),
+                                "wave_instructions_per_launch": vinst,
+                                "note": "SQ_INSTS_VALU of the four kernels (profiles/r02_vote_traffic.json, separate --pmc pass) / the "
+                                        "live launch time; peak = 1024 SIMD-32 x 2.4 GHz / 2 cycles per wave64 instruction"}
+        roof["note"] = ("HIP events on the launch stream around the whole call; at hn=1000 the sequence is VALU-bound (`valu`), "
+                        "the HBM fraction is what the metric's definition gives; traffic from profiles/r02_vote_traffic.json (PMC)")
         line = {
             "metric": "img/s end-to-end 640x480 inference; hough-vote kernel HBM GB/s vs roofline",
-            "value": round(world * Bq * args.steps / dt, 3), "unit": "img/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True,
+            "value": res["value"], "unit": "img/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": res["ms_per_step"], "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"{args.encoder}-FPN + all heads, batch={Bq} 640x480 per GPU, hn={args.hn}, "
-                                   f"{n_inst} instances/frame (vote-bench fixture), random-init weights",
-                       "global_batch": world * Bq, "parallelism": f"image-sharded dp{world}" if world > 1 else "single GPU",
-                       "vote_only": bool(args.vote_only),
-                       "frames_in_flight": 1 + depth, "net_streams": len(streamer.models),
-                       "ms_per_frame_one_in_flight": round(latency_ms, 4)},
-            "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": traffic,
-                         "kernel": "fpc_ransac_voting_v3 launch sequence (k_chunk_count .. k_count_hi .. k_refine)",
-                         "algorithmic_bytes_per_launch": alg_bytes, "measured_copy_GBps": copy_gbps, "launch_ms": round(vote_t * 1e3, 4),
-                         "note": "HIP events on the launch stream around the whole call; at hn=1000 the count "
-                                 "kernel is VALU-bound (DESIGN.md); traffic from profiles/r01_vote_traffic.json (PMC)"},
+            "config": {"workload": res["workload"], "global_batch": res["global_batch"],
+                       "parallelism": f"image-sharded dp{world}" if world > 1 else "single GPU",
+                       "vote_only": bool(args.vote_only), "frames_in_flight": res["frames_in_flight"],
+                       "net_streams": res["net_streams"], "ms_per_frame_one_in_flight": res["ms_per_frame_one_in_flight"],
+                       "post_network_input": "synthetic vote-bench fixture (SURVEY.md 8d), not the random-weight network's output"},
+            "roofline": roof,
         }
-        if net_ms:
-            t_net = net_ms[len(net_ms) // 2] * 1e-3
-            tf = Bq * BACKBONE_GFLOP.get(args.encoder, 0.0) / t_net / 1e3
-            line["backbone"] = {"bound": "mfma", "achieved": round(tf, 2), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                                "frac": round(tf / MFMA_F32_PEAK_TFLOPS, 4), "ms": round(t_net * 1e3, 4),
-                                "algorithmic_gflop_per_frame": round(BACKBONE_GFLOP.get(args.encoder, 0.0), 2),
-                                "note": "direct-convolution FLOP count; the engine runs the large 3x3 layers as "
-                                        "Winograd F(2x2,3x3) on f32 MFMA (2.25x fewer multiply-adds)"}
-        if world == 1 and not args.no_cpu_baseline:
-            one = {k: v[:1] for k, v in cat_cpu.items()}
-            line["cpu_baseline"] = cpu_baseline(model.to("cpu"), image[:1], one, args.hn,
-                                                torch.inverse(torch.from_numpy(hp.NUMPY_INTRINSICS).float()).numpy())
+        if "backbone" in res:
+            line["backbone"] = res["backbone"]
+
+    if world == 1:
+        # the training value of hn on a 32-frame batch (F/config.py:93): where the sequence is closest to its HBM bound
+        if not args.no_hn128:
+            hp128 = ctx["hp"]
+            hp128.HV_NUM_OF_HYPOTHESES = 128
+            cat32_cpu, _ = synth.make_vote_batch(range(32))
+            cat32 = {k: v.to(dev) for k, v in cat32_cpu.items()}
+            line["roofline_hn128"] = vote_roofline(ctx["model_gpu"], cat32, 6 * 32, 10, "batch 32, hn 128, 192 instances")
+            hp128.HV_NUM_OF_HYPOTHESES = args.hn
+            del cat32
+        if not args.no_cpu_baseline:
+            one = {k: v[:1] for k, v in ctx["cat_cpu"].items()}
+            line["cpu_baseline"] = cpu_baseline(ctx["model"].to("cpu"), ctx["image"][:1], one, args.hn,
+                                                torch.inverse(torch.from_numpy(ctx["hp"].NUMPY_INTRINSICS).float()).numpy(),
+                                                args.encoder)
+        if not args.no_config3 and not (args.encoder == "resnet34" and args.batch == 32):
+            del ctx
+            torch.cuda.empty_cache()
+            st = max(10, args.steps // 10)
+            r3, ctx3 = run_inference(args, "resnet34", 32, args.hn, st, max(2, args.warmup // 5), 1, 0, dev)
+            c3 = {"metric": "img/s end-to-end 640x480 inference", "value": r3["value"], "unit": "img/s",
+                  "ms_per_step": r3["ms_per_step"], "steps": r3["steps"], "warmup": r3["warmup"], "dtype": "f32",
+                  "config": {"workload": r3["workload"], "global_batch": 32, "frames_in_flight": r3["frames_in_flight"],
+                             "ms_per_step_one_in_flight": r3["ms_per_frame_one_in_flight"]}}
+            if "backbone" in r3:
+                c3["backbone"] = r3["backbone"]
+            c3["roofline"] = vote_roofline(ctx3["model_gpu"], ctx3["cat"], ctx3["n_inst"], 10, f"batch 32, hn {args.hn}, 192 instances")
+            line["configs"] = {"config3": c3}
+    if rank == 0:
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()

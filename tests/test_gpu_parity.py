@@ -357,6 +357,35 @@ def test_fullsize_vote_bench_frame(lib, oracle, dev):
         assert abs(got[cls][0] - cx) < 0.5 and abs(got[cls][1] - cy) < 0.5
 
 
+def test_config3_post_network_batch32_vs_oracle(lib, oracle, dev):
+    """BASELINE.json configs[2] post-network side: the 32-frame vote-bench batch (192 instances, per-image seeds 0..31)
+    through the model's deferred path (device-side instance count, capacity-sized buffers) against the oracle: every
+    integer output bit-exact, centres / RT within tolerance."""
+    from fastposecnn_amd import config, synth
+    hp = config.INFERENCE()
+    hp.RUNTIME_TIMING = False
+    hp.HV_NUM_OF_HYPOTHESES = 128
+    model = lib.pose_regressor.MODELS['PoseRegressor'].load_from_ckpt(None, hp).to(dev).eval()
+    cat_cpu, _ = synth.make_vote_batch(range(32))
+    cat = {k: v.to(dev) for k, v in cat_cpu.items()}
+    agg = model.post_network_finish(model.post_network_enqueue(cat, seed=77))
+    torch.cuda.synchronize()
+    oracle.set_threads(0)
+    try:
+        want = oracle.aggregate({k: v.numpy() for k, v in cat_cpu.items()})
+        wxy = oracle.ransac_voting_layer_v3(want["instance_masks"], want["xy"].transpose(0, 2, 3, 1)[:, :, :, None, :], 128, seed=77)
+    finally:
+        oracle.set_threads(1)
+    n = want["class_ids"].shape[0]
+    assert n == 192 and agg["class_ids"].shape[0] == n
+    assert np.array_equal(agg["class_ids"].cpu().numpy(), want["class_ids"])
+    assert np.array_equal(agg["sample_ids"].cpu().numpy(), want["sample_ids"])
+    assert np.array_equal(agg["instance_masks"].cpu().numpy(), want["instance_masks"])
+    np.testing.assert_allclose(agg["xy"].cpu().numpy(), wxy[:, 0], atol=1e-4, rtol=0)
+    R, T, RT = oracle.pose_rt(want["quaternion"], wxy[:, 0], want["z"], model.inv_intrinsics.cpu().numpy())
+    np.testing.assert_allclose(agg["RT"].cpu().numpy(), RT, rtol=2e-5, atol=1e-5)      # relative: |z| is ~ 6e2
+
+
 # ----------------------------------------------------------------------------- vote filter soundness
 
 @pytest.mark.parametrize("case", ["perfect", "noise", "scaled", "parallel_mix"])

@@ -269,3 +269,30 @@ def test_encoder_weights_from_local_file(tmp_path, monkeypatch, caplog):
         enc = bb.get_encoder('resnet18', weights='imagenet')
     assert enc.loaded_weights is None and "RANDOMLY initialised" in caplog.text
     assert bb.get_encoder('resnet18', weights=None).requested_weights is None
+
+
+def test_bench_launches_its_own_ranks():
+    """`python bench.py --gpus N` (the way the driver starts it) must spawn its N ranks itself: fresh child processes
+    with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set, rank 0's JSON line relayed, exit code propagated.  Dry run:
+    gloo rendezvous and one all-reduce instead of the GPU work."""
+    import json
+    import subprocess
+    env = dict(os.environ, FPC_BENCH_DRYRUN="1")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1"],
+                         env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout                       # ONE line, from rank 0 only
+    rec = json.loads(lines[0])
+    assert rec == {"dryrun": True, "n_gpus": 2, "rank_sum": 3.0, "local_rank": 0, "master": "127.0.0.1"}
+    # under an external launcher (WORLD_SIZE already set) the script is a rank, it does not spawn again
+    env1 = dict(env, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1")
+    out = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "1"], env=env1, capture_output=True,
+                         text=True, timeout=300)
+    assert out.returncode == 0 and json.loads(out.stdout.strip().splitlines()[-1])["n_gpus"] == 1
+    # a mismatch between --gpus and the launcher's world size is refused
+    out = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "4"], env=env1, capture_output=True,
+                         text=True, timeout=300)
+    assert out.returncode != 0
