@@ -40,6 +40,9 @@ _SIGNATURES = {
     "fpc_pack_pose_records": (_i, [_vp] * 9 + [_i, _i, _i, _vp, _vp]),
     "fpc_mask_iou_workspace_bytes": (_sz, [_i, _i, _i64]),
     "fpc_mask_iou": (_i, [_vp, _i, _vp, _i, _i64, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "fpc_preprocess_workspace_bytes": (_sz, [_i]),
+    "fpc_preprocess_u8": (_i, [_vp, _i, _i, _i, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double), _i, _vp, _vp,
+                               _sz, _vp]),
     "fpc_net_create": (_i, [ctypes.c_char_p, _i, _i, _i, _i, ctypes.POINTER(_vp)]),
     "fpc_net_destroy": (None, [_vp]),
     "fpc_net_set_graph": (_i, [_vp, _i]),

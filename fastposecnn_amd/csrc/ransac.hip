@@ -825,6 +825,17 @@ __global__ __launch_bounds__(256) void k_vote_final(int W, int HW, int nch, int 
         const int nent = fg;
         const float fox = (float)plan[inst * kPlanI + 3], foy = (float)plan[inst * kPlanI + 4];
         const float frad = (float)plan[inst * kPlanI + 5];
+        const bool has_px = b0 * kBlockPx < nent;                      // uniform
+        if (!has_px) {
+            // a task without entries publishes nothing: it arrives at once, and only has work if it arrives last
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                const int tk = __hip_atomic_fetch_add(&tickets[inst], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                s_last = (tk == nb_grid - 1);
+            }
+            __syncthreads();
+            if (!s_last) continue;                                     // uniform
+        }
         // winner: every task of the instance finds the same one
         int wc = -1, wi = 0x7fffffff;
         for (int h = threadIdx.x; h < hn; h += blockDim.x) {
@@ -856,6 +867,7 @@ __global__ __launch_bounds__(256) void k_vote_final(int W, int HW, int nch, int 
         const float wE = efac_ref * (fabsf(wxs) + fabsf(wys) + frad);
         const int32_t* tab = lds_table ? s_cpre : chunk_pre + (size_t)inst * (nch + 1);
 
+        if (has_px) {
         double v[kRec] = {0, 0, 0, 0, 0, 0};                            // inliers, a00, a01, a11, b0, b1
         for (int b = b0; b * kBlockPx < nent; b += nb_grid) {
 #pragma unroll
@@ -884,7 +896,7 @@ __global__ __launch_bounds__(256) void k_vote_final(int W, int HW, int nch, int 
             if (lane == 0) s_part[wv][a] = r;
         }
         __syncthreads();
-        if (b0 * kBlockPx < nent && threadIdx.x < kRec) {               // a task without entries publishes nothing
+        if (threadIdx.x < kRec) {
             const double r = s_part[0][threadIdx.x] + s_part[1][threadIdx.x] + s_part[2][threadIdx.x] + s_part[3][threadIdx.x];
             __hip_atomic_store((gu64*)(partial + ((size_t)inst * nbx + b0) * kRec + threadIdx.x),
                                __builtin_bit_cast(unsigned long long, r), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -897,6 +909,7 @@ __global__ __launch_bounds__(256) void k_vote_final(int W, int HW, int nch, int 
         }
         __syncthreads();
         if (!s_last) continue;                                         // uniform
+        }
 
         // last arriver of the instance: the records in task order (independent sc1 loads, four in flight per lane)
         if (wv == 0) {
@@ -1026,7 +1039,7 @@ extern "C" int fpc_ransac_voting_v3(const float* mask, const float* vertex, int6
     const long long tasks = ((long long)n * nb_launch + 7) / 8 * 8 * S;
     const int count_grid = (int)std::min<long long>(tasks, 8192);            // a multiple of 8 either way
     const size_t count_lds = (size_t)gps * (kWave / 2) * sizeof(int) + table_lds;
-    static const int count_waves = getenv("FPC_COUNT_WAVES") ? atoi(getenv("FPC_COUNT_WAVES")) : 4;      // tuning aid
+    static const int count_waves = getenv("FPC_COUNT_WAVES") ? atoi(getenv("FPC_COUNT_WAVES")) : 5;      // tuning aid
 #define FPC_LAUNCH_COUNT(M)                                                                                              \
     if (count_waves >= 6) FPC_LAUNCH_COUNT2(M, 6); else if (count_waves == 5) FPC_LAUNCH_COUNT2(M, 5); else FPC_LAUNCH_COUNT2(M, 4)
 #define FPC_LAUNCH_COUNT2(M, WV)                                                                                         \

@@ -22,6 +22,7 @@
  *   fpc_pack_pose_records        (none: multi-GPU gather record)
  *   fpc_mask_iou                 lib/gpu_tensor_funcs.py:386-409 (batchwise_get_2d_iou), called by lib/matching.py:264-267
  *   fpc_net_*                    lib/pose_regressor.py:709-743 (+ segmentation_models_pytorch encoder/decoder/head)
+ *   fpc_preprocess_u8            tools/dataset.py:249-262 (preprocessing_fn, transpose, / max|.|, img_as_float32)
  * The Python-side bindings a maintainer would add are shown in INTEGRATION.md.
  */
 #ifndef FPC_H_
@@ -150,6 +151,16 @@ int fpc_pack_pose_records(const int64_t* sample_ids, const int64_t* class_ids, c
 size_t fpc_mask_iou_workspace_bytes(int n1, int n2, int64_t hw);
 int fpc_mask_iou(const void* masks1, int n1, const void* masks2, int n2, int64_t hw, int elem_size,
                  float* iou, int32_t* inter, int32_t* uni, void* ws, size_t ws_bytes, fpc_stream_t stream);
+
+/* ---- input side: colour frame -> network tensor --------------------------------
+ * tools/dataset.py:249-262 on the device.  img_hwc u8 [B,H,W,3] (device, 16-byte aligned; RGB as skimage.io.imread
+ * returns it), mean3 / std3 HOST doubles (smp's preprocessing parameters of the encoder: imagenet 0.485 0.456 0.406 /
+ * 0.229 0.224 0.225), input_range_01 != 0: smp's rule "x / 255 when x.max() > 1" applies.
+ * -> out f32 [B,3,H,W] = float32( ((x [/ 255]) - mean) / std / max|.| ), all in IEEE double with one final rounding:
+ * bit-identical to the reference's numpy chain.  For B > 1: H*W % 4 == 0 and (3*H*W) % 16 == 0. */
+size_t fpc_preprocess_workspace_bytes(int B);
+int fpc_preprocess_u8(const uint8_t* img_hwc, int B, int H, int W, const double* mean3, const double* std3,
+                      int input_range_01, float* out_nchw, void* ws, size_t ws_bytes, fpc_stream_t stream);
 
 /* ---- backbone engine ----------------------------------------------------------
  * PoseRegressor.pure_model_forward + Model.class_compression for inference
