@@ -287,6 +287,34 @@ def run_inference(args, encoder, Bq, hn, steps, warmup, world, rank, dev, want_b
            "global_batch": world * Bq, "frames_in_flight": 1 + depth, "net_streams": len(streamer.models),
            "ms_per_frame_one_in_flight": round(latency_ms, 4)}
 
+    # the same pipeline fed from HOST memory: decoded u8 frames -> pinned staging -> H2D -> preprocessing kernels -> network
+    # (F/tools/dataset.py:249-262 on the device).  PCIe-inclusive, so never `value`.
+    if want_backbone and not args.vote_only and world == 1:
+        import numpy as np
+        from fastposecnn_amd.tools.dataset import FrameUploader
+        up = FrameUploader(Bq, 480, 640, device=dev, slots=depth + 2)
+        frames = np.random.default_rng(0).integers(0, 256, (Bq, 480, 640, 3), dtype=np.uint8)
+        cur = torch.cuda.current_stream(dev)
+
+        def step_host():
+            t, ready = up.upload(frames)
+            cur.wait_event(ready)
+            pending.append(streamer.submit(t, categorical_override=cat))
+            if len(pending) > depth:
+                finish(pending.pop(0))
+
+        nh = max(10, steps // 4)
+        for _ in range(depth + 3):
+            step_host()
+        drain()
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        for _ in range(nh):
+            step_host()
+        drain()
+        torch.cuda.synchronize()
+        res["host_frames_img_per_s"] = round(Bq * nh / (time.perf_counter() - t2), 2)
+
     # backbone alone: HIP events around the engine call on its stream
     if want_backbone and not args.vote_only:
         net_ms = []
@@ -392,7 +420,11 @@ def main():
                        "parallelism": f"image-sharded dp{world}" if world > 1 else "single GPU",
                        "vote_only": bool(args.vote_only), "frames_in_flight": res["frames_in_flight"],
                        "net_streams": res["net_streams"], "ms_per_frame_one_in_flight": res["ms_per_frame_one_in_flight"],
-                       "post_network_input": "synthetic vote-bench fixture (SURVEY.md 8d), not the random-weight network's output"},
+                       "post_network_input": "synthetic vote-bench fixture (SURVEY.md 8d), not the random-weight network's output",
+                       "img_per_s_from_host_u8_frames": res.get("host_frames_img_per_s"),
+                       "img_per_s_from_host_u8_frames_note": "PCIe-inclusive: pinned u8 frames -> H2D -> preprocessing kernels "
+                                                             "(tools/dataset.py:249-262 on the device) -> the same pipeline; "
+                                                             "`value` starts from tensors resident in HBM"},
             "roofline": roof,
         }
         if "backbone" in res:
@@ -421,6 +453,7 @@ def main():
             c3 = {"metric": "img/s end-to-end 640x480 inference", "value": r3["value"], "unit": "img/s",
                   "ms_per_step": r3["ms_per_step"], "steps": r3["steps"], "warmup": r3["warmup"], "dtype": "f32",
                   "config": {"workload": r3["workload"], "global_batch": 32, "frames_in_flight": r3["frames_in_flight"],
+                             "img_per_s_from_host_u8_frames": r3.get("host_frames_img_per_s"),
                              "ms_per_step_one_in_flight": r3["ms_per_frame_one_in_flight"]}}
             if "backbone" in r3:
                 c3["backbone"] = r3["backbone"]

@@ -29,13 +29,18 @@ _SIGNATURES = {
     "fpc_voting_for_hypothesis": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _f, _vp]),
     "fpc_ransac_workspace_bytes": (_sz, [_i, _i, _i, _i]),
     "fpc_ransac_voting_v3": (_i, [_vp, _vp, _i64, _i64, _i64, _i64, _i, _vp, _i, _i, _i, _vp, _vp, _u64, _f, _i, _i,
-                                  _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+                                  _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "fpc_class_compress": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     "fpc_cc_workspace_bytes": (_sz, [_i, _i, _i]),
     "fpc_cc_label": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _i, _vp, _sz, _vp]),
     "fpc_aggregate_workspace_bytes": (_sz, [_i]),
-    "fpc_aggregate": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz,
+    "fpc_aggregate": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz,
                            _vp]),
+    "fpc_post_network_backward": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _f, _i, _u64, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "fpc_vote_refine_backward": (_i, [_vp, _vp, _i64, _i64, _i64, _i64, _i, _i, _i, _vp, _f, _i, _u64, _vp, _vp, _vp]),
+    "fpc_class_compress_backward": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
+    "fpc_grad_sumsq": (_i, [_vp, _sz, _vp, _vp]),
+    "fpc_lookahead_radam_step": (_i, [_vp, _vp, _vp, _vp, _vp, _sz, _f, _f, _f, _f, _f, _i64, _i, _f, _vp, _vp]),
     "fpc_pose_rt": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp]),
     "fpc_pack_pose_records": (_i, [_vp] * 9 + [_i, _i, _i, _vp, _vp]),
     "fpc_mask_iou_workspace_bytes": (_sz, [_i, _i, _i64]),
@@ -81,7 +86,7 @@ def lib():
             fn = getattr(L, name)
             fn.restype = res
             fn.argtypes = args
-        if L.fpc_abi_version() != 4:
+        if L.fpc_abi_version() != 5:
             raise RuntimeError("fastposecnn_amd: libfpc_hip.so ABI version mismatch")
         _lib = L
     return _lib

@@ -116,7 +116,8 @@ __global__ __launch_bounds__(256) void k_agg_accum(const int32_t* __restrict__ l
 __global__ void k_agg_finalize(int N, const int32_t* __restrict__ n_dev, const double* __restrict__ sums, const int32_t* __restrict__ cnt,
                                const uint32_t* __restrict__ cls_min, const int32_t* __restrict__ sample,
                                int64_t* __restrict__ class_ids, int64_t* __restrict__ sample_ids,
-                               float* __restrict__ oq, float* __restrict__ os, float* __restrict__ oz) {
+                               float* __restrict__ oq, float* __restrict__ os, float* __restrict__ oz,
+                               float* __restrict__ stats) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (n_dev) N = min(N, *n_dev);
     if (i >= N) return;
@@ -125,6 +126,7 @@ __global__ void k_agg_finalize(int N, const int32_t* __restrict__ n_dev, const d
 #pragma unroll
     for (int a = 0; a < 4; ++a) q[a] = (float)(sums[(size_t)i * 8 + a] / c);
     float nq = sqrtf(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+    if (stats) { stats[(size_t)i * 2] = (float)cnt[i]; stats[(size_t)i * 2 + 1] = nq; }     // for the backward (train.hip)
     if (nq == 0.0f) nq = 1.0f;
 #pragma unroll
     for (int a = 0; a < 4; ++a) oq[(size_t)i * 4 + a] = q[a] / nq;
@@ -191,7 +193,7 @@ extern "C" int fpc_aggregate(const int32_t* labels, const int64_t* cat_mask, con
                              const float* xy, const float* z, int B, int H, int W, int N, const int32_t* n_dev,
                              int64_t* class_ids,
                              int64_t* sample_ids, float* inst_masks, float* oq, float* os, float* oz, float* oxy,
-                             void* ws, size_t ws_bytes, fpc_stream_t stream) {
+                             float* out_stats, void* ws, size_t ws_bytes, fpc_stream_t stream) {
     if (B < 0 || H < 1 || W < 1 || N < 0) return FPC_EINVAL;
     if (N == 0 || B == 0) return FPC_OK;
     if (B > 65535 || N > 65535) return FPC_EINVAL;
@@ -213,7 +215,7 @@ extern "C" int fpc_aggregate(const int32_t* labels, const int64_t* cat_mask, con
                        H, W, N, n_dev, w.sums,
                        w.cnt, w.cls_min, w.sample);
     hipLaunchKernelGGL(k_agg_finalize, dim3(cdiv(N, 64)), dim3(64), 0, s, N, n_dev, w.sums, w.cnt, w.cls_min, w.sample,
-                       class_ids, sample_ids, oq, os, oz);
+                       class_ids, sample_ids, oq, os, oz, out_stats);
     if (inst_masks || oxy)
         hipLaunchKernelGGL(k_agg_planes, dim3(gx, N), dim3(256), 0, s, labels, xy, w.sample, HW, n_dev, inst_masks, oxy);
     return check_launch();

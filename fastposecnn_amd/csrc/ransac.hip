@@ -799,7 +799,8 @@ __global__ __launch_bounds__(256) void k_vote_final(int W, int HW, int nch, int 
                                                     const float4* __restrict__ clist, int32_t* __restrict__ tickets,
                                                     double* __restrict__ partial, float* __restrict__ out_xy,
                                                     int32_t* __restrict__ out_tn, int32_t* __restrict__ out_win_idx,
-                                                    int32_t* __restrict__ out_win_count, int32_t* __restrict__ out_inl) {
+                                                    int32_t* __restrict__ out_win_count, int32_t* __restrict__ out_inl,
+                                                    double* __restrict__ out_refine) {
     extern __shared__ __attribute__((aligned(16))) int s_cpre[];      // [nch + 1]
     __shared__ int s_red[2 * kFinWaves];
     __shared__ int s_last;
@@ -819,6 +820,8 @@ __global__ __launch_bounds__(256) void k_vote_final(int W, int HW, int nch, int 
                 if (out_win_idx) out_win_idx[inst] = -1;
                 if (out_win_count) out_win_count[inst] = 0;
                 if (out_inl) out_inl[inst] = 0;
+                if (out_refine)
+                    for (int i = 0; i < 8; ++i) out_refine[(size_t)inst * 8 + i] = 0.0;
             }
             continue;
         }
@@ -941,6 +944,11 @@ __global__ __launch_bounds__(256) void k_vote_final(int W, int HW, int nch, int 
                 if (out_win_idx) out_win_idx[inst] = wi;
                 if (out_win_count) out_win_count[inst] = wc;
                 if (out_inl) out_inl[inst] = (int)tot[0];
+                if (out_refine) {      // what the refinement's backward needs (fpc_vote_refine_backward)
+                    double* r = out_refine + (size_t)inst * 8;
+                    r[0] = (double)wx; r[1] = (double)wy; r[2] = tot[1]; r[3] = tot[2]; r[4] = tot[3]; r[5] = tot[4];
+                    r[6] = tot[5]; r[7] = tot[0];
+                }
             }
         }
     }
@@ -983,7 +991,8 @@ extern "C" int fpc_ransac_voting_v3(const float* mask, const float* vertex, int6
                                     const int32_t* idxs, const uint8_t* keep, uint64_t seed, float inlier_thresh,
                                     int min_num, int max_num, float* out_xy, int32_t* out_tn, int32_t* out_win_idx,
                                     int32_t* out_win_count, int32_t* out_inl_count, float* out_hyp,
-                                    int32_t* out_counts, void* ws, size_t ws_bytes, fpc_stream_t stream) {
+                                    int32_t* out_counts, double* out_refine, void* ws, size_t ws_bytes,
+                                    fpc_stream_t stream) {
     if (n < 0 || H < 1 || W < 1 || hn < 1 || hn > kMaxHn || max_num < 1) return FPC_EINVAL;
     if ((int64_t)H * W > (1 << 30)) return FPC_EINVAL;
     if (n == 0) return FPC_OK;
@@ -1057,7 +1066,7 @@ extern "C" int fpc_ransac_voting_v3(const float* mask, const float* vertex, int6
     hipLaunchKernelGGL(k_vote_final<M>, dim3(fin_grid), dim3(256), table_lds, s, W, HW, w.nch, n, n_dev, hn, w.hnp, nb_launch,  \
                        w.nbx, inlier_thresh, kappa1, kappa2, efac, max_num, seed, keep, lds_table, w.chunk_pre, w.plan, w.hyp, \
                        w.upper, w.list, w.clist, w.tickets, w.partial, out_xy, out_tn, out_win_idx, out_win_count,         \
-                       out_inl_count)
+                       out_inl_count, out_refine)
     if (fast) FPC_LAUNCH_FINAL(kModeCones); else FPC_LAUNCH_FINAL(kModeReference);
 #undef FPC_LAUNCH_FINAL
 

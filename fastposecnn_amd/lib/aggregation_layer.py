@@ -44,8 +44,9 @@ class AggregationLayer(nn.Module):
             return labels, n_dev
         return labels, int(n_dev.item())
 
-    def _aggregate(self, cat_data, cm, labels, N, n_dev):
-        """Shared body: N is the exact count (n_dev None) or a capacity gated on the device by n_dev."""
+    def _aggregate(self, cat_data, cm, labels, N, n_dev, stats=None):
+        """Shared body: N is the exact count (n_dev None) or a capacity gated on the device by n_dev.
+        `stats` (f32 [N,2], optional) receives each instance's pixel count and mean-quaternion norm (training backward)."""
         dev = cm.device
         B, H, W = cm.shape
         f32 = dict(dtype=torch.float32, device=dev)
@@ -70,7 +71,7 @@ class AggregationLayer(nn.Module):
             nat.check(L.fpc_aggregate(nat.ptr(labels), nat.ptr(cm), nat.ptr(q), nat.ptr(s), nat.ptr(xy), nat.ptr(z),
                                       B, H, W, N, nat.ptr(n_dev), nat.ptr(out['class_ids']), nat.ptr(out['sample_ids']),
                                       nat.ptr(out['instance_masks']), nat.ptr(out['quaternion']),
-                                      nat.ptr(out['scales']), nat.ptr(out['z']), nat.ptr(out['xy']),
+                                      nat.ptr(out['scales']), nat.ptr(out['z']), nat.ptr(out['xy']), nat.ptr(stats),
                                       nat.ptr(ws), ws.numel(), nat.stream()), "fpc_aggregate")
         return out
 

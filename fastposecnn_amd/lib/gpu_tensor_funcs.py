@@ -109,9 +109,29 @@ def quats_2_rotation_matrix(q):
     return torch.transpose(R, dim0=-2, dim1=-1)
 
 
+def _batchwise_get_RT_autograd(q, xys, exp_zs, inv_intrinsics):
+    """The same maths (reference :204-235) in torch ops on the [n, .] tensors, for a training step: R / T / RT keep their
+    autograd edges to q, xy, z.  R is orthonormal for a unit quaternion, so inv(inv_RT) is written out: RT = [R^-T | -R^-T T]
+    with inv_R = R^T."""
+    n = q.shape[0]
+    z = exp_zs.reshape(n, 1) / 1000
+    T = (inv_intrinsics @ torch.cat([xys * z, z], dim=1).T).T
+    norm = q.norm(dim=1, keepdim=True)
+    qn = q / torch.where(norm > 0, norm, torch.ones_like(norm))
+    R = quats_2_rotation_matrix(qn)
+    inv_R = torch.inverse(R) if n else R
+    top = torch.cat([inv_R, T.unsqueeze(-1)], dim=-1)
+    bottom = torch.tensor([0, 0, 0, 1], device=q.device, dtype=q.dtype).expand((n, 1, 4))
+    inv_RT = torch.cat([top, bottom], dim=1)
+    RT = torch.inverse(inv_RT) if n else inv_RT
+    return R, T, RT
+
+
 def batchwise_get_RT(q, xys, exp_zs, inv_intrinsics):
     """q [n,4] scalar-last, xys [n,2], exp_zs [n,1], inv_intrinsics [3,3] -> R [n,3,3], T [n,3], RT [n,4,4]."""
     nat.require_gpu(q, xys, exp_zs, what="batchwise_get_RT")
+    if torch.is_grad_enabled() and (q.requires_grad or xys.requires_grad or exp_zs.requires_grad):
+        return _batchwise_get_RT_autograd(q, xys, exp_zs, inv_intrinsics.to(q.device))
     n = q.shape[0]
     dev = q.device
     R = torch.empty((n, 3, 3), dtype=torch.float32, device=dev)

@@ -288,8 +288,24 @@ class PoseRegressor(Model, torch.nn.Module):
     def forward(self, x: torch.Tensor):
         self._inv_k(x.device)
         logits = self.pure_model_forward(x)
+        if x.is_cuda and torch.is_grad_enabled() and any(v.requires_grad for v in logits.values()):
+            return self._forward_train(logits)
         categorical_data = self.class_compression(logits)
         agg_pred = self.agg_hough_and_generate_RT(categorical_data)
+        return {'logits': logits, 'categorical': categorical_data, 'aggregated': agg_pred}
+
+    def _forward_train(self, logits):
+        """The post-network stages of a training step: the inference kernels forward, csrc/train.hip backward
+        (lib/train_functions.py).  Same dict as the inference path; quaternion / scales / xy / z (+ R, T, RT) of
+        'aggregated' and the four regression planes of 'categorical' carry autograd edges to the logits."""
+        import train_functions as tf
+        categorical_data = tf.class_compression_train(self.classes, logits)
+        agg_pred = None
+        if self.HPARAM.PERFORM_AGGREGATION:
+            if not self.HPARAM.PERFORM_HOUGH_VOTING:
+                raise NotImplementedError("training with PERFORM_AGGREGATION but without PERFORM_HOUGH_VOTING: no reference "
+                                          "preset does (F/config.py:95-133)")
+            agg_pred = tf.post_network_train(self, categorical_data)
         return {'logits': logits, 'categorical': categorical_data, 'aggregated': agg_pred}
 
 

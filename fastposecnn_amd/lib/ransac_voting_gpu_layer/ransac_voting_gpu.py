@@ -31,7 +31,8 @@ def b_inv(b_mat):
 
 
 def ransac_voting_layer_v3(mask, vertex, round_hyp_num, inlier_thresh=0.999, confidence=0.99, max_iter=20,
-                           min_num=5, max_num=30000, *, idxs=None, keep=None, seed=None, return_debug=False, n_dev=None):
+                           min_num=5, max_num=30000, *, idxs=None, keep=None, seed=None, return_debug=False, n_dev=None,
+                           refine_out=None):
     """
     :param mask:      [b,h,w]   foreground where != 0
     :param vertex:    [b,h,w,vn,2]  (any strides; the permuted view of hough_voting.py:51 is read in place)
@@ -69,6 +70,9 @@ def ransac_voting_layer_v3(mask, vertex, round_hyp_num, inlier_thresh=0.999, con
                 ii = idxs[:, :, vi, :].to(device=dev, dtype=torch.int32).contiguous()
                 if tuple(ii.shape) != (b, hn, 2):
                     raise RuntimeError("ransac_voting_layer_v3: idxs must be [b,hn,vn,2]")
+            refine = None
+            if refine_out is not None:      # f64 [b,vn,8]: winner, normal equations, inlier count (training backward)
+                refine = refine_out[:, vi, :] if vn == 1 else torch.empty((b, 8), dtype=torch.float64, device=dev)
             xy = out[:, vi, :] if vn == 1 else torch.empty((b, 2), dtype=torch.float32, device=dev)
             d = None
             if return_debug:
@@ -83,10 +87,12 @@ def ransac_voting_layer_v3(mask, vertex, round_hyp_num, inlier_thresh=0.999, con
                 (seed + vi) & (2 ** 64 - 1), float(inlier_thresh), int(min_num), int(max_num), nat.ptr(xy),
                 nat.ptr(d["tn"]) if d else None, nat.ptr(d["win_idx"]) if d else None,
                 nat.ptr(d["win_count"]) if d else None, nat.ptr(d["inlier_count"]) if d else None,
-                nat.ptr(d["hyp"]) if d else None, nat.ptr(d["counts"]) if d else None,
+                nat.ptr(d["hyp"]) if d else None, nat.ptr(d["counts"]) if d else None, nat.ptr(refine),
                 nat.ptr(ws), ws.numel(), nat.stream()), "fpc_ransac_voting_v3")
             if vn != 1:
                 out[:, vi, :] = xy
+                if refine is not None:
+                    refine_out[:, vi, :] = refine
             if d:
                 dbg.append(d)
     return (out, dbg) if return_debug else out

@@ -23,6 +23,11 @@
  *   fpc_mask_iou                 lib/gpu_tensor_funcs.py:386-409 (batchwise_get_2d_iou), called by lib/matching.py:264-267
  *   fpc_net_*                    lib/pose_regressor.py:709-743 (+ segmentation_models_pytorch encoder/decoder/head)
  *   fpc_preprocess_u8            tools/dataset.py:249-262 (preprocessing_fn, transpose, / max|.|, img_as_float32)
+ *   fpc_post_network_backward    torch autograd over lib/aggregation_layer.py:119-156 + RV/ransac_voting_gpu.py:583-599
+ *   fpc_vote_refine_backward     torch autograd over RV/ransac_voting_gpu.py:583-599
+ *   fpc_class_compress_backward  torch autograd over lib/gpu_tensor_funcs.py:37-99
+ *   fpc_lookahead_radam_step     lib/pose_regressor.py:417-423 (catalyst Lookahead(RAdam)), F/train.py gradient_clip_val,
+ *                                lib/pose_regressor.py:341-415 (inf / NaN guard)
  * The Python-side bindings a maintainer would add are shown in INTEGRATION.md.
  */
 #ifndef FPC_H_
@@ -35,7 +40,7 @@
 extern "C" {
 #endif
 
-#define FPC_ABI_VERSION 4
+#define FPC_ABI_VERSION 5
 
 #define FPC_OK 0
 #define FPC_EINVAL (-1)      /* bad argument (shape, null pointer, ...) */
@@ -89,7 +94,7 @@ int fpc_ransac_voting_v3(const float* mask, const float* vertex,
                          float inlier_thresh, int min_num, int max_num,
                          float* out_xy, int32_t* out_tn, int32_t* out_win_idx,
                          int32_t* out_win_count, int32_t* out_inl_count,
-                         float* out_hyp, int32_t* out_counts,
+                         float* out_hyp, int32_t* out_counts, double* out_refine,
                          void* ws, size_t ws_bytes, fpc_stream_t stream);
 
 /* ---- class compression ------------------------------------------------------
@@ -119,13 +124,14 @@ int fpc_cc_label(const int64_t* cat_mask, int B, int H, int W,
  * or a capacity when n_dev — DEVICE i32[1], fpc_cc_label's n_out — is given: then only the first
  * min(N, *n_dev) instances are produced and the remaining rows are left untouched), categorical planes quat [B,4,HW], scales [B,3,HW], xy [B,2,HW], z [B,HW].
  * -> class_ids i64 [N], sample_ids i64 [N], inst_masks f32 [N,HW] (nullable),
- *    oq [N,4], os [N,3], oz [N], oxy f32 [N,2,HW] (nullable). */
+ *    oq [N,4], os [N,3], oz [N], oxy f32 [N,2,HW] (nullable), out_stats f32 [N,2] (nullable: pixel count and the norm
+ *    of the mean quaternion before normalisation — what fpc_post_network_backward's table is built from). */
 size_t fpc_aggregate_workspace_bytes(int N);
 int fpc_aggregate(const int32_t* labels, const int64_t* cat_mask,
                   const float* quat, const float* scales, const float* xy, const float* z,
                   int B, int H, int W, int N, const int32_t* n_dev,
                   int64_t* class_ids, int64_t* sample_ids, float* inst_masks,
-                  float* oq, float* os, float* oz, float* oxy,
+                  float* oq, float* os, float* oz, float* oxy, float* out_stats,
                   void* ws, size_t ws_bytes, fpc_stream_t stream);
 
 /* ---- pose assembly ----------------------------------------------------------
@@ -161,6 +167,36 @@ int fpc_mask_iou(const void* masks1, int n1, const void* masks2, int n2, int64_t
 size_t fpc_preprocess_workspace_bytes(int B);
 int fpc_preprocess_u8(const uint8_t* img_hwc, int B, int H, int W, const double* mean3, const double* std3,
                       int input_range_01, float* out_nchw, void* ws, size_t ws_bytes, fpc_stream_t stream);
+
+/* ---- training: backward of the post-network path, optimiser step ----------------
+ * fpc_post_network_backward: labels i32 [B,H,W] (fpc_cc_label), cat_xy f32 [B,2,H,W] (the categorical vote planes the
+ * forward aggregated), table f64 [N,16] per instance: [0..3] dL/d(pixel quaternion), [4..6] dL/d(pixel scales),
+ * [7] dL/d(pixel z) (the instance gradients chained through the mean / normalise / exp and divided by the pixel count),
+ * [8..9] lam = (sum n n^T)^-1 dL/dxy, [10..11] the refined xy, [12..13] the winning hypothesis, [14] foreground count,
+ * [15] != 0: the instance voted.  inlier_thresh / max_num / seed / keep: as in the forward fpc_ransac_voting_v3 call.
+ * -> g_q [B,4,H,W], g_s [B,3,H,W], g_xy [B,2,H,W], g_z [B,H,W]: every element written.
+ * fpc_vote_refine_backward: the vote term alone on the forward's mask [n,H,W] / vertex planes; table f64 [n,8]:
+ * lam(2), refined xy(2), winner(2), foreground count, active.  -> g_vertex f32 [n,2,H,W].
+ * fpc_ransac_voting_v3's out_refine f64 [n,8] = winner(2), a00, a01, a11, b0, b1, inliers supplies the normal equations.
+ * fpc_class_compress_backward: go_* gradients of the four categorical outputs (NULL = zero) -> dense gradients of the four
+ * logit tensors (layouts of fpc_class_compress). */
+int fpc_post_network_backward(const int32_t* labels, const float* cat_xy, int B, int H, int W, int N,
+                              const int32_t* n_dev, const double* table, float inlier_thresh, int max_num,
+                              uint64_t seed, const uint8_t* keep, float* g_q, float* g_s, float* g_xy, float* g_z,
+                              fpc_stream_t stream);
+int fpc_vote_refine_backward(const float* mask, const float* vertex, int64_t vs_n, int64_t vs_h, int64_t vs_w,
+                             int64_t vs_c, int n, int H, int W, const double* table, float inlier_thresh, int max_num,
+                             uint64_t seed, const uint8_t* keep, float* g_vertex, fpc_stream_t stream);
+int fpc_class_compress_backward(const int64_t* cat_mask, const float* quat, const float* xy, const float* go_q,
+                                const float* go_s, const float* go_xy, const float* go_z, int B, int C, int HW,
+                                float* g_q, float* g_s, float* g_xy, float* g_z, fpc_stream_t stream);
+/* out2 f64 [2] (caller zeroes): [0] += sum g^2, [1] += 1 when a non-finite element was seen.  g 16-byte aligned. */
+int fpc_grad_sumsq(const float* g, size_t n, double* out2, fpc_stream_t stream);
+/* One Lookahead(RAdam) step on a flat f32 shard (p, g, m, v, slow: n elements each; step counts from 1).
+ * ctl (device f32[2] or NULL): [0] multiplies every gradient (clip coefficient / world size), [1] != 0 skips the step. */
+int fpc_lookahead_radam_step(float* p, const float* g, float* m, float* v, float* slow, size_t n, float lr, float beta1,
+                             float beta2, float eps, float weight_decay, int64_t step, int la_k, float la_alpha,
+                             const float* ctl, fpc_stream_t stream);
 
 /* ---- backbone engine ----------------------------------------------------------
  * PoseRegressor.pure_model_forward + Model.class_compression for inference

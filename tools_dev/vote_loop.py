@@ -29,7 +29,7 @@ st = torch.cuda.current_stream().cuda_stream
 
 def vote(seed):
     nat.check(lib.fpc_ransac_voting_v3(mask.data_ptr(), vertex.data_ptr(), sn, sh, sw, sc, n, None, H, W, a.hn, None, None,
-                                       seed, 0.999, 5, 30000, out.data_ptr(), None, None, None, None, None, None,
+                                       seed, 0.999, 5, 30000, out.data_ptr(), None, None, None, None, None, None, None,
                                        ws.data_ptr(), ws.numel(), st), "vote")
 
 for i in range(20):
