@@ -61,8 +61,8 @@ H, W = 480, 640
 def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=300)
-    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=None, help="timed steps (default 300; 20 with --train)")
+    ap.add_argument("--warmup", type=int, default=None, help="untimed warm-up steps (default 20; 3 with --train)")
     ap.add_argument("--hn", type=int, default=1000, help="HV_NUM_OF_HYPOTHESES (1000 = config.INFERENCE)")
     ap.add_argument("--encoder", default="resnet18")
     ap.add_argument("--batch", type=int, default=1, help="frames per GPU per step (1 = BASELINE.json configs[1]; 32 = configs[2]/[3])")
@@ -74,8 +74,15 @@ def parse(argv=None):
     ap.add_argument("--net-streams", type=int, default=4, help="frame streams: native plans on their own HIP streams that take consecutive frames")
     ap.add_argument("--post-stream", action="store_true", help="run the post-network stages of all frames on one extra stream instead of the frame's own")
     ap.add_argument("--no-pipeline", action="store_true", help="finish every frame before starting the next (latency mode)")
-    ap.add_argument("--train", action="store_true", help="BASELINE.json configs[4]: train step (fwd + losses + bwd + gradient all-reduce)")
-    return ap.parse_args(argv)
+    ap.add_argument("--train", action="store_true", help="BASELINE.json configs[4]: train step (fwd + losses + bwd + gradient reduction + optimiser)")
+    ap.add_argument("--train-batch", type=int, default=8, help="frames per GPU per training step (8 x 8 GPUs = configs[4]'s 64)")
+    ap.add_argument("--bucket-mb", type=float, default=16.0, help="gradient bucket size of the training step")
+    args = ap.parse_args(argv)
+    if args.steps is None:
+        args.steps = 20 if args.train else 300
+    if args.warmup is None:
+        args.warmup = 3 if args.train else 20
+    return args
 
 
 # --------------------------------------------------------------------------------------------------- launcher

@@ -36,6 +36,7 @@ _SIGNATURES = {
     "fpc_aggregate_workspace_bytes": (_sz, [_i]),
     "fpc_aggregate": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz,
                            _vp]),
+    "fpc_pose_errors": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp]),
     "fpc_post_network_backward": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _f, _i, _u64, _vp, _vp, _vp, _vp, _vp, _vp]),
     "fpc_vote_refine_backward": (_i, [_vp, _vp, _i64, _i64, _i64, _i64, _i, _i, _i, _vp, _f, _i, _u64, _vp, _vp, _vp]),
     "fpc_class_compress_backward": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),

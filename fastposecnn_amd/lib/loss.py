@@ -228,6 +228,31 @@ class ZLoss(_Loss):
         return self.loss_func(torch.log(gt_pred_matches[self.key][0]), torch.log(gt_pred_matches[self.key][1]))
 
 
+class _PoseLoss(_Loss):
+    """Losses over the assembled poses (F/lib/loss.py:546-626): NaN without matches, NaN-filtered mean."""
+
+    def __init__(self, eps=0.1):
+        super().__init__()
+        self.eps = eps
+
+    def forward(self, gt_pred_matches):
+        if gt_pred_matches is None or 'RT' not in gt_pred_matches.keys():
+            return _nan(gt_pred_matches)
+        return _mean_without_nan(self.pair_loss(gt_pred_matches))
+
+
+class Iou3dLoss(_PoseLoss):
+
+    def pair_loss(self, m):
+        return 1 - gtf.get_3d_ious(m['RT'][0], m['RT'][1], m['scales'][0], m['scales'][1])
+
+
+class OffsetLoss(_PoseLoss):
+
+    def pair_loss(self, m):
+        return gtf.from_RTs_get_T_offset_errors(m['RT'][0], m['RT'][1]) / 10
+
+
 def head_training_criterion(xy_loss_type='L2', z_loss_type='L2', scales_loss_type='L2'):
     """The criterion table of F/train.py:159-187 (D = where the inputs come from, weight = the factor in the task sum)."""
     return {

@@ -1,0 +1,197 @@
+"""Data-parallel training step across the GPUs of one node (BASELINE config 5; SURVEY.md 8e "Training").
+
+The reference delegates this to Lightning's DDP (F/config.py:60, F/train.py:316-327): NCCL all-reduce of every gradient
+bucket, then every rank runs the whole Lookahead(RAdam) step on all 18.7 M parameters.  Here the same mathematics is laid
+out for xGMI, which is point-to-point and per-link bound:
+
+    backward  ->  per bucket, as soon as its last gradient has been accumulated:  reduce-scatter (RCCL, side stream)
+    step      ->  every rank owns 1/world of each bucket: gradient norm of its shards (one scalar all-reduce), then ONE
+                  native Lookahead(RAdam) launch per shard with clip coefficient, 1/world and the inf/NaN guard folded in
+                  as device scalars (csrc/train.hip) — optimiser state and work are 1/world per rank
+              ->  all-gather of the updated parameters, in place in the flat parameter buffer
+
+reduce-scatter + all-gather move the same bytes as an all-reduce; the optimiser runs once per element instead of `world`
+times, and its state (m, v, slow weights: 3 x 74.7 MB for ResNet18-FPN) is sharded.  Parameters and gradients live in two
+flat f32 buffers (bucket-contiguous, each bucket padded to world x 4 elements): `p.data` / `p.grad` are views, so the
+collectives and the optimiser see contiguous memory and no per-step flatten / unflatten copy exists.
+No host synchronisation inside a step: the clip coefficient and the skip flag stay on the device.
+"""
+import math
+
+import torch
+import torch.distributed as dist
+
+
+class ShardedLookaheadRAdam:
+
+    def __init__(self, model, lr=1e-5, betas=(0.9, 0.999), eps=1e-8, weight_decay=3e-4, la_k=5, la_alpha=0.5,
+                 clip_norm=0.15, bucket_mb=16.0, group=None, step_fn=None):
+        """lr / weight_decay: F/config.py:56-57; clip_norm: F/train.py `gradient_clip_val`; la_k / la_alpha / betas / eps:
+        catalyst's defaults (F/lib/pose_regressor.py:420-423).  `step_fn(p, g, m, v, slow, step, ctl)`: replaces the native
+        kernel (CPU tests only; without it CPU parameters are refused — there is no CPU fallback)."""
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.backend = dist.get_backend(group) if dist.is_initialized() else None
+        self.hp = dict(lr=lr, beta1=betas[0], beta2=betas[1], eps=eps, weight_decay=weight_decay, la_k=la_k, la_alpha=la_alpha)
+        self.clip_norm = clip_norm
+        self.step_count = 0
+        self.step_fn = step_fn
+        params = [p for p in model.parameters() if p.requires_grad]
+        if not params:
+            raise ValueError("no trainable parameters")
+        self.device = params[0].device
+        if self.device.type != "cuda" and step_fn is None:
+            raise RuntimeError("fastposecnn_amd: the optimiser step is a HIP kernel; parameters must be on a GPU")
+        # buckets in reverse registration order (~ the order backward produces gradients)
+        quantum = 4 * self.world
+        limit = int(bucket_mb * (1 << 20) / 4)
+        self.buckets = []                  # dicts: params, offset (in the flat buffers), numel (padded)
+        cur, cur_n = [], 0
+        for p in reversed(params):
+            cur.append(p)
+            cur_n += p.numel()
+            if cur_n >= limit:
+                self.buckets.append({"params": cur, "raw": cur_n})
+                cur, cur_n = [], 0
+        if cur:
+            self.buckets.append({"params": cur, "raw": cur_n})
+        off = 0
+        for b in self.buckets:
+            b["offset"] = off
+            b["numel"] = (b["raw"] + quantum - 1) // quantum * quantum
+            off += b["numel"]
+        self.total = off
+        f32 = dict(dtype=torch.float32, device=self.device)
+        self.flat_p = torch.zeros(self.total, **f32)
+        self.flat_g = torch.zeros(self.total, **f32)
+        shard_total = self.total // self.world
+        self.m = torch.zeros(shard_total, **f32)
+        self.v = torch.zeros(shard_total, **f32)
+        self.slow = torch.zeros(shard_total, **f32)
+        self.g_shard = torch.zeros(shard_total, **f32) if self.world > 1 else None
+        soff = 0
+        self._hooks = []
+        for bi, b in enumerate(self.buckets):
+            o = b["offset"]
+            for p in b["params"]:
+                n = p.numel()
+                if p.dtype != torch.float32:
+                    raise TypeError("f32 parameters only")
+                view = self.flat_p[o:o + n].view_as(p)
+                view.copy_(p.data)
+                p.data = view
+                p.grad = self.flat_g[o:o + n].view_as(p)
+                self._hooks.append(p.register_post_accumulate_grad_hook(self._make_hook(bi)))
+                o += n
+            b["shard"] = b["numel"] // self.world
+            b["shard_offset"] = soff
+            soff += b["shard"]
+            b["pending"] = len(b["params"])
+            b["launched"] = False
+        self.comm_stream = torch.cuda.Stream(device=self.device) if self.device.type == "cuda" else None
+        self.stat = torch.zeros(2, dtype=torch.float64, device=self.device)
+        self.ctl = torch.zeros(2, **f32)
+        self.skipped = torch.zeros(1, dtype=torch.int64, device=self.device)     # steps dropped by the inf / NaN guard
+
+    # ---- backward-time reduction -------------------------------------------------------------------------------
+    def _make_hook(self, bi):
+        def hook(_p):
+            b = self.buckets[bi]
+            b["pending"] -= 1
+            if b["pending"] == 0:
+                self._reduce_bucket(b)
+        return hook
+
+    def _bucket_grad(self, b):
+        return self.flat_g[b["offset"]:b["offset"] + b["numel"]]
+
+    def _bucket_param(self, b):
+        return self.flat_p[b["offset"]:b["offset"] + b["numel"]]
+
+    def _reduce_bucket(self, b):
+        b["launched"] = True
+        if self.world == 1:
+            return
+        g = self._bucket_grad(b)
+        out = self.g_shard[b["shard_offset"]:b["shard_offset"] + b["shard"]]
+        if self.backend == "gloo":          # gloo has no reduce-scatter: all-reduce and keep the own shard (tests only)
+            dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.group)
+            out.copy_(g[self.rank * b["shard"]:(self.rank + 1) * b["shard"]])
+        elif self.comm_stream is not None:
+            self.comm_stream.wait_stream(torch.cuda.current_stream(self.device))
+            with torch.cuda.stream(self.comm_stream):
+                dist.reduce_scatter_tensor(out, g, op=dist.ReduceOp.SUM, group=self.group)
+        else:
+            dist.reduce_scatter_tensor(out, g, op=dist.ReduceOp.SUM, group=self.group)
+
+    def zero_grad(self):
+        self.flat_g.zero_()
+        for b in self.buckets:
+            b["pending"] = len(b["params"])
+            b["launched"] = False
+            for p in b["params"]:           # a caller's zero_grad(set_to_none=True) must not detach the views
+                if p.grad is None or p.grad.data_ptr() < self.flat_g.data_ptr() or \
+                        p.grad.data_ptr() >= self.flat_g.data_ptr() + 4 * self.total:
+                    raise RuntimeError("a parameter's .grad no longer aliases the flat gradient buffer: use "
+                                       "ShardedLookaheadRAdam.zero_grad(), not zero_grad(set_to_none=True)")
+
+    # ---- the step -----------------------------------------------------------------------------------------------
+    def _shard_views(self, b):
+        so, sh = b["shard_offset"], b["shard"]
+        p = self._bucket_param(b)[self.rank * sh:(self.rank + 1) * sh]
+        g = self.g_shard[so:so + sh] if self.world > 1 else self._bucket_grad(b)
+        return p, g, self.m[so:so + sh], self.v[so:so + sh], self.slow[so:so + sh]
+
+    def step(self):
+        for b in self.buckets:              # heads without a gradient this step (no matched instance): zeros
+            if not b["launched"]:
+                self._reduce_bucket(b)
+        if self.comm_stream is not None:
+            torch.cuda.current_stream(self.device).wait_stream(self.comm_stream)
+        self.step_count += 1
+        # gradient norm of the SUMMED gradients -> clip coefficient of the MEAN gradients, all on the device
+        self.stat.zero_()
+        native = self.device.type == "cuda" and self.step_fn is None
+        if native:
+            from fastposecnn_amd import _native as nat
+            L = nat.lib()
+        for b in self.buckets:
+            _, g, _, _, _ = self._shard_views(b)
+            if native:
+                with torch.cuda.device(self.device):
+                    nat.check(L.fpc_grad_sumsq(nat.ptr(g), g.numel(), nat.ptr(self.stat), nat.stream()), "fpc_grad_sumsq")
+            else:
+                self.stat[0] += (g.double() ** 2).sum()
+                self.stat[1] += (~torch.isfinite(g)).sum()
+        if self.world > 1:
+            dist.all_reduce(self.stat, op=dist.ReduceOp.SUM, group=self.group)
+        norm = torch.sqrt(self.stat[0]) / self.world
+        bad = (self.stat[1] != 0) | ~torch.isfinite(norm)
+        coef = torch.clamp(self.clip_norm / (norm + 1e-6), max=1.0) if self.clip_norm else torch.ones_like(norm)
+        self.ctl[0] = (coef / self.world).float()
+        self.ctl[1] = bad.float()
+        self.skipped += bad.long()
+        hp = self.hp
+        for b in self.buckets:
+            p, g, m, v, slow = self._shard_views(b)
+            if native:
+                with torch.cuda.device(self.device):
+                    nat.check(L.fpc_lookahead_radam_step(nat.ptr(p), nat.ptr(g), nat.ptr(m), nat.ptr(v), nat.ptr(slow), p.numel(),
+                                                         hp["lr"], hp["beta1"], hp["beta2"], hp["eps"], hp["weight_decay"],
+                                                         self.step_count, hp["la_k"], hp["la_alpha"], nat.ptr(self.ctl),
+                                                         nat.stream()), "fpc_lookahead_radam_step")
+            else:
+                self.step_fn(p, g, m, v, slow, self.step_count, self.ctl, hp)
+        if self.world > 1:
+            for b in self.buckets:
+                p = self._shard_views(b)[0]
+                dist.all_gather_into_tensor(self._bucket_param(b), p, group=self.group)
+        return norm
+
+    def grad_norm_and_flag(self):
+        """(norm of the mean gradient, non-finite flag) of the last step — device tensors, no synchronisation."""
+        return torch.sqrt(self.stat[0]) / self.world, self.stat[1] != 0
+
+    def state_bytes(self):
+        return 4 * (self.m.numel() + self.v.numel() + self.slow.numel())

@@ -23,6 +23,7 @@
  *   fpc_mask_iou                 lib/gpu_tensor_funcs.py:386-409 (batchwise_get_2d_iou), called by lib/matching.py:264-267
  *   fpc_net_*                    lib/pose_regressor.py:709-743 (+ segmentation_models_pytorch encoder/decoder/head)
  *   fpc_preprocess_u8            tools/dataset.py:249-262 (preprocessing_fn, transpose, / max|.|, img_as_float32)
+ *   fpc_pose_errors              lib/gpu_tensor_funcs.py:411-476, 486-547, 563-565 (degree error, 3-D IoU, offset error)
  *   fpc_post_network_backward    torch autograd over lib/aggregation_layer.py:119-156 + RV/ransac_voting_gpu.py:583-599
  *   fpc_vote_refine_backward     torch autograd over RV/ransac_voting_gpu.py:583-599
  *   fpc_class_compress_backward  torch autograd over lib/gpu_tensor_funcs.py:37-99
@@ -167,6 +168,18 @@ int fpc_mask_iou(const void* masks1, int n1, const void* masks2, int n2, int64_t
 size_t fpc_preprocess_workspace_bytes(int B);
 int fpc_preprocess_u8(const uint8_t* img_hwc, int B, int H, int W, const double* mean3, const double* std3,
                       int input_range_01, float* out_nchw, void* ws, size_t ws_bytes, fpc_stream_t stream);
+
+/* ---- evaluation maths on matched pairs (lib/gpu_tensor_funcs.py:411-476, 486-547, 563-565) ----------------------
+ * One launch for n (ground truth, prediction) pairs; every output is optional (NULL skips it and its inputs).
+ * out_degree f64 [n]: get_raw_quat_distance (computed in f32) where symmetric_ids[i] == 0 or symmetric_ids is NULL,
+ *   else get_symmetric_quat_distance over the nrot rotations rot f32 [nrot,4] (quat_symmetric_tf's table), in f64.
+ *   Pair order is the input order (the Python wrapper applies the reference's non-symmetric-first concatenation).
+ * out_iou3d f32 [n]: get_asymmetric_3d_iou(RT1, RT2, scales1, scales2), RT f32 [n,4,4], scales f32 [n,3].
+ * out_offset f32 [n]: |T1 - T2| * 10, T f32 [n,3]. */
+int fpc_pose_errors(const float* q0, const float* q1, const int64_t* symmetric_ids, const float* rot, int nrot,
+                    const float* RT1, const float* RT2, const float* scales1, const float* scales2,
+                    const float* T1, const float* T2, int n, double* out_degree, float* out_iou3d, float* out_offset,
+                    fpc_stream_t stream);
 
 /* ---- training: backward of the post-network path, optimiser step ----------------
  * fpc_post_network_backward: labels i32 [B,H,W] (fpc_cc_label), cat_xy f32 [B,2,H,W] (the categorical vote planes the

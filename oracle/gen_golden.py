@@ -429,9 +429,123 @@ def gen_matching(ref, rng):
     print("matching:", {k: tuple(v.shape) for k, v in out.items()}, "| nan case rows:", out2["class_ids"].tolist())
 
 
+def gen_eval_and_losses(ref):
+    """SURVEY 8f rank 2 + the matched losses of rank 4, from the reference's own functions on one synthetic set of matched
+    pairs: gpu_tensor_funcs.get_quat_distance (raw / symmetric / mixed), get_3d_ious, from_Ts_get_offset_error,
+    from_RTs_get_T_offset_errors, calculate_aps, calculate_complex_aps; loss.QLoss / XYLoss / ZLoss / ScalesLoss / RLoss /
+    TLoss / Iou3dLoss / OffsetLoss / CE / CCE with their input gradients.  loss.Focal needs pytorch_toolbelt (absent) and
+    is not pinned.  Own RNG: the older fixtures do not change when this one is added."""
+    torch = ref.torch
+    gtf = ref.gtf
+    rng = np.random.default_rng(20261004)
+    _stub("matplotlib"); sys.modules["matplotlib"].pyplot = _stub("matplotlib.pyplot")
+    foc = _stub("pytorch_toolbelt.losses.focal", FocalLoss=object)
+    sys.modules["pytorch_toolbelt.losses"].focal = foc
+    import loss as ref_loss
+    n = 11
+    f32 = lambda a: np.asarray(a, np.float32)
+
+    def poses(seed):
+        r = np.random.default_rng(seed)
+        q = r.normal(size=(n, 4)); q /= np.linalg.norm(q, axis=1, keepdims=True)
+        xy = r.uniform(50, 590, (n, 2)); z = r.uniform(600, 1500, (n, 1)); sc = r.uniform(0.08, 0.6, (n, 3))
+        return f32(q), f32(xy), f32(z), f32(sc)
+
+    q0, xy0, z0, s0 = poses(1)
+    dq, dxy, dz, ds = poses(2)
+    q1 = q0 + 0.25 * dq; q1 /= np.linalg.norm(q1, axis=1, keepdims=True)
+    q1[3] = -q0[3]                                   # antipodal pair: zero distance through the |q0 + q1| branch
+    xy1 = xy0 + f32(rng.normal(0, 6, (n, 2))); z1 = z0 * f32(rng.uniform(0.9, 1.1, (n, 1))); s1 = s0 * f32(rng.uniform(0.8, 1.25, (n, 3)))
+    K = np.array([[577.5, 0, 319.5], [0., 577.5, 239.5], [0., 0., 1.]])
+    inv_k = torch.inverse(torch.from_numpy(K).float())
+    t = torch.from_numpy
+    R0, T0, RT0 = gtf.batchwise_get_RT(t(q0), t(xy0), t(z0), inv_k)
+    R1, T1, RT1 = gtf.batchwise_get_RT(t(f32(q1)), t(xy1), t(z1), inv_k)
+    sym = np.asarray([0, 1, 0, 2, 0, 1, 0, 0, 1, 0, 2], np.int64)
+    cls = np.asarray([1, 1, 2, 2, 3, 3, 1, 4, 4, 5, 6], np.int64)
+    out = {"q0": q0, "q1": f32(q1), "xy0": xy0, "xy1": xy1, "z0": z0, "z1": z1, "s0": s0, "s1": s1, "sym": sym, "cls": cls,
+           "R0": R0.numpy(), "T0": T0.numpy(), "RT0": RT0.numpy(), "R1": R1.numpy(), "T1": T1.numpy(), "RT1": RT1.numpy()}
+    tq0, tq1 = t(q0), t(f32(q1))
+    out["deg_mixed"] = gtf.get_quat_distance(tq0, tq1, t(sym)).numpy()
+    out["deg_raw"] = gtf.get_quat_distance(tq0, tq1).numpy()
+    out["deg_sym"] = gtf.get_symmetric_quat_distance(tq0, tq1).numpy()
+    out["deg_all_sym"] = gtf.get_quat_distance(tq0, tq1, torch.ones(n, dtype=torch.int64)).numpy()
+    out["deg_none_sym"] = gtf.get_quat_distance(tq0, tq1, torch.zeros(n, dtype=torch.int64)).numpy()
+    out["iou3d"] = gtf.get_3d_ious(RT0, RT1, t(s0), t(s1)).numpy()
+    out["iou3d_self"] = gtf.get_3d_ious(RT0, RT0, t(s0), t(s0)).numpy()
+    out["offset"] = gtf.from_Ts_get_offset_error(T0, T1).numpy()
+    out["offset_rt"] = gtf.from_RTs_get_T_offset_errors(RT0, RT1).numpy()
+    rot, _ = gtf.quat_symmetric_tf(tq1[:2], tq0[:2])
+    out["sym_tf_first2"] = rot.numpy()
+    # calculate_aps / calculate_complex_aps as evaluate.py:205-330 drives them
+    raw = {"degree_error": {}, "3d_iou": {}, "offset_error": {}}
+    deg_pp = torch.from_numpy(np.where(sym == 0, out["deg_raw"], out["deg_sym"]))
+    for c in np.unique(cls):
+        i = torch.from_numpy(np.where(cls == c)[0])
+        raw["degree_error"][int(c)] = deg_pp[i]
+        raw["3d_iou"][int(c)] = torch.from_numpy(out["iou3d"])[i] * 100
+        raw["offset_error"][int(c)] = torch.from_numpy(out["offset"])[i]
+    raw["degree_error"][1][0] = float("nan")        # NaNs are dropped per class
+    thr = {"degree_error": torch.tensor([5., 10., 30., 60.]), "3d_iou": torch.tensor([1., 10., 25., 50.]),
+           "offset_error": torch.tensor([5., 10., 50., 200.])}
+    ops = {"degree_error": torch.less, "3d_iou": torch.greater, "offset_error": torch.less}
+    aps = gtf.calculate_aps(raw, thr, ops)
+    for k in aps:
+        for c, v in aps[k].items():
+            out[f"aps_{k}_{c}"] = v.numpy()
+    raw2 = {k: {c: torch.nan_to_num(v.double(), nan=1e9) for c, v in d.items()} for k, d in raw.items()}
+    cthr = {"degree_error+offset_error": torch.vstack((torch.tensor([5, 10, 60]), torch.tensor([5, 50, 200])))}
+    caps = gtf.calculate_complex_aps(raw2, cthr, ops)
+    for c, v in caps["degree_error+offset_error"].items():
+        out[f"caps_{c}"] = v.numpy()
+    for k, d in raw.items():
+        for c, v in d.items():
+            out[f"raw_{k}_{c}"] = v.numpy()
+
+    # matched losses with gradients w.r.t. the prediction
+    def matched(pred_req):
+        m = {"instance_masks": torch.zeros((2, n, 2, 2)), "symmetric_ids": t(sym), "class_ids": t(cls)}
+        leaves = {}
+        for key, a, b in (("quaternion", q0, f32(q1)), ("xy", xy0, xy1), ("z", z0, z1), ("scales", s0, s1),
+                          ("R", R0.numpy(), R1.numpy()), ("T", T0.numpy(), T1.numpy()), ("RT", RT0.numpy(), RT1.numpy())):
+            p = t(np.ascontiguousarray(b)).clone().requires_grad_(pred_req)
+            leaves[key] = p
+            m[key] = torch.stack((t(np.ascontiguousarray(a)), p))
+        return m, leaves
+
+    for name, fn in (("QLoss", ref_loss.QLoss(key="quaternion")), ("XYLoss", ref_loss.XYLoss(key="xy")),
+                     ("ZLoss", ref_loss.ZLoss(key="z")), ("ScalesLoss", ref_loss.ScalesLoss(key="scales")),
+                     ("RLoss", ref_loss.RLoss(key="R")), ("TLoss", ref_loss.TLoss(key="T")),
+                     ("Iou3dLoss", ref_loss.Iou3dLoss()), ("OffsetLoss", ref_loss.OffsetLoss())):
+        m, leaves = matched(True)
+        val = fn(m)
+        out[f"loss_{name}"] = val.detach().numpy()
+        if val.requires_grad:
+            val.backward()
+            key = {"QLoss": "quaternion", "XYLoss": "xy", "ZLoss": "z", "ScalesLoss": "scales", "RLoss": "R", "TLoss": "T",
+                   "Iou3dLoss": "RT", "OffsetLoss": "RT"}[name]
+            out[f"grad_{name}"] = leaves[key].grad.numpy()
+        out[f"loss_{name}_none"] = fn(None).cpu().numpy()
+    # pixel-wise mask losses
+    B, C, H, W = 2, 7, 12, 16
+    ml = t(f32(rng.normal(0, 2, (B, C, H, W)))).requires_grad_(True)
+    gt_mask = t(rng.integers(0, C, (B, H, W)).astype(np.int64))
+    out["mask_logits"] = ml.detach().numpy(); out["gt_mask"] = gt_mask.numpy()
+    for name, fn in (("CE", ref_loss.CE()), ("CCE", ref_loss.CCE())):
+        ml.grad = None
+        val = fn({"logits": {"mask": ml}}, {"mask": gt_mask})
+        val.backward()
+        out[f"loss_{name}"] = val.detach().numpy(); out[f"grad_{name}"] = ml.grad.numpy().copy()
+    np.savez_compressed(os.path.join(OUT, "eval_losses.npz"), **out)
+    print("eval_losses:", {k: (v.shape, str(v.dtype)) for k, v in out.items() if k.startswith(("deg_", "iou", "off", "loss_"))})
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     ref = import_reference()
+    if "--only-eval" in sys.argv:
+        gen_eval_and_losses(ref)
+        return
     rng = np.random.default_rng(20261003)
     gen_vote_small(ref, rng)
     gen_vote_fullres(ref, rng)
@@ -440,6 +554,7 @@ def main():
     gen_pose_rt(ref, rng)
     gen_pipeline(ref, rng)
     gen_matching(ref, rng)
+    gen_eval_and_losses(ref)
     import torch, scipy
     with open(os.path.join(OUT, "PROVENANCE.txt"), "w") as f:
         f.write("generated by oracle/gen_golden.py from /root/reference (FastPoseCNN @ v0)\n"

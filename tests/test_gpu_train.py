@@ -237,3 +237,24 @@ def test_grad_sumsq_kernel():
     out.zero_()
     nat.check(L.fpc_grad_sumsq(nat.ptr(g), g.numel(), nat.ptr(out), nat.stream()), "sumsq")
     assert out[1].item() > 0
+
+
+def test_train_step_bench_line_and_two_ranks_on_one_gpu():
+    """`bench.py --train`: the whole config-5 step (network forward/backward through torch modules, post-network forward and
+    backward through the HIP kernels, losses, sharded optimiser).  Two ranks share this box's one GPU over gloo (RCCL needs
+    one device per rank): the bucket reduction, the sharded step and the parameter all-gather run for real, and the ranks
+    must end with identical parameters."""
+    import json, os, subprocess, sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, FPC_BENCH_BACKEND="gloo")
+    r = subprocess.run([sys.executable, os.path.join(repo, "bench.py"), "--train", "--gpus", "2", "--steps", "3", "--warmup", "2",
+                        "--train-batch", "1", "--bucket-mb", "8"], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["config"]["global_batch"] == 2 and line["value"] > 0
+    chk = line["step_check"]
+    assert chk["replicas_in_sync"] and chk["skipped_steps"] == 0 and chk["matched_instances"] >= 4
+    assert math.isfinite(chk["total_loss"]) and chk["total_loss"] > 0
+    for task in ("mask", "quaternion", "xy", "z", "scales"):
+        assert chk["losses"][task]["task_total_loss"] is not None
+    assert line["config"]["buckets"] >= 2

@@ -1,0 +1,120 @@
+"""Config 5's data-parallel step on CPU: two gloo ranks through ShardedLookaheadRAdam (bucketed reduce-scatter of the
+flat gradient buffer -> sharded optimiser step -> all-gather of the parameters) against one process that averages both
+ranks' gradients and steps the whole model.  The step function is a torch restatement injected for the test (the
+product's step is the HIP kernel, checked on the GPU in tests/test_gpu_train.py)."""
+import math
+import socket
+
+import pytest
+import torch
+
+
+def _tiny_model():
+    torch.manual_seed(5)
+    return torch.nn.Sequential(torch.nn.Conv2d(3, 8, 3, padding=1), torch.nn.ReLU(), torch.nn.Conv2d(8, 8, 3, padding=1),
+                               torch.nn.ReLU(), torch.nn.Conv2d(8, 5, 1))
+
+
+def _step_fn(p, g, m, v, slow, step, ctl, hp):
+    """RAdam + Lookahead (published algorithms) on one shard, honouring ctl = [gradient scale, skip]."""
+    if float(ctl[1]) != 0:
+        return
+    g = g * ctl[0]
+    b1, b2 = hp["beta1"], hp["beta2"]
+    v.mul_(b2).add_((1 - b2) * g * g)
+    m.mul_(b1).add_((1 - b1) * g)
+    b2t = b2 ** step
+    sma_max = 2 / (1 - b2) - 1
+    sma = sma_max - 2 * step * b2t / (1 - b2t)
+    if hp["weight_decay"]:
+        p.add_(p, alpha=-hp["weight_decay"] * hp["lr"])
+    if sma >= 5:
+        ss = hp["lr"] * math.sqrt((1 - b2t) * (sma - 4) / (sma_max - 4) * (sma - 2) / sma * sma_max / (sma_max - 2)) / (1 - b1 ** step)
+        p.add_(-ss * m / (v.sqrt() + hp["eps"]))
+    else:
+        p.add_(-hp["lr"] / (1 - b1 ** step) * m)
+    if (step - 1) % hp["la_k"] == 0:
+        if step == 1:
+            slow.copy_(p)
+        slow.add_((p - slow) * hp["la_alpha"])
+        p.copy_(slow)
+
+
+def _data(rank, step):
+    g = torch.Generator().manual_seed(100 * rank + step)
+    return torch.randn((2, 3, 12, 16), generator=g), torch.randint(0, 5, (2, 12, 16), generator=g)
+
+
+def _train(world, rank, steps, opt_kw):
+    from fastposecnn_amd.train_parallel import ShardedLookaheadRAdam
+    model = _tiny_model()
+    opt = ShardedLookaheadRAdam(model, step_fn=_step_fn, **opt_kw)
+    norms = []
+    for s in range(steps):
+        opt.zero_grad()
+        if world == 1:                      # the single-process reference: mean of both ranks' losses
+            loss = sum(torch.nn.functional.cross_entropy(model(x), y) for x, y in (_data(0, s), _data(1, s))) / 2
+        else:
+            x, y = _data(rank, s)
+            loss = torch.nn.functional.cross_entropy(model(x), y)
+        loss.backward()
+        norms.append(float(opt.step()))
+    return torch.cat([p.detach().reshape(-1) for p in model.parameters()]), norms, opt
+
+
+def _worker(rank, world, port, q):
+    import torch.distributed as dist
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    flat, norms, opt = _train(world, rank, 7, dict(lr=1e-2, weight_decay=3e-4, clip_norm=0.15, bucket_mb=0.0001))
+    q.put((rank, flat.tolist(), norms, len(opt.buckets), opt.state_bytes()))
+    dist.destroy_process_group()
+
+
+def test_sharded_step_matches_single_process_gloo_world2():
+    import torch.multiprocessing as mp
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=180) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    want, want_norms, opt1 = _train(1, 0, 7, dict(lr=1e-2, weight_decay=3e-4, clip_norm=0.15, bucket_mb=0.0001))
+    r0, r1 = torch.tensor(res[0][1]), torch.tensor(res[1][1])
+    assert torch.equal(r0, r1)                                  # the ranks hold identical parameters after every all-gather
+    torch.testing.assert_close(r0, want, rtol=1e-5, atol=1e-6)
+    for a, b in zip(res[0][2], want_norms):                     # norm of the MEAN gradient, as a single process computes it
+        assert abs(a - b) <= 1e-5 * max(1.0, b)
+    assert res[0][3] > 2                                        # several buckets were reduced
+    assert res[0][4] * 2 <= opt1.state_bytes() + 3 * 4 * 8 * len(opt1.buckets)    # optimiser state is sharded
+
+
+def test_guard_skips_non_finite_step_and_views_stay_attached():
+    from fastposecnn_amd.train_parallel import ShardedLookaheadRAdam
+    model = _tiny_model()
+    opt = ShardedLookaheadRAdam(model, step_fn=_step_fn, lr=1e-2)
+    before = torch.cat([p.detach().reshape(-1) for p in model.parameters()]).clone()
+    opt.zero_grad()
+    x, y = _data(0, 0)
+    torch.nn.functional.cross_entropy(model(x), y).backward()
+    next(model.parameters()).grad.view(-1)[0] = float("inf")
+    opt.step()
+    after = torch.cat([p.detach().reshape(-1) for p in model.parameters()])
+    assert torch.equal(before, after) and int(opt.skipped) == 1     # F/lib/pose_regressor.py:341-415: the step is dropped
+    # parameters and gradients are views of the flat buffers
+    for p in model.parameters():
+        assert opt.flat_p.data_ptr() <= p.data_ptr() < opt.flat_p.data_ptr() + 4 * opt.total
+    model.zero_grad(set_to_none=True)
+    with pytest.raises(RuntimeError):
+        opt.zero_grad()
+
+
+def test_cpu_parameters_are_refused_without_injected_step():
+    from fastposecnn_amd.train_parallel import ShardedLookaheadRAdam
+    with pytest.raises(RuntimeError):
+        ShardedLookaheadRAdam(_tiny_model())
