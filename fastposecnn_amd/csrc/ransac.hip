@@ -136,6 +136,8 @@ struct Ws {
     double* partial;      // [n, nbx, kRec] k_vote_final per-task records
     float4* list;         // [n, HW]        {x, y, dx, dy} of the foreground pixels, compacted per chunk (k_vote_scan)
     float4* clist;        // [n, HW]        {ey, -ex, cs, ct}: their filter constants (NaN cs: never an inlier)
+    int2* units;          // [n * nbx]      (instance, block of 512 list entries) of every block that has entries (k_vote_plan)
+    int32_t* n_units;     // [1]            how many; zeroed by k_vote_scan
     int nch, nwords, hnp, nbx;
     size_t total;
 };
@@ -170,6 +172,8 @@ static Ws carve(void* base, int n, int H, int W, int hn) {
     w.partial = (double*)take(sizeof(double) * (size_t)n * w.nbx * kRec);
     w.list = (float4*)take(sizeof(float4) * (size_t)n * HW);
     w.clist = (float4*)take(sizeof(float4) * (size_t)n * HW);
+    w.units = (int2*)take(sizeof(int2) * (size_t)n * w.nbx);
+    w.n_units = (int32_t*)take(sizeof(int32_t));
     w.total = off;
     return w;
 }
@@ -241,8 +245,10 @@ __global__ __launch_bounds__(256) void k_vote_scan(const float* __restrict__ mas
                                                    int nch, int n, const int32_t* __restrict__ n_dev,
                                                    uint64_t* __restrict__ bits, uint32_t* __restrict__ word_pre,
                                                    int32_t* __restrict__ chunk_fg, int32_t* __restrict__ chunk_box,
-                                                   float4* __restrict__ list, float4* __restrict__ clist) {
+                                                   float4* __restrict__ list, float4* __restrict__ clist,
+                                                   int32_t* __restrict__ n_units) {
     __shared__ __attribute__((aligned(16))) uint8_t s_nib[kChunkPx / 4];
+    if (blockIdx.x == 0 && threadIdx.x == 0) *n_units = 0;         // k_vote_plan appends this call's work units
     __shared__ uint64_t s_word[kChunkWords];
     __shared__ int s_wpre[kChunkWords];
     __shared__ int s_box[4];
@@ -423,9 +429,11 @@ __global__ __launch_bounds__(1024) void k_vote_plan(const uint8_t* __restrict__ 
                                                     float* __restrict__ hx, float* __restrict__ hy,
                                                     float* __restrict__ hxs, float* __restrict__ hys,
                                                     float* __restrict__ eg, float* __restrict__ hyp,
-                                                    int32_t* __restrict__ upper, int32_t* __restrict__ tickets) {
+                                                    int32_t* __restrict__ upper, int32_t* __restrict__ tickets,
+                                                    int2* __restrict__ units, int32_t* __restrict__ n_units) {
     extern __shared__ __attribute__((aligned(16))) int s_tab[];      // [2][nch + 1] when lds_table
     __shared__ int s_w[20];
+    __shared__ int s_ubase;
     __shared__ int s_box[4];
     int* s_cpre = lds_table ? s_tab : nullptr;
     int* s_cpreK = lds_table ? s_tab + (nch + 1) : nullptr;
@@ -499,8 +507,12 @@ __global__ __launch_bounds__(1024) void k_vote_plan(const uint8_t* __restrict__ 
             plan[inst * kPlanI + 3] = ox;
             plan[inst * kPlanI + 4] = oy;
             plan[inst * kPlanI + 5] = rad;
+            // the work units of k_vote_count: one per block of 512 list entries (no unit for an instance that does not vote)
+            const int nb_i = tn > 0 ? (fg + kBlockPx - 1) / kBlockPx : 0;
+            s_ubase = nb_i ? atomicAdd(n_units, nb_i) : 0;
         }
         __syncthreads();               // the tables of this instance are complete (same CU: visible)
+        for (int b = threadIdx.x; b * kBlockPx < (tn > 0 ? fg : 0); b += blockDim.x) units[s_ubase + b] = make_int2(inst, b);
 
         const int32_t* tab = lds_table ? s_cpre : cpre;
         const int32_t* tabK = lds_table ? s_cpreK : cpreK;
@@ -586,13 +598,57 @@ __device__ __forceinline__ bool classify_pair(const float4 cst, const float4 q, 
     return sure && valid;
 }
 
-// The pairs between the cones: the reference's own arithmetic for the lanes of `band`, out of line so that the hot
-// loop of k_vote_count stays a run of FMAs and compares.  Returns how many of them are inliers.
-__device__ __attribute__((noinline)) int count_band_pairs(unsigned long long band, float4 q, float n1, float gx, float gy,
-                                                          float thresh) {
+// The pairs between the cones take the reference's own arithmetic.  The hot loop of k_vote_count only QUEUES them
+// (entry = hypothesis g | tile << 6 | lane << 7, in the wave's LDS queue); band_flush evaluates up to 64 queued pairs at
+// once, one per lane — the pixel comes from its owner lane and the point from lane g by ds_bpermute — and adds the
+// inliers to the group's packed LDS counts.  Out of line: the hot loop stays a run of FMAs, compares and scalar counts,
+// with no scalar-memory wait and no per-event sqrt / division.
+constexpr int kBandQ = 256;          // queue entries per wave: one step of the hot loop adds at most 4 x 64
+
+__device__ __forceinline__ float lane_fetch(float v, int src_lane) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(src_lane << 2, __builtin_bit_cast(int, v)));
+}
+
+__device__ __attribute__((noinline)) void band_flush(int n, const int* __restrict__ queue, float4 q0, float4 q1, float hxv,
+                                                     float hyv, float thresh, int* __restrict__ s_cnt_group) {
     const int lane = threadIdx.x & (kWave - 1);
-    const bool in = ((band >> lane) & 1ull) && pair_is_inlier(q.x, q.y, q.z, q.w, n1, gx, gy, thresh);
-    return __popcll(__builtin_amdgcn_ballot_w64(in));
+    for (int base = 0; base < n; base += kWave) {                           // uniform
+        const bool on = base + lane < n;
+        const int e = on ? queue[base + lane] : 0;
+        const int g = e & 63, src = e >> 7;
+        const bool t1 = (e >> 6) & 1;
+        const float x0 = lane_fetch(q0.x, src), y0 = lane_fetch(q0.y, src), z0 = lane_fetch(q0.z, src), w0 = lane_fetch(q0.w, src);
+        const float x1 = lane_fetch(q1.x, src), y1 = lane_fetch(q1.y, src), z1 = lane_fetch(q1.z, src), w1 = lane_fetch(q1.w, src);
+        const float gx = lane_fetch(hxv, g), gy = lane_fetch(hyv, g);
+        const float qx = t1 ? x1 : x0, qy = t1 ? y1 : y0, qz = t1 ? z1 : z0, qw = t1 ? w1 : w0;
+        if (on && pair_is_inlier(qx, qy, qz, qw, sqrtf(qz * qz + qw * qw), gx, gy, thresh))
+            atomicAdd(&s_cnt_group[g >> 1], 1 << ((g & 1) * 16));
+    }
+}
+
+// the lanes of `m` append (their code | lane << 7) to the wave's queue
+__device__ __forceinline__ void band_push(unsigned long long m, int code, int lane, int* __restrict__ bq, int& qn) {
+    if ((m >> lane) & 1ull)
+        bq[qn + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0))] = code | (lane << 7);
+    qn += __popcll(m);
+}
+
+// In-register 64 x 64 bit-matrix transpose across the wave (row = lane, column = bit of hi:lo): six block-swap stages.
+__device__ __forceinline__ void transpose64(unsigned& lo, unsigned& hi, int lane) {
+    {   // 32 x 32 blocks: lanes < 32 give their high word and take the partner's low word
+        const unsigned recv = (unsigned)__shfl_xor((int)((lane & 32) ? lo : hi), 32, kWave);
+        if (lane & 32) lo = recv; else hi = recv;
+    }
+#pragma unroll
+    for (int st = 0; st < 5; ++st) {
+        const int m = 16 >> st;
+        const unsigned cm = m == 16 ? 0xFFFF0000u : m == 8 ? 0xFF00FF00u : m == 4 ? 0xF0F0F0F0u : m == 2 ? 0xCCCCCCCCu : 0xAAAAAAAAu;
+        const bool up = (lane & m) != 0;                     // keeps its high columns, takes the partner's into the low ones
+        const unsigned keep = up ? cm : ~cm;
+        const unsigned ylo = (unsigned)__shfl_xor((int)lo, m, kWave), yhi = (unsigned)__shfl_xor((int)hi, m, kWave);
+        lo = (lo & keep) | ((up ? (ylo >> m) : (ylo << m)) & ~keep);
+        hi = (hi & keep) | ((up ? (yhi >> m) : (yhi << m)) & ~keep);
+    }
 }
 
 struct TilePair {                    // one lane's two list entries: filter constants, |vote|, raw pixel
@@ -610,9 +666,10 @@ struct TilePair {                    // one lane's two list entries: filter cons
 enum { kModeCones = 0, kModeReference = 1 };
 
 template <int MODE, int WAVES /* waves per SIMD the register allocation aims at */>
-__global__ __launch_bounds__(256, WAVES) void k_vote_count(int W, int HW, int nch, int n, const int32_t* __restrict__ n_dev,
-                                                    int hn, int hnp, int nb_grid, int S,
-                                                    int gps /* groups of 64 hypotheses per slice */, float kappa1,
+__global__ __launch_bounds__(256, WAVES) void k_vote_count(int W, int HW, int nch, const int2* __restrict__ units,
+                                                    const int32_t* __restrict__ n_units, int hn, int hnp,
+                                                    int task_target /* tasks the launch wants: slices are cut to reach it */,
+                                                    int s_fixed /* > 0: that many slices (tuning aid) */, float kappa1,
                                                     float kappa2, float thresh, int max_num, uint64_t seed,
                                                     const uint8_t* __restrict__ keep, int lds_table,
                                                     const int32_t* __restrict__ chunk_pre,
@@ -620,16 +677,20 @@ __global__ __launch_bounds__(256, WAVES) void k_vote_count(int W, int HW, int nc
                                                     const float* __restrict__ hy, const float* __restrict__ hxs,
                                                     const float* __restrict__ hys, const float* __restrict__ eg,
                                                     int32_t* __restrict__ counts, const float4* __restrict__ list,
-                                                    const float4* __restrict__ clist) {
+                                                    const float4* __restrict__ clist, int dbg) {
     extern __shared__ __attribute__((aligned(16))) int s_dyn[];
-    int* s_cnt = s_dyn;                              // [gps * 32]
-    int* s_cpre = s_dyn + gps * (kWave / 2);         // [nch + 1]
-    const int n_act = active_instances(n, n_dev);
-    const long long units = (long long)n_act * nb_grid;
-    const long long total = (units + 7) / 8 * 8 * S;
-    const int lane = threadIdx.x & (kWave - 1), wv = threadIdx.x / kWave;
     const int ngroups = hnp / kWave;
-    const float qnan = __builtin_nanf("");
+    int* s_cnt = s_dyn;                              // [ngroups * 32] (a slice uses its first gps * 32)
+    int* s_cpre = s_dyn + ngroups * (kWave / 2);     // [nch + 1]
+    __shared__ int s_bandq[4][kBandQ];               // per wave: queued band pairs of the current group
+    // The units (blocks that have entries) are known on the device only; each is cut into S slices of gps groups of 64
+    // hypotheses so that units x S ~ the task count the launch was sized for: one round of equal tasks over the chip.
+    const int nu = *n_units;
+    const int S0 = s_fixed > 0 ? s_fixed : max(1, task_target / max(nu, 1));
+    const int gps = (ngroups + min(S0, ngroups) - 1) / min(S0, ngroups);
+    const int S = (ngroups + gps - 1) / gps;
+    const long long total = ((long long)nu + 7) / 8 * 8 * S;
+    const int lane = threadIdx.x & (kWave - 1), wv = threadIdx.x / kWave;
     // sure  <=>  |s| <= kappa2 t - E  =  r (kappa1 t + E) - (1 + r) E   with r = kappa2 / kappa1: one FMA on the other bound
     const float ratio = kappa1 > 0.0f ? kappa2 / kappa1 : 0.0f;
     int cached_inst = -1;
@@ -637,15 +698,16 @@ __global__ __launch_bounds__(256, WAVES) void k_vote_count(int W, int HW, int nc
         const long long grp = t / (8 * S);
         const int rem = (int)(t - grp * (8 * S));
         const int s = rem >> 3;
-        const long long u = grp * 8 + (rem & 7);
-        if (u >= units) continue;
-        const int inst = (int)(u / nb_grid), b0 = (int)(u - (long long)inst * nb_grid);
-        const int fg = plan[inst * kPlanI + 0], tn = plan[inst * kPlanI + 1];
+        const int u = (int)(grp * 8 + (rem & 7));
+        if (u >= nu) continue;
+        const int2 ub = units[u];
+        const int inst = ub.x, b = ub.y;
+        const int fg = plan[inst * kPlanI + 0];
         const bool thin = plan[inst * kPlanI + 2] != 0;
         const float fox = (float)plan[inst * kPlanI + 3], foy = (float)plan[inst * kPlanI + 4];
-        const int nent = tn > 0 ? fg : 0;                           // list entries to visit (all foreground pixels)
+        const int nent = fg;                                        // list entries of the instance (all foreground pixels)
         const int g_lo = s * gps, g_hi = min(ngroups, g_lo + gps);
-        if (g_lo >= g_hi || b0 * kBlockPx >= nent) continue;        // uniform
+        if (g_lo >= g_hi) continue;                                 // uniform
         if (lds_table && cached_inst != inst) {                     // uniform
             __syncthreads();
             for (int i = threadIdx.x; i <= nch; i += blockDim.x) s_cpre[i] = chunk_pre[(size_t)inst * (nch + 1) + i];
@@ -653,8 +715,7 @@ __global__ __launch_bounds__(256, WAVES) void k_vote_count(int W, int HW, int nc
             __syncthreads();
         }
         const int32_t* tab = lds_table ? s_cpre : chunk_pre + (size_t)inst * (nch + 1);
-        // an instance normally has at most nb_grid blocks (<= max_num pixels unless thinned); a larger one wraps around
-        for (int b = b0; b * kBlockPx < nent; b += nb_grid) {
+        {
             TilePair tp;                                            // this lane's two entries
             float c_t0[2];
             bool valid[2];
@@ -662,15 +723,18 @@ __global__ __launch_bounds__(256, WAVES) void k_vote_count(int W, int HW, int nc
             for (int tl = 0; tl < 2; ++tl) {
                 const int e = b * kBlockPx + (wv * 2 + tl) * kWave + lane;
                 valid[tl] = e < nent;
-                float4 cst = make_float4(0.f, 0.f, qnan, qnan);      // NaN: the slot never counts
+                // a slot that never counts: |s| = +inf, so both margins are -inf (sign set, never NaN)
+                const float4 never = make_float4(0.f, 0.f, __builtin_inff(), 0.f);
+                float4 cst = never;
                 tp.q[tl] = make_float4(0.f, 0.f, 0.f, 0.f);
                 if (valid[tl]) {
                     const size_t slot = (size_t)inst * HW + entry_slot(tab, nch, e);
                     tp.q[tl] = list[slot];
                     if (MODE == kModeCones) cst = recentre_constants(clist[slot], tp.q[tl], fox, foy);
+                    if (cst.z != cst.z) cst = never;                 // a vote the reference skips (pixel_constants)
                     if (thin && !entry_kept(tp.q[tl], W, HW, inst, fg, max_num, seed, keep)) {
                         valid[tl] = false;
-                        cst = make_float4(0.f, 0.f, qnan, qnan);
+                        cst = never;
                     }
                 }
                 // folded constants:  s = a_s gx + b_s gy + c_s ;  kappa1 t + E_g = a_t gx + b_t gy + (c_t0 + E_g)
@@ -682,6 +746,7 @@ __global__ __launch_bounds__(256, WAVES) void k_vote_count(int W, int HW, int nc
             __syncthreads();
 
             for (int G = g_lo; G < g_hi; ++G) {
+                if (dbg == 1) break;                 // tuning aid (FPC_COUNT_DBG=1): prologue / epilogue only, results wrong
                 // HX / HY: the points themselves (the reference's arithmetic); HXS / HYS: minus the origin (the cones)
                 const float* HX = static_cast<const float*>(__builtin_assume_aligned(hx + (size_t)inst * hnp + (size_t)G * kWave, 256));
                 const float* HY = static_cast<const float*>(__builtin_assume_aligned(hy + (size_t)inst * hnp + (size_t)G * kWave, 256));
@@ -706,46 +771,68 @@ __global__ __launch_bounds__(256, WAVES) void k_vote_count(int W, int HW, int nc
                 }
                 tp.c_t[0] = c_t0[0] + eg_g; tp.c_t[1] = c_t0[1] + eg_g;
                 const float e2 = (1.0f + ratio) * eg_g;
-                // one (hypothesis, two 64-entry tiles) step; two hypotheses' counts (<= 128 each) share one SGPR, dropped into
-                // lane g/2 of cntv by v_writelane (no builtin for it in ROCm 7.2's clang; the lane select is an immediate,
-                // the value an SGPR written by SALU: no wait states required)
-#define FPC_VOTE_HYP(g, j, c)                                                                                          \
+                // lane g holds point g of the group: minus the origin for the cones (v_readlane -> SGPR operands of the
+                // FMAs: no scalar-memory wait inside the loop), as it is for band_flush
+                const float hxv = HX[lane], hyv = HY[lane];
+                int* bq = s_bandq[wv];
+                int* cnt_g = s_cnt + (G - g_lo) * (kWave / 2);
+                // One (hypothesis, two 64-entry tiles) step is plain VALU work only: per tile the margins to the outer cone
+                // (d = u1 - |s|) and to the inner one (d2 = r u1 - e2 - |s|), whose SIGN bits are shifted into per-lane
+                // bit rows (v_alignbit: row = (row << 1) | sign).  x - y >= 0 exactly when y <= x, so the signs are the
+                // reference-safe compares of the two-cone filter; no v_cmp -> SGPR -> s_bcnt chain, no branch.  Ten f32
+                // lane-operations per (entry, point): measured, the loop runs at the SIMD's plain-f32 rate (4 cycles per
+                // wave64 instruction; v_pk_fma_f32 on the two tiles at once costs twice that, i.e. gains nothing).
+                unsigned rowO[2][2] = {{0u, 0u}, {0u, 0u}}, rowS[2][2] = {{0u, 0u}, {0u, 0u}};
+#define FPC_VOTE_HYP(g)                                                                                                \
                 {                                                                                                      \
-                    const float gxs = GXS[(j)], gys = GYS[(j)];                                                        \
-                    unsigned long long band[2];                                                                        \
+                    const float gxs = HXS[(g)], gys = HYS[(g)];      /* scalar loads, batched by the compiler */        \
                     _Pragma("unroll") for (int tl = 0; tl < 2; ++tl) {                                                 \
                         const float ss = fabsf(__builtin_fmaf(tp.a_s[tl], gxs, __builtin_fmaf(tp.b_s[tl], gys, tp.c_s[tl]))); \
                         const float u1 = __builtin_fmaf(tp.a_t[tl], gxs, __builtin_fmaf(tp.b_t[tl], gys, tp.c_t[tl])); \
-                        const unsigned long long sure = __builtin_amdgcn_ballot_w64(ss <= __builtin_fmaf(ratio, u1, -e2)); \
-                        band[tl] = __builtin_amdgcn_ballot_w64(ss <= u1) & ~sure;                                      \
-                        c += __popcll(sure);                                                                           \
-                    }                                                                                                  \
-                    if (__builtin_expect((band[0] | band[1]) != 0ull, 0)) {      /* a few % of the steps */            \
-                        const float gx = HX[(g)], gy = HY[(g)];                                                        \
-                        if (band[0]) c += __builtin_amdgcn_readfirstlane(count_band_pairs(band[0], tp.q[0], tp.n1[0], gx, gy, thresh)); \
-                        if (band[1]) c += __builtin_amdgcn_readfirstlane(count_band_pairs(band[1], tp.q[1], tp.n1[1], gx, gy, thresh)); \
+                        const float d = u1 - ss, d2 = __builtin_fmaf(ratio, u1, -e2) - ss;                             \
+                        rowO[tl][(g) >> 5] = __builtin_amdgcn_alignbit(rowO[tl][(g) >> 5], __float_as_uint(d), 31);    \
+                        rowS[tl][(g) >> 5] = __builtin_amdgcn_alignbit(rowS[tl][(g) >> 5], __float_as_uint(d2), 31);   \
                     }                                                                                                  \
                 }
-#define FPC_VOTE_PAIR(g2, j2)                                                                                          \
-                {                                                                                                      \
-                    int c0 = 0, c1 = 0;                                                                                \
-                    FPC_VOTE_HYP(2 * (g2), 2 * (j2), c0) FPC_VOTE_HYP(2 * (g2) + 1, 2 * (j2) + 1, c1)                  \
-                    const int pk = c0 | (c1 << 16);                                                                    \
-                    asm("v_writelane_b32 %0, %1, %2" : "+v"(cntv) : "s"(pk), "n"(g2));                                 \
-                }
-                // eight hypotheses per scalar-load batch: the points are fetched before the run of steps (the rare branch
-                // to the band handler ends a basic block, and the compiler does not batch scalar loads across blocks)
-#define FPC_VOTE_OCT(o)                                                                                                \
-                {                                                                                                      \
-                    float GXS[8], GYS[8];                                                                              \
-                    _Pragma("unroll") for (int i = 0; i < 8; ++i) { GXS[i] = HXS[8 * (o) + i]; GYS[i] = HYS[8 * (o) + i]; } \
-                    FPC_VOTE_PAIR(4 * (o), 0) FPC_VOTE_PAIR(4 * (o) + 1, 1) FPC_VOTE_PAIR(4 * (o) + 2, 2) FPC_VOTE_PAIR(4 * (o) + 3, 3) \
-                }
-                FPC_VOTE_OCT(0) FPC_VOTE_OCT(1) FPC_VOTE_OCT(2) FPC_VOTE_OCT(3) FPC_VOTE_OCT(4) FPC_VOTE_OCT(5) FPC_VOTE_OCT(6) FPC_VOTE_OCT(7)
-#undef FPC_VOTE_OCT
-#undef FPC_VOTE_PAIR
+#define FPC_VOTE_4(g) FPC_VOTE_HYP(g) FPC_VOTE_HYP((g) + 1) FPC_VOTE_HYP((g) + 2) FPC_VOTE_HYP((g) + 3)
+#define FPC_VOTE_16(g) FPC_VOTE_4(g) FPC_VOTE_4((g) + 4) FPC_VOTE_4((g) + 8) FPC_VOTE_4((g) + 12)
+                FPC_VOTE_16(0) FPC_VOTE_16(16) FPC_VOTE_16(32) FPC_VOTE_16(48)
+#undef FPC_VOTE_16
+#undef FPC_VOTE_4
 #undef FPC_VOTE_HYP
-                if (lane < kWave / 2) atomicAdd(&s_cnt[(G - g_lo) * (kWave / 2) + lane], cntv);   // fields <= 512: no carry
+                // bit g of a row <-> point g: sure = inside the inner cone, band = between the cones (rare)
+                unsigned long long sure[2], band[2];
+#pragma unroll
+                for (int tl = 0; tl < 2; ++tl) {
+                    const unsigned o0 = ~__builtin_bitreverse32(rowO[tl][0]), o1 = ~__builtin_bitreverse32(rowO[tl][1]);
+                    const unsigned s0 = ~__builtin_bitreverse32(rowS[tl][0]), s1 = ~__builtin_bitreverse32(rowS[tl][1]);
+                    sure[tl] = ((unsigned long long)s1 << 32) | s0;
+                    band[tl] = ((unsigned long long)(o1 & ~s1) << 32) | (o0 & ~s0);
+                }
+                // the pairs between the cones are queued (one entry per pair), then evaluated 64 at a time by band_flush
+                int qn = 0;
+                while (__builtin_amdgcn_ballot_w64((band[0] | band[1]) != 0ull)) {                   // uniform; usually not entered
+                    const bool has = (band[0] | band[1]) != 0ull;
+                    int code = 0;
+                    if (band[0]) { code = __ffsll((long long)band[0]) - 1; band[0] &= band[0] - 1; }
+                    else if (band[1]) { code = (__ffsll((long long)band[1]) - 1) | 64; band[1] &= band[1] - 1; }
+                    const unsigned long long m = __builtin_amdgcn_ballot_w64(has);
+                    if (qn + __popcll(m) > kBandQ) {
+                        band_flush(qn, bq, tp.q[0], tp.q[1], hxv, hyv, thresh, cnt_g);
+                        qn = 0;
+                    }
+                    band_push(m, code, lane, bq, qn);
+                }
+                if (qn) band_flush(qn, bq, tp.q[0], tp.q[1], hxv, hyv, thresh, cnt_g);
+                // 64 x 64 bit transposes across the wave: lane g then holds the sure bits of point g over the tile's entries
+                int cnt = 0;
+#pragma unroll
+                for (int tl = 0; tl < 2; ++tl) {
+                    unsigned lo = (unsigned)sure[tl], hi = (unsigned)(sure[tl] >> 32);
+                    transpose64(lo, hi, lane);
+                    cnt += __popc(lo) + __popc(hi);
+                }
+                atomicAdd(&cnt_g[lane >> 1], cnt << ((lane & 1) * 16));                              // fields <= 512: no carry
             }
             __syncthreads();
             // one integer atomic per (block, hypothesis) with any count: order-independent result
@@ -1012,7 +1099,7 @@ extern "C" int fpc_ransac_voting_v3(const float* mask, const float* vertex, int6
     const int scan_grid = (int)std::min<long long>((long long)n * w.nch, 8192);
 #define FPC_LAUNCH_SCAN(A, B)                                                                                            \
     hipLaunchKernelGGL((k_vote_scan<A, B>), dim3(scan_grid), dim3(256), 0, s, mask, vertex, vs_n, vs_h, vs_w, vs_c, W, HW,  \
-                       w.nch, n, n_dev, w.bits, w.word_pre, w.chunk_fg, w.chunk_box, w.list, w.clist)
+                       w.nch, n, n_dev, w.bits, w.word_pre, w.chunk_fg, w.chunk_box, w.list, w.clist, w.n_units)
     if (vg4) FPC_LAUNCH_SCAN(true, true); else if (vec4) FPC_LAUNCH_SCAN(true, false); else FPC_LAUNCH_SCAN(false, false);
 #undef FPC_LAUNCH_SCAN
 
@@ -1034,27 +1121,27 @@ extern "C" int fpc_ransac_voting_v3(const float* mask, const float* vertex, int6
     hipLaunchKernelGGL(k_vote_plan, dim3(std::min(n, 2048)), dim3(1024), 2 * table_lds, s, keep, W, HW, w.nch, n, n_dev, hn, w.hnp,
                        idxs, seed, min_num, max_num, efac, lds_table, w.chunk_fg, w.chunk_box, w.chunk_pre, w.word_pre, w.bits,
                        w.chunk_preK, w.word_preK, w.bitsK, w.list, w.plan, w.hx, w.hy, w.hxs, w.hys, w.eg, w.hyp, w.upper,
-                       w.tickets);
+                       w.tickets, w.units, w.n_units);
 
-    // 3. exact inlier counts of every hypothesis
-    const int nb_launch = std::min(w.nbx, cdiv(std::min(HW, max_num), kBlockPx) + 1);   // blocks per instance in the task grids
+    // 3. exact inlier counts of every hypothesis.  One resident round of workgroups (five per CU); the kernel reads how many
+    // blocks have entries and cuts each into hypothesis slices so that the tasks fill that round evenly.
+    const int nb_launch = std::min(w.nbx, cdiv(std::min(HW, max_num), kBlockPx) + 1);   // blocks per instance in the final's task grid
     const int ngroups = w.hnp / kWave;
-    // hypothesis slices: enough waves to fill the chip evenly when there are few instances (an instance typically fills
-    // half of its blocks; with a device-side count the capacity n over-states the instances by ~8x)
-    const long long waves_per_slice = std::max<long long>(1, (long long)(n_dev ? std::max(1, n / 8) : n) * nb_launch * 2);
-    const int s_needed = (int)std::min<long long>(ngroups, std::max<long long>(1, (12288 + waves_per_slice - 1) / waves_per_slice));
-    const int gps = cdiv(ngroups, s_needed);
-    const int S = cdiv(ngroups, gps);
-    const long long tasks = ((long long)n * nb_launch + 7) / 8 * 8 * S;
-    const int count_grid = (int)std::min<long long>(tasks, 8192);            // a multiple of 8 either way
-    const size_t count_lds = (size_t)gps * (kWave / 2) * sizeof(int) + table_lds;
-    static const int count_waves = getenv("FPC_COUNT_WAVES") ? atoi(getenv("FPC_COUNT_WAVES")) : 5;      // tuning aid
+    static const int count_waves = getenv("FPC_COUNT_WAVES") ? atoi(getenv("FPC_COUNT_WAVES")) : 5;      // tuning aids
+    static const int count_slices = getenv("FPC_COUNT_SLICES") ? atoi(getenv("FPC_COUNT_SLICES")) : 0;
+    static const int count_rounds = getenv("FPC_COUNT_ROUNDS") ? atoi(getenv("FPC_COUNT_ROUNDS")) : 1;
+    static const int count_dbg = getenv("FPC_COUNT_DBG") ? atoi(getenv("FPC_COUNT_DBG")) : 0;
+    const long long cap_tasks = ((long long)n * w.nbx + 7) / 8 * 8 * ngroups;
+    const int resident = 256 * std::min(std::max(count_waves, 4), 6);                  // workgroups the chip holds at once
+    const int count_grid = (int)std::min<long long>(cap_tasks, resident);                 // a multiple of 8 either way
+    const int task_target = count_grid * std::max(1, count_rounds);
+    const size_t count_lds = (size_t)ngroups * (kWave / 2) * sizeof(int) + table_lds;
 #define FPC_LAUNCH_COUNT(M)                                                                                              \
     if (count_waves >= 6) FPC_LAUNCH_COUNT2(M, 6); else if (count_waves == 5) FPC_LAUNCH_COUNT2(M, 5); else FPC_LAUNCH_COUNT2(M, 4)
 #define FPC_LAUNCH_COUNT2(M, WV)                                                                                         \
-    hipLaunchKernelGGL((k_vote_count<M, WV>), dim3(count_grid), dim3(256), count_lds, s, W, HW, w.nch, n, n_dev, hn, w.hnp,   \
-                       nb_launch, S, gps, kappa1, kappa2, inlier_thresh, max_num, seed, keep, lds_table, w.chunk_pre, w.plan,  \
-                       w.hx, w.hy, w.hxs, w.hys, w.eg, w.upper, w.list, w.clist)
+    hipLaunchKernelGGL((k_vote_count<M, WV>), dim3(count_grid), dim3(256), count_lds, s, W, HW, w.nch, w.units, w.n_units, hn, \
+                       w.hnp, task_target, count_slices, kappa1, kappa2, inlier_thresh, max_num, seed, keep, lds_table,     \
+                       w.chunk_pre, w.plan, w.hx, w.hy, w.hxs, w.hys, w.eg, w.upper, w.list, w.clist, count_dbg)
     if (fast) { FPC_LAUNCH_COUNT(kModeCones); } else { FPC_LAUNCH_COUNT(kModeReference); }
 #undef FPC_LAUNCH_COUNT
 #undef FPC_LAUNCH_COUNT2

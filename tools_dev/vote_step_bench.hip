@@ -82,6 +82,40 @@ __global__ __launch_bounds__(256) void probe(const float* __restrict__ hx, const
 #undef MF
 #undef MF1
                 total += cntv;
+            } else if (KIND == 6) {
+                // sign-bit rows: per (tile, hypothesis) 4 FMA + bound FMA + 2 sub + 2 alignbit, operands via v_readlane
+                const float hxv = HX[lane], hyv = HY[lane];
+                unsigned ro[T], rs[T];
+#pragma unroll
+                for (int t = 0; t < T; ++t) { ro[t] = 0; rs[t] = 0; }
+#define MG(g) { const float gx = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, hxv), (g))); \
+                const float gy = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, hyv), (g))); \
+                _Pragma("unroll") for (int t = 0; t < T; ++t) { \
+                const float ss = fabsf(__builtin_fmaf(a_s[t], gx, __builtin_fmaf(b_s[t], gy, c_s[t]))); \
+                const float u1 = __builtin_fmaf(a_t[t], gx, __builtin_fmaf(b_t[t], gy, c_t[t])); \
+                const float d = u1 - ss, d2 = __builtin_fmaf(0.97f, u1, -0.001f) - ss; \
+                ro[t] = __builtin_amdgcn_alignbit(ro[t], __builtin_bit_cast(unsigned, d), 31); \
+                rs[t] = __builtin_amdgcn_alignbit(rs[t], __builtin_bit_cast(unsigned, d2), 31); } }
+                STEP64(MG)
+#undef MG
+#pragma unroll
+                for (int t = 0; t < T; ++t) total += __popc(ro[t]) + __popc(rs[t]);
+            } else if (KIND == 7) {
+                // the same with the operands from scalar loads
+                unsigned ro[T], rs[T];
+#pragma unroll
+                for (int t = 0; t < T; ++t) { ro[t] = 0; rs[t] = 0; }
+#define MH(g) { const float gx = HX[(g)], gy = HY[(g)]; \
+                _Pragma("unroll") for (int t = 0; t < T; ++t) { \
+                const float ss = fabsf(__builtin_fmaf(a_s[t], gx, __builtin_fmaf(b_s[t], gy, c_s[t]))); \
+                const float u1 = __builtin_fmaf(a_t[t], gx, __builtin_fmaf(b_t[t], gy, c_t[t])); \
+                const float d = u1 - ss, d2 = __builtin_fmaf(0.97f, u1, -0.001f) - ss; \
+                ro[t] = __builtin_amdgcn_alignbit(ro[t], __builtin_bit_cast(unsigned, d), 31); \
+                rs[t] = __builtin_amdgcn_alignbit(rs[t], __builtin_bit_cast(unsigned, d2), 31); } }
+                STEP64(MH)
+#undef MH
+#pragma unroll
+                for (int t = 0; t < T; ++t) total += __popc(ro[t]) + __popc(rs[t]);
             } else if (KIND == 3) {
                 float f = 0.f;
 #define MD(g) { const float gx = HX[(g)], gy = HY[(g)]; const float ss = __builtin_fmaf(a_s[0], gx, __builtin_fmaf(b_s[0], gy, c_s[0])); \
@@ -119,7 +153,10 @@ int main() {
     hipMalloc(&hx, 4096 * 4); hipMalloc(&hy, 4096 * 4); hipMalloc(&out, 256 * 8 * 256 * 4);
     float h[4096]; for (int i = 0; i < 4096; ++i) h[i] = 100.f + (i * 37 % 400);
     hipMemcpy(hx, h, sizeof(h), hipMemcpyHostToDevice); hipMemcpy(hy, h, sizeof(h), hipMemcpyHostToDevice);
-    for (int w : {2, 4, 5, 8}) {
+    for (int w : {1, 2, 4, 5, 8}) {
+        run<6, 2>("G2 sign-bit rows, 2 tiles, readlane operands (20 VALU / 2-tile step)", w, hx, hy, out);
+        run<7, 2>("H2 sign-bit rows, 2 tiles, s_load operands (18 VALU / 2-tile step)", w, hx, hy, out);
+        run<7, 4>("H4 sign-bit rows, 4 tiles, s_load operands", w, hx, hy, out);
         run<3, 1>("D  4 FMA only", w, hx, hy, out);
         run<4, 1>("E  4 FMA + cmp->sgpr + bcnt + s_add", w, hx, hy, out);
         run<0, 1>("A  ... + v_writelane per step", w, hx, hy, out);
