@@ -870,14 +870,15 @@ constexpr int kFinWaves = 4;         // 256-thread workgroups
 typedef unsigned long long __attribute__((address_space(1))) gu64;
 
 // Winner (largest count, lowest index: torch.max, RV/ransac_voting_gpu.py:567), its inliers voted again (:583-589), the
-// fp64 normal equations and the 2x2 solve (:592-599).  Task = (instance, block b0 of 512 list entries); every instance
-// has nb_grid tasks, whatever its size, and the one whose arrival ticket comes last combines their records
+// fp64 normal equations and the 2x2 solve (:592-599).  Task = one work unit of k_vote_plan's list = (instance, block b0 of
+// 512 list entries); the unit of an instance whose arrival ticket comes last combines the instance's records
 // (cdna_hip_programming.md Guideline 16, counter form: records stored write-through (sc1), the storing wave drained,
 // one agent-scope add per workgroup; the last arriver reads them back with sc1 loads, in task order: bit-reproducible).
 // dynamic LDS: the chunk prefix [nch + 1] when lds_table.
 template <int MODE>
 __global__ __launch_bounds__(256) void k_vote_final(int W, int HW, int nch, int n, const int32_t* __restrict__ n_dev,
-                                                    int hn, int hnp, int nb_grid, int nbx, float thresh, float kappa1,
+                                                    const int2* __restrict__ units, const int32_t* __restrict__ n_units,
+                                                    int hn, int hnp, int nbx, float thresh, float kappa1,
                                                     float kappa2, float efac_ref, int max_num, uint64_t seed,
                                                     const uint8_t* __restrict__ keep, int lds_table,
                                                     const int32_t* __restrict__ chunk_pre,
@@ -895,37 +896,27 @@ __global__ __launch_bounds__(256) void k_vote_final(int W, int HW, int nch, int 
     const int n_act = active_instances(n, n_dev);
     const int lane = threadIdx.x & (kWave - 1), wv = threadIdx.x / kWave;
     const Cones cones{kappa1, kappa2};
-    const long long total = (long long)n_act * nb_grid;
-    for (long long t = blockIdx.x; t < total; t += gridDim.x) {
-        const int inst = (int)(t / nb_grid), b0 = (int)(t - (long long)inst * nb_grid);
+    // instances that do not vote (fewer than min_num pixels) have no unit: zeros (RV/ransac_voting_gpu.py:536-539)
+    for (int inst = blockIdx.x * blockDim.x + threadIdx.x; inst < n_act; inst += gridDim.x * blockDim.x)
+        if (plan[inst * kPlanI + 1] == 0) {
+            out_xy[inst * 2] = 0.0f; out_xy[inst * 2 + 1] = 0.0f;
+            if (out_tn) out_tn[inst] = 0;
+            if (out_win_idx) out_win_idx[inst] = -1;
+            if (out_win_count) out_win_count[inst] = 0;
+            if (out_inl) out_inl[inst] = 0;
+            if (out_refine)
+                for (int i = 0; i < 8; ++i) out_refine[(size_t)inst * 8 + i] = 0.0;
+        }
+    const int nu = *n_units;
+    for (int t = blockIdx.x; t < nu; t += gridDim.x) {
+        const int2 ub = units[t];
+        const int inst = ub.x, b0 = ub.y;
         const int fg = plan[inst * kPlanI + 0], tn = plan[inst * kPlanI + 1];
         const bool thin = plan[inst * kPlanI + 2] != 0;
-        if (tn == 0) {                                                 // uniform; RV/ransac_voting_gpu.py:536-539
-            if (b0 == 0 && threadIdx.x == 0) {
-                out_xy[inst * 2] = 0.0f; out_xy[inst * 2 + 1] = 0.0f;
-                if (out_tn) out_tn[inst] = 0;
-                if (out_win_idx) out_win_idx[inst] = -1;
-                if (out_win_count) out_win_count[inst] = 0;
-                if (out_inl) out_inl[inst] = 0;
-                if (out_refine)
-                    for (int i = 0; i < 8; ++i) out_refine[(size_t)inst * 8 + i] = 0.0;
-            }
-            continue;
-        }
         const int nent = fg;
+        const int nb_i = (nent + kBlockPx - 1) / kBlockPx;              // units of this instance = arrivals to wait for
         const float fox = (float)plan[inst * kPlanI + 3], foy = (float)plan[inst * kPlanI + 4];
         const float frad = (float)plan[inst * kPlanI + 5];
-        const bool has_px = b0 * kBlockPx < nent;                      // uniform
-        if (!has_px) {
-            // a task without entries publishes nothing: it arrives at once, and only has work if it arrives last
-            __syncthreads();
-            if (threadIdx.x == 0) {
-                const int tk = __hip_atomic_fetch_add(&tickets[inst], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                s_last = (tk == nb_grid - 1);
-            }
-            __syncthreads();
-            if (!s_last) continue;                                     // uniform
-        }
         // winner: every task of the instance finds the same one
         int wc = -1, wi = 0x7fffffff;
         for (int h = threadIdx.x; h < hn; h += blockDim.x) {
@@ -957,12 +948,11 @@ __global__ __launch_bounds__(256) void k_vote_final(int W, int HW, int nch, int 
         const float wE = efac_ref * (fabsf(wxs) + fabsf(wys) + frad);
         const int32_t* tab = lds_table ? s_cpre : chunk_pre + (size_t)inst * (nch + 1);
 
-        if (has_px) {
         double v[kRec] = {0, 0, 0, 0, 0, 0};                            // inliers, a00, a01, a11, b0, b1
-        for (int b = b0; b * kBlockPx < nent; b += nb_grid) {
+        {
 #pragma unroll
             for (int tl = 0; tl < 2; ++tl) {
-                const int e = b * kBlockPx + (wv * 2 + tl) * kWave + lane;
+                const int e = b0 * kBlockPx + (wv * 2 + tl) * kWave + lane;
                 bool valid = e < nent;
                 const size_t slot = (size_t)inst * HW + (valid ? entry_slot(tab, nch, e) : 0);
                 const float4 q = list[slot];
@@ -995,15 +985,14 @@ __global__ __launch_bounds__(256) void k_vote_final(int W, int HW, int nch, int 
         __syncthreads();
         if (threadIdx.x == 0) {
             const int tk = __hip_atomic_fetch_add(&tickets[inst], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            s_last = (tk == nb_grid - 1);
+            s_last = (tk == nb_i - 1);
         }
         __syncthreads();
         if (!s_last) continue;                                         // uniform
-        }
 
         // last arriver of the instance: the records in task order (independent sc1 loads, four in flight per lane)
         if (wv == 0) {
-            const int nrec = min(nb_grid, (nent + kBlockPx - 1) / kBlockPx);
+            const int nrec = nb_i;
             double tot[kRec] = {0, 0, 0, 0, 0, 0};
             // lane = (record slot r8 = lane / 8, value a = lane % 8): eight records per sweep, then a fixed-order lane tree
             const int a = lane & 7, r8 = lane >> 3;
@@ -1146,13 +1135,12 @@ extern "C" int fpc_ransac_voting_v3(const float* mask, const float* vertex, int6
 #undef FPC_LAUNCH_COUNT
 #undef FPC_LAUNCH_COUNT2
 
-    // 4. winner, its inliers, refinement
-    const long long fin_tasks = (long long)n * nb_launch;
-    const int fin_grid = (int)std::min<long long>(fin_tasks, 8192);
+    // 4. winner, its inliers, refinement: one task per work unit
+    const int fin_grid = (int)std::min<long long>(std::max<long long>((long long)n * std::min(w.nbx, nb_launch), 1), 2048);
 #define FPC_LAUNCH_FINAL(M)                                                                                              \
-    hipLaunchKernelGGL(k_vote_final<M>, dim3(fin_grid), dim3(256), table_lds, s, W, HW, w.nch, n, n_dev, hn, w.hnp, nb_launch,  \
-                       w.nbx, inlier_thresh, kappa1, kappa2, efac, max_num, seed, keep, lds_table, w.chunk_pre, w.plan, w.hyp, \
-                       w.upper, w.list, w.clist, w.tickets, w.partial, out_xy, out_tn, out_win_idx, out_win_count,         \
+    hipLaunchKernelGGL(k_vote_final<M>, dim3(fin_grid), dim3(256), table_lds, s, W, HW, w.nch, n, n_dev, w.units, w.n_units, hn, \
+                       w.hnp, w.nbx, inlier_thresh, kappa1, kappa2, efac, max_num, seed, keep, lds_table, w.chunk_pre, w.plan, \
+                       w.hyp, w.upper, w.list, w.clist, w.tickets, w.partial, out_xy, out_tn, out_win_idx, out_win_count,   \
                        out_inl_count, out_refine)
     if (fast) FPC_LAUNCH_FINAL(kModeCones); else FPC_LAUNCH_FINAL(kModeReference);
 #undef FPC_LAUNCH_FINAL
