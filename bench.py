@@ -54,7 +54,9 @@ if REPO not in sys.path:
 
 HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured float4 copy)
 MFMA_F32_PEAK_TFLOPS = 157.3    # MI355X_MICROARCH.md: f32-input MFMA = f32 vector peak (155 measured)
-VALU_PEAK_WAVE_INSTR_PER_S = 1024 * 2.4e9 / 2      # 1024 SIMD-32 units, a wave64 instruction issues over 2 cycles
+VALU_PEAK_WAVE_INSTR_PER_S = 1024 * 2.4e9 / 2      # 1024 SIMD-32 units, a wave64 instruction issues over 2 cycles (the guide)
+VALU_MEASURED_F32_PER_S = 1024 * 2.4e9 / 4         # what plain f32 VALU streams sustained here: 4 cycles per wave64 instruction
+                                                   # at 5 waves/SIMD (tools_dev/vote_step_bench.hip; DESIGN.md, k_vote_count)
 H, W = 480, 640
 
 
@@ -301,12 +303,10 @@ def run_inference(args, encoder, Bq, hn, steps, warmup, world, rank, dev, want_b
         from fastposecnn_amd.tools.dataset import FrameUploader
         up = FrameUploader(Bq, 480, 640, device=dev, slots=depth + 2)
         frames = np.random.default_rng(0).integers(0, 256, (Bq, 480, 640, 3), dtype=np.uint8)
-        cur = torch.cuda.current_stream(dev)
 
         def step_host():
             t, ready = up.upload(frames)
-            cur.wait_event(ready)
-            pending.append(streamer.submit(t, categorical_override=cat))
+            pending.append(streamer.submit(t, categorical_override=cat, ready=ready))
             if len(pending) > depth:
                 finish(pending.pop(0))
 
@@ -413,6 +413,7 @@ def main():
                 rate = vinst / (roof["launch_ms"] * 1e-3)
                 roof["valu"] = {"bound": "valu", "achieved": round(rate / 1e9, 2), "peak": round(VALU_PEAK_WAVE_INSTR_PER_S / 1e9, 1),
                                 "unit": "G wave-instr/s", "frac": round(rate / VALU_PEAK_WAVE_INSTR_PER_S, 4),
+                                "frac_of_measured_plain_f32_rate": round(rate / VALU_MEASURED_F32_PER_S, 4),
                                 "wave_instructions_per_launch": vinst,
                                 "note": "SQ_INSTS_VALU of the four kernels (profiles/r02_vote_traffic.json, separate --pmc pass) / the "
                                         "live launch time; peak = 1024 SIMD-32 x 2.4 GHz / 2 cycles per wave64 instruction"}

@@ -82,13 +82,17 @@ class FrameStreamer:
         for _ in range(len(self.models)):
             self.collect(self.submit(x, categorical_override=categorical_override))
 
-    def submit(self, x, categorical_override=None):
+    def submit(self, x, categorical_override=None, ready=None):
         """Enqueue one frame (x f32 [B,3,H,W] on the device).  `categorical_override` replaces the
-        network's categorical output as the input of the post-network stages (benchmark fixture)."""
+        network's categorical output as the input of the post-network stages (benchmark fixture).
+        `ready`: the event after which x is valid (e.g. FrameUploader.upload's); default: everything enqueued so far on
+        the caller's current stream."""
         k = self._n % len(self.models)
         self._n += 1
-        x_ready = torch.cuda.Event()
-        x_ready.record(torch.cuda.current_stream(self.device))
+        x_ready = ready
+        if x_ready is None:
+            x_ready = torch.cuda.Event()
+            x_ready.record(torch.cuda.current_stream(self.device))
         seed = int(torch.randint(0, 2 ** 62, (1,)).item())    # the vote's sampler seed: drawn here, in submission order
         key = (k, tuple(x.shape))
         if key not in self._warm:
