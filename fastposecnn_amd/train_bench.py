@@ -70,6 +70,8 @@ def main(args):
     _native.lib()
 
     Bq = args.train_batch
+    # MIOpen's find mode (FPC_TRAIN_MIOPEN_FIND=1) was measured: same step time (59.3 ms either way) after minutes of search
+    torch.backends.cudnn.benchmark = bool(int(os.environ.get("FPC_TRAIN_MIOPEN_FIND", "0")))
     hp = config.HEAD_TRAINING()
     hp.ENCODER = args.encoder
     hp.RUNTIME_TIMING = False
