@@ -24,11 +24,14 @@ import torch
 import torch.distributed as dist
 
 
-def _fixture_logit_offsets(cat, G=6, gain=12.0):
-    """Constant logits that make class compression reproduce the fixture `cat` (lib/gpu_tensor_funcs.class_compress)."""
+def _fixture_logit_offsets(cat, G=6, gain=12.0, mask_gain=40.0):
+    """Constant logits that make class compression reproduce the fixture `cat` (lib/gpu_tensor_funcs.class_compress).
+    The mask margin is wide enough that the random-weight network's own mask logits never flip a pixel: the predicted
+    instances stay the fixture's while the weights move (with a margin of 12 the count drifted from 78 to 544 specks
+    over 20 optimiser steps and the matching / loss stage with it)."""
     B, H, W = cat["mask"].shape
     onehot = torch.nn.functional.one_hot(cat["mask"], G + 1).permute(0, 3, 1, 2).float()
-    off = {"mask": onehot * gain}
+    off = {"mask": onehot * mask_gain}
     sel = torch.nn.functional.one_hot((cat["mask"] - 1).clamp(min=0), G).permute(0, 3, 1, 2).unsqueeze(2).float()
     sel = sel * (cat["mask"] != 0).float().view(B, 1, 1, H, W)
     for key, a in (("quaternion", 4), ("scales", 3), ("xy", 2), ("z", 1)):
@@ -70,6 +73,9 @@ def main(args):
     _native.lib()
 
     Bq = args.train_batch
+    # the step's host work is a few dozen tiny CPU tensor ops (matching's arg-max on an [n1,n2] matrix, scalar NaN tests):
+    # torch's intra-op pool (one thread per core, 256 here) only adds wake-up stalls to them
+    torch.set_num_threads(int(os.environ.get("FPC_TRAIN_CPU_THREADS", "4")))
     # MIOpen's find mode (FPC_TRAIN_MIOPEN_FIND=1) was measured: same step time (59.3 ms either way) after minutes of search
     torch.backends.cudnn.benchmark = bool(int(os.environ.get("FPC_TRAIN_MIOPEN_FIND", "0")))
     hp = config.HEAD_TRAINING()
@@ -120,8 +126,14 @@ def main(args):
         step()
     barrier()
     t0 = time.perf_counter()
+    trace = []
     for _ in range(args.steps):
         step()
+        if os.environ.get("FPC_TRAIN_TRACE"):
+            torch.cuda.synchronize()
+            trace.append(round((time.perf_counter() - t0) * 1e3, 1))
+    if trace and rank == 0:
+        print("cumulative ms per step:", trace, flush=True)
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
