@@ -3,45 +3,38 @@
 //  * fpc_generate_hypothesis / fpc_voting_for_hypothesis: B1-compatible kernels
 //    (reference: RV/src/ransac_voting_kernel.cu:11-167).
 //  * fpc_ransac_voting_v3: the whole of ransac_voting_layer_v3 (RV/ransac_voting_gpu.py:518-607) for a batch of
-//    instances in FOUR stateless launches, without a host round trip, without the hn x tn inlier matrix and without
-//    a compacted pixel list on the critical path:
+//    instances in FOUR stateless launches, without a host round trip and without the hn x tn inlier matrix:
 //
-//      k_vote_scan    streams the mask planes once (float4 per lane) into a 1-bit-per-pixel image: per 64 pixels a
-//                     u64 word, its in-chunk exclusive count, per 4096-pixel chunk the foreground count.
-//                                                                                   (HBM: n x H*W*4 bytes read)
-//      k_vote_plan    one 1024-thread workgroup per instance: chunk prefix, the > max_num thinning (:541-545: the
-//                     kept pixels replace the bit image, so everything downstream sees the thinned instance), then
-//                     the hn hypotheses (:552,559): pair sampling, pixel look-up by rank in the bit image (two
-//                     binary searches + select), the vote gathered from the caller's strided planes, 2-line
-//                     intersection exactly as .cu:28-45.  Writes the points as SoA rows the count kernel reads
-//                     with scalar loads, per 64 hypotheses the rounding allowance E_g of the filter, and zeroes the
-//                     instance's count row.
-//      k_vote_count   task = (instance, 256-pixel block, slice of the hypotheses); lanes own pixels (looked up by
-//                     rank, votes gathered once: the only read of the vote planes), the hypotheses arrive in SGPRs.
-//                     Per (pixel, hypothesis): 4 FMA + 1 compare, ballot + s_bcnt1, one v_writelane per
-//                     hypothesis — an UPPER BOUND U_h of the inlier count (cone widened by the reference's own
-//                     rounding, see below).  A block's counts are combined in LDS and added to the instance's row
-//                     with one integer atomic per (block, hypothesis) that has any; slice 0 also leaves the block's
-//                     pixels (raw and as filter constants) as two float4 lists for the refinement.
-//      k_vote_refine  one 1024-thread workgroup per instance: candidates in order (U desc, index asc), four per pass,
-//                     are counted EXACTLY — two cones decide almost every pixel ("surely an inlier" / "surely not"),
-//                     the pixels between them take the reference's own arithmetic (.cu:106-125) — until no
-//                     remaining U can beat or tie-break the best exact count: that is torch.max's winner (:567, first
-//                     maximal index).  The winner's inliers give the fp64 normal equations and the closed-form 2x2
-//                     solve (b_inv, :503-516, :583-599).
+//      k_vote_scan    task = (instance, chunk of 4096 pixels): the only pass over the caller's planes.  Mask -> bit words,
+//                     in-chunk prefix, chunk count and bounding box; the chunk's foreground pixels are compacted in order
+//                     into its own slots of two float4 lists: {x, y, dx, dy} (vote gathered through the caller's
+//                     strides) and the pixel's filter constants.            (HBM: n x 12 H W bytes read: at the roofline)
+//      k_vote_plan    one 1024-thread workgroup per instance: chunk prefix (rank -> slot), the > max_num thinning
+//                     (:541-545), the integer origin / radius the filter's coordinates are measured from, the hn
+//                     hypotheses (:552,559; pair sampling, two-line intersection exactly as .cu:28-45) as SoA rows, the
+//                     rounding allowance E_g per 64 of them, a zeroed count row, and the WORK UNITS: one (instance, block of
+//                     512 list entries) record per block that has entries, appended to a device-side list.
+//      k_vote_count   one resident round of workgroups over units x hypothesis slices (the slicing is chosen on the device
+//                     from the unit count).  EXACT inlier counts: per (entry, point) the margins to two cones, their sign
+//                     bits shifted into per-lane bit rows; after 64 points a 64 x 64 bit transpose across the wave and
+//                     v_bcnt give the counts; the pairs between the cones are queued and take the reference's own
+//                     arithmetic (.cu:106-125) 64 at a time.  Integer atomics per (block, hypothesis).
+//      k_vote_final   task = work unit: torch.max's winner (:567, first maximal index), its inliers voted again, fp64
+//                     normal-equation records; the unit of an instance that arrives last sums them in unit order and
+//                     solves the 2x2 system in closed form (b_inv, :503-516, :583-599).
 //
 // Why the cones are sound: the reference accepts a pair when fl(cos) > th, where fl(cos) carries at most
 // 8 ulp(1) < 1e-6 of rounding.  So an accepted pair has true cos >= th' = th - 1e-6, i.e. |s| <= kappa' t with
 // t = d.e, s = d x e (e the unit vote, d = h - p), kappa' = sqrt(1-th'^2)/th' ("maybe"), and a pair with true
 // cos >= th'' = th + 1e-6, i.e. |s| <= kappa'' t, is accepted for sure.  t and s are affine in the hypothesis (two
-// FMAs each against per-pixel constants); the evaluation's own rounding is at most (3.6e-7 + 4.8e-7 kappa) M with
-// M = |hx| + |hy| + W + H (six roundings at magnitude <= M on the s side, eight at kappa M on the t side):
+// FMAs each against per-pixel constants, all measured from the instance's integer origin so that magnitudes stay
+// small); the evaluation's own rounding is at most (3.6e-7 + 4.8e-7 kappa) M with M = |gx - ox| + |gy - oy| + radius
+// (six roundings at magnitude <= M on the s side, eight at kappa M on the t side):
 //     accepted  =>  |s| <= kappa' t + E        (computed values);        |s| <= kappa'' t - E  =>  accepted
-// for any E >= that bound.  k_vote_count folds kappa' and E into the constants:
-// kappa' t + E = (kappa' ex) gx + (kappa' ey) gy + (kappa' ct + E_g), E_g = max over the 64 hypotheses of a group of
-// 1e-6 (1 + kappa') M; k_vote_refine classifies with 2e-6 (1 + kappa') M per hypothesis.  Hypotheses with huge or
-// non-finite coordinates are outside the filter's domain: their U is the pixel count and every pixel takes the
-// reference's arithmetic.  Thresholds <= 2e-6 have no cone: every pair takes the reference's arithmetic (U exact).
+// for any E >= that bound; E_g = max over the 64 hypotheses of a group of 2e-6 (1 + kappa') M.  The compares are taken
+// as sign bits of differences (x - y >= 0 exactly when y <= x in IEEE arithmetic).  A group with a huge or non-finite
+// point is outside the filter's domain: every pair of it takes the reference's arithmetic.  Thresholds <= 2e-6 have no
+// cone: kModeReference.
 //
 // One RANSAC round: the reference's rounds re-evaluate identical samples.
 #include <stdlib.h>
