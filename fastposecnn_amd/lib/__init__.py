@@ -4,8 +4,8 @@ Like the reference, the directory itself is put on sys.path and the modules are 
 under their bare names (`gpu_tensor_funcs`, `aggregation_layer`, `hough_voting`,
 `pose_regressor`, `ransac_voting_gpu_layer.*`), so `train.py` / `evaluate.py` /
 `inference.py` keep working with `import lib` pointed at this directory.
-`matching.batchwise_find_matches` is shipped; loss / metrics and the rest of
-matching.py are outside the hot path and are not.
+`matching.batchwise_find_matches`, `loss` and `metrics` (ranks 2 and 4: the classes
+train.py selects) are shipped; the rest of matching.py is outside the hot path and is not.
 """
 import os
 import sys
@@ -18,7 +18,10 @@ if _HERE not in sys.path:
     sys.path.insert(0, _HERE)
 
 import gpu_tensor_funcs as gtf  # noqa: E402
+import matching as mg  # noqa: E402,F401   (the reference's alias, F/lib/__init__.py:8)
 import aggregation_layer  # noqa: E402
 import hough_voting  # noqa: E402
 import pose_regressor  # noqa: E402
 import matching  # noqa: E402
+import loss  # noqa: E402
+import metrics  # noqa: E402

@@ -147,3 +147,40 @@ def test_eval_maths_native_matches_reference(G):
 @pytest.mark.gpu
 def test_losses_match_reference_gpu(G):
     _check_losses(G, "cuda")
+
+
+def _check_metrics(G, dev):
+    """lib/metrics.py accumulators over two rounds against the arithmetic of F/lib/metrics.py applied to the golden values."""
+    import fastposecnn_amd.lib  # noqa: F401
+    import metrics as M
+    n = G["q0"].shape[0]
+    m = {"symmetric_ids": _t(G["sym"], dev), "class_ids": _t(G["cls"], dev)}
+    for key, a, b in (("quaternion", "q0", "q1"), ("scales", "s0", "s1"), ("T", "T0", "T1"), ("RT", "RT0", "RT1")):
+        m[key] = torch.stack((_t(G[a], dev), _t(G[b], dev)))
+    deg, iou, off, off_rt = G["deg_mixed"], G["iou3d"], G["offset"], float(G["offset_rt"])
+    table = M.head_training_metrics()["pose"]
+    assert set(table) == {"degree_error", "degree_error_AP_5", "iou_3d_mAP_0.25", "iou_3d_accuracy", "offset_error_AP_5cm", "offset_error"}
+    for rounds in (1, 2):
+        for e in table.values():
+            e["F"].reset()
+        out = {}
+        for _ in range(rounds):
+            out = {k: e["F"](m) for k, e in table.items()}
+        run = lambda v: v / 2 if rounds == 1 else (v / 2 + v) / 2          # state = (state + value) / 2 from 0
+        want = {"degree_error": run(deg.mean()), "degree_error_AP_5": (deg < 5).mean() * 100,
+                "iou_3d_mAP_0.25": (iou > 0.25).mean() * 100, "iou_3d_accuracy": run((iou * 100).mean()),
+                "offset_error_AP_5cm": (off < 5).mean() * 100, "offset_error": run(off_rt)}
+        for k, w in want.items():
+            assert abs(float(out[k]) - float(w)) <= 1e-4 * max(1.0, abs(float(w))), (k, float(out[k]), float(w))
+    # no matches: the state is untouched
+    d = M.DegreeError()
+    assert float(d(None)) == 0.0 and float(d({"instance_masks": torch.zeros(1)})) == 0.0
+
+
+def test_metrics_accumulators_cpu(G):
+    _check_metrics(G, "cpu")
+
+
+@pytest.mark.gpu
+def test_metrics_accumulators_gpu(G):
+    _check_metrics(G, "cuda")
