@@ -474,14 +474,26 @@ __global__ __launch_bounds__(1024) void k_vote_plan(const uint8_t* __restrict__ 
             // count / exact kernels re-derive each entry's decision.
             for (int c = wv; c < nch; c += nw) {
                 const size_t wi = (size_t)c * kChunkWords + lane;
-                uint64_t rem = bw[wi], kept = 0;
-                while (rem) {
-                    const int b = __ffsll((long long)rem) - 1;
-                    rem &= rem - 1;
-                    const int p = (int)(wi * 64) + b;
-                    const bool k = keep ? (keep[(size_t)inst * HW + p] != 0)
-                                        : (fpc_rand_keep(seed, (uint32_t)inst, (uint32_t)p, (uint32_t)fg, (uint32_t)max_num) != 0);
-                    if (k) kept |= 1ull << b;
+                // lane = word for the loads and the prefix; the keep decisions of one word are taken by the 64 lanes at
+                // once (lane = pixel), word by word over the chunk's non-empty words: a dense chunk costs 64 hashes per
+                // lane, not 64 x 64 (one lane walking its own word's bits was 35 us for a 30 000-pixel instance)
+                const uint64_t word = bw[wi];
+                uint64_t kept = 0;
+                unsigned long long todo = __builtin_amdgcn_ballot_w64(word != 0);
+                while (todo) {                                               // uniform
+                    const int w = __ffsll((long long)todo) - 1;
+                    todo &= todo - 1;
+                    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)word, w);
+                    const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(word >> 32), w);
+                    const uint64_t ww = ((uint64_t)hi << 32) | lo;
+                    bool k = false;
+                    if ((ww >> lane) & 1ull) {
+                        const int p = (int)(((size_t)c * kChunkWords + w) * 64) + lane;
+                        k = keep ? (keep[(size_t)inst * HW + p] != 0)
+                                 : (fpc_rand_keep(seed, (uint32_t)inst, (uint32_t)p, (uint32_t)fg, (uint32_t)max_num) != 0);
+                    }
+                    const uint64_t kw = __builtin_amdgcn_ballot_w64(k);
+                    if (lane == w) kept = kw;
                 }
                 int tot;
                 const int ex = wave_excl_scan(__popcll(kept), tot);
@@ -1100,7 +1112,8 @@ extern "C" int fpc_ransac_voting_v3(const float* mask, const float* vertex, int6
     const size_t table_lds = lds_table ? (size_t)(w.nch + 1) * sizeof(int) : 0;
 
     // 2. per instance: prefix, thinning, origin, hypotheses, zeroed count row and arrival ticket
-    hipLaunchKernelGGL(k_vote_plan, dim3(std::min(n, 2048)), dim3(1024), 2 * table_lds, s, keep, W, HW, w.nch, n, n_dev, hn, w.hnp,
+    static const int plan_threads = getenv("FPC_PLAN_THREADS") ? atoi(getenv("FPC_PLAN_THREADS")) : 1024;      // tuning aid
+    hipLaunchKernelGGL(k_vote_plan, dim3(std::min(n, 2048)), dim3(plan_threads), 2 * table_lds, s, keep, W, HW, w.nch, n, n_dev, hn, w.hnp,
                        idxs, seed, min_num, max_num, efac, lds_table, w.chunk_fg, w.chunk_box, w.chunk_pre, w.word_pre, w.bits,
                        w.chunk_preK, w.word_preK, w.bitsK, w.list, w.plan, w.hx, w.hy, w.hxs, w.hys, w.eg, w.hyp, w.upper,
                        w.tickets, w.units, w.n_units);

@@ -7,7 +7,7 @@ mkdir -p $OUT
 run() {   # name, then exported env assignments
     name=$1; shift
     for kv in "$@"; do export "$kv"; done
-    cd /tmp && timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/$name -- python3 /root/repo/tools_dev/vote_time.py ${B:-1} ${HN:-1000} 100 > $OUT/$name.log 2>&1
+    rm -rf $OUT/$name; cd /tmp && timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/$name -- python3 /root/repo/tools_dev/vote_time.py ${B:-1} ${HN:-1000} 100 > $OUT/$name.log 2>&1
     cd /root/repo
     f=$(ls $OUT/$name/*/*kernel_stats.csv | tail -1)
     echo "== $name"; python tools_dev/kstats.py $f --top 4 | tail -4
