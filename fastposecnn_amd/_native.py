@@ -40,6 +40,7 @@ _SIGNATURES = {
     "fpc_post_network_backward": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _f, _i, _u64, _vp, _vp, _vp, _vp, _vp, _vp]),
     "fpc_vote_refine_backward": (_i, [_vp, _vp, _i64, _i64, _i64, _i64, _i, _i, _i, _vp, _f, _i, _u64, _vp, _vp, _vp]),
     "fpc_class_compress_backward": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
+    "fpc_mask_losses": (_i, [_vp, _vp, _i, _i, _i, _i64, _i64, _f, _f, _vp, _vp, _vp, _vp]),
     "fpc_grad_sumsq": (_i, [_vp, _sz, _vp, _vp]),
     "fpc_lookahead_radam_step": (_i, [_vp, _vp, _vp, _vp, _vp, _sz, _f, _f, _f, _f, _f, _i64, _i, _f, _vp, _vp]),
     "fpc_pose_rt": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp]),

@@ -168,6 +168,102 @@ __global__ __launch_bounds__(256) void k_cc_backward(const int64_t* __restrict__
     }
 }
 
+// ---- mask losses --------------------------------------------------------------------------------------------------
+// CE + CCE + Focal of F/lib/loss.py:26-98 on the mask logits [B,C,HW] in ONE pass each way.  The reference (and the
+// torch-op mirror in lib/loss.py) runs log_softmax three times, two NLL reductions and, for Focal, ~8 elementwise
+// kernels per class over the 17 M logits of a batch-8 step.  Per pixel: y = log_softmax(x);
+//   CE  = -y[t]                          (nn.CrossEntropyLoss: its own ignore_index = -100)
+//   CCE = -y[t]  unless t == ignore      (nn.NLLLoss(ignore_index))
+//   Focal = sum over classes c of  a_c (1 - pt)^gamma bce,  bce = BCE-with-logits(y_c, [t == c]),  pt = exp(-bce),
+//           a_c = alpha [t == c] + (1 - alpha) [t != c], unless t == ignore     (pytorch_toolbelt, applied to y as the
+//           reference does)
+// forward: sums and counts (fp64 atomics, one set per workgroup); backward: d/dx of  w0 CE + w1 CCE + w2 Focal  with the
+// three weights (upstream gradient / count) read from device memory: no host synchronisation.
+struct FocalTerm { float loss, dldy; };
+
+__device__ __forceinline__ FocalTerm focal_term(float y, bool pos, float alpha, float gamma) {
+    const float tgt = pos ? 1.0f : 0.0f;
+    const float bce = fmaxf(y, 0.0f) - y * tgt + log1pf(expf(-fabsf(y)));
+    const float pt = expf(-bce);
+    const float om = 1.0f - pt;
+    const float a = pos ? alpha : 1.0f - alpha;
+    const float fg = gamma == 2.0f ? om * om : powf(om, gamma);
+    const float sig = 1.0f / (1.0f + expf(-y));
+    const float dbce = sig - tgt;
+    // d/dy [ om^g bce ] = g om^(g-1) pt dbce bce + om^g dbce
+    const float dfg = gamma == 2.0f ? 2.0f * om : (om > 0.0f ? gamma * powf(om, gamma - 1.0f) : 0.0f);
+    FocalTerm r;
+    r.loss = a * fg * bce;
+    r.dldy = a * dbce * (dfg * pt * bce + fg);
+    return r;
+}
+
+template <int MAXC, bool BWD>
+__global__ __launch_bounds__(256) void k_mask_losses(const float* __restrict__ logits, const int64_t* __restrict__ target,
+                                                     int C, int HW, long long ignore_ce, long long ignore_cce, float alpha,
+                                                     float gamma, double* __restrict__ sums /* fwd: [6] */,
+                                                     const float* __restrict__ w3 /* bwd */, float* __restrict__ grad) {
+    __shared__ double s_red[4][6];
+    const int b = blockIdx.y;
+    double acc[6] = {0, 0, 0, 0, 0, 0};        // ce sum, ce count, cce sum, cce count, focal sum, focal count
+    float w0 = 0.f, w1 = 0.f, w2 = 0.f;
+    if (BWD) { w0 = w3[0]; w1 = w3[1]; w2 = w3[2]; }
+    for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < HW; p += gridDim.x * blockDim.x) {
+        const float* x = logits + (size_t)b * C * HW + p;
+        const long long t = target[(size_t)b * HW + p];
+        float v[MAXC];
+        float mx = x[0];
+        v[0] = mx;
+#pragma unroll
+        for (int c = 1; c < MAXC; ++c)
+            if (c < C) { v[c] = x[(size_t)c * HW]; mx = fmaxf(mx, v[c]); }
+        float se = 0.0f;
+#pragma unroll
+        for (int c = 0; c < MAXC; ++c)
+            if (c < C) se += expf(v[c] - mx);
+        const float lse = mx + logf(se);
+        const bool ce_on = t != ignore_ce && t >= 0 && t < C, cce_on = t != ignore_cce && t >= 0 && t < C;
+        const bool foc_on = t != ignore_cce;
+        float gy[MAXC];
+        float gsum = 0.0f;
+#pragma unroll
+        for (int c = 0; c < MAXC; ++c)
+            if (c < C) {
+                const float y = v[c] - lse;
+                const bool pos = t == c;
+                float g = 0.0f;
+                if (pos && ce_on) { acc[0] -= (double)y; g -= w0; }
+                if (pos && cce_on) { acc[2] -= (double)y; g -= w1; }
+                if (foc_on) {
+                    const FocalTerm f = focal_term(y, pos, alpha, gamma);
+                    acc[4] += (double)f.loss;
+                    g += w2 * f.dldy;
+                }
+                gy[c] = g;
+                gsum += g;
+            }
+        acc[1] += ce_on ? 1.0 : 0.0;
+        acc[3] += cce_on ? 1.0 : 0.0;
+        acc[5] += foc_on ? 1.0 : 0.0;
+        if (BWD) {      // y = x - lse(x):  dL/dx_j = g_j - softmax_j sum_c g_c
+            float* go = grad + (size_t)b * C * HW + p;
+#pragma unroll
+            for (int c = 0; c < MAXC; ++c)
+                if (c < C) go[(size_t)c * HW] = gy[c] - expf(v[c] - lse) * gsum;
+        }
+    }
+    if (!BWD) {
+        const int lane = threadIdx.x & (kWave - 1), wv = threadIdx.x / kWave;
+#pragma unroll
+        for (int a = 0; a < 6; ++a) {
+            const double r = wave_reduce_add(acc[a]);
+            if (lane == 0) s_red[wv][a] = r;
+        }
+        __syncthreads();
+        if (threadIdx.x < 6) unsafeAtomicAdd(&sums[threadIdx.x], s_red[0][threadIdx.x] + s_red[1][threadIdx.x] + s_red[2][threadIdx.x] + s_red[3][threadIdx.x]);
+    }
+}
+
 // ---- optimiser --------------------------------------------------------------------------------------------------
 // out[0] += sum g^2 (fp64), out[1] != 0 when a non-finite element was seen.  One atomic pair per workgroup.
 __global__ __launch_bounds__(256) void k_sumsq(const float* __restrict__ g, size_t n, double* __restrict__ out) {
@@ -305,5 +401,22 @@ extern "C" int fpc_lookahead_radam_step(float* p, const float* g, float* m, floa
     a.la_init = step == 1 ? 1 : 0;
     const int grid = (int)std::min<size_t>(4096, (n + 255) / 256);
     hipLaunchKernelGGL(k_lookahead_radam, dim3(grid), dim3(256), 0, (hipStream_t)stream, p, g, m, v, slow, n, a, ctl);
+    return check_launch();
+}
+
+extern "C" int fpc_mask_losses(const float* logits, const int64_t* target, int B, int C, int HW, int64_t ignore_ce,
+                               int64_t ignore_cce, float alpha, float gamma, double* sums6, const float* w3, float* grad,
+                               fpc_stream_t stream) {
+    if (B < 0 || C < 2 || C > 32 || HW < 1) return FPC_EINVAL;
+    if (B == 0) return FPC_OK;
+    if (B > 65535 || !logits || !target || (!sums6 && !grad) || (grad && !w3)) return FPC_EINVAL;
+    const dim3 grid(std::min(cdiv(HW, 256), 1024), B);
+    hipStream_t s = (hipStream_t)stream;
+#define FPC_ML(MAXC, BWD)                                                                                              \
+    hipLaunchKernelGGL((k_mask_losses<MAXC, BWD>), grid, dim3(256), 0, s, logits, target, C, HW, (long long)ignore_ce,     \
+                       (long long)ignore_cce, alpha, gamma, sums6, w3, grad)
+    if (grad) { if (C <= 8) FPC_ML(8, true); else FPC_ML(32, true); }
+    else { if (C <= 8) FPC_ML(8, false); else FPC_ML(32, false); }
+#undef FPC_ML
     return check_launch();
 }

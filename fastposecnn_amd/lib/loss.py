@@ -24,6 +24,55 @@ def _nan(gt_pred_matches=None):
 
 
 # ---- mask losses (F/lib/loss.py:26-98) ---------------------------------------------------------------------------
+class _MaskLossFn(torch.autograd.Function):
+    """One of CE / CCE / Focal (which = 0 / 1 / 2) from the shared forward sums; its own backward launch, so the three loss
+    objects stay independent autograd nodes (csrc/train.hip: k_mask_losses)."""
+
+    @staticmethod
+    def forward(ctx, logits, target, sums, which, ignore_cce, alpha, gamma):
+        ctx.save_for_backward(logits, target, sums)
+        ctx.args = (int(which), int(ignore_cce), float(alpha), float(gamma))
+        return (sums[2 * which] / sums[2 * which + 1]).float()
+
+    @staticmethod
+    def backward(ctx, g):
+        from fastposecnn_amd import _native as nat
+        x, t, sums = ctx.saved_tensors
+        which, ignore_cce, alpha, gamma = ctx.args
+        w3 = torch.zeros(3, dtype=torch.float32, device=x.device)
+        w3[which] = (g.double() / sums[2 * which + 1]).float()
+        grad = torch.empty_like(x)
+        with torch.cuda.device(x.device):
+            nat.check(nat.lib().fpc_mask_losses(nat.ptr(x), nat.ptr(t), x.shape[0], x.shape[1], x[0, 0].numel(), -100, ignore_cce,
+                                                alpha, gamma, None, nat.ptr(w3), nat.ptr(grad), nat.stream()), "fpc_mask_losses")
+        return grad, None, None, None, None, None, None
+
+
+def _fused_mask_loss(which, logits, target, ignore_cce=-1, alpha=0.5, gamma=2):
+    """CE / CCE / Focal (which = 0 / 1 / 2) for GPU f32 logits; the forward pass (all three sums) runs once per
+    (logits, target, parameters) and is shared by the three loss objects of the criterion table, which are called one after
+    the other on the same tensors.  None when the torch-op forms must run."""
+    import os
+    if not (logits.is_cuda and logits.dtype == torch.float32 and logits.dim() >= 3 and logits.shape[1] <= 32
+            and bool(int(os.environ.get("FPC_FUSED_MASK_LOSSES", "1")))):
+        return None
+    from fastposecnn_amd import _native as nat
+    key = (int(ignore_cce), float(alpha), float(gamma))
+    cached = getattr(logits, "_fpc_mask_losses", None)
+    if cached is not None and cached[0] is target and cached[1] == key and cached[2] == logits._version:
+        x, t, sums = cached[3]
+    else:
+        x = logits.detach()
+        x = x if x.is_contiguous() else x.contiguous()
+        t = target.to(torch.int64).contiguous()
+        sums = torch.zeros(6, dtype=torch.float64, device=x.device)
+        with torch.cuda.device(x.device):
+            nat.check(nat.lib().fpc_mask_losses(nat.ptr(x), nat.ptr(t), x.shape[0], x.shape[1], x[0, 0].numel(), -100, key[0], key[1],
+                                                key[2], nat.ptr(sums), None, None, nat.stream()), "fpc_mask_losses")
+        logits._fpc_mask_losses = (target, key, logits._version, (x, t, sums))
+    return _MaskLossFn.apply(logits, t, sums, which, *key)
+
+
 class CE(_Loss):
 
     def __init__(self, ignore_index=-1):
@@ -31,6 +80,9 @@ class CE(_Loss):
         self.ignore_index = ignore_index
 
     def forward(self, pred, gt):
+        fused = _fused_mask_loss(0, pred['logits']['mask'], gt['mask'])
+        if fused is not None:
+            return fused
         return nn.functional.cross_entropy(pred['logits']['mask'], gt['mask'])
 
 
@@ -42,6 +94,9 @@ class CCE(_Loss):
         self.ignore_index = ignore_index
 
     def forward(self, pred, gt):
+        fused = _fused_mask_loss(1, pred['logits']['mask'], gt['mask'], ignore_cce=self.ignore_index)
+        if fused is not None:
+            return fused
         y = nn.functional.log_softmax(pred['logits']['mask'], dim=1)
         return nn.functional.nll_loss(y, gt['mask'], ignore_index=self.ignore_index)
 
@@ -87,6 +142,9 @@ class Focal(_Loss):
         self.gamma = gamma
 
     def forward(self, pred, gt):
+        fused = _fused_mask_loss(2, pred['logits']['mask'], gt['mask'], ignore_cce=self.ignore_index, alpha=self.alpha, gamma=self.gamma)
+        if fused is not None:
+            return fused
         y = nn.functional.log_softmax(pred['logits']['mask'], dim=1)       # the reference feeds log-probabilities (:91-98)
         return FocalLoss(alpha=self.alpha, gamma=self.gamma, ignore_index=self.ignore_index)(y, gt['mask'])
 

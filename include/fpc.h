@@ -27,6 +27,7 @@
  *   fpc_post_network_backward    torch autograd over lib/aggregation_layer.py:119-156 + RV/ransac_voting_gpu.py:583-599
  *   fpc_vote_refine_backward     torch autograd over RV/ransac_voting_gpu.py:583-599
  *   fpc_class_compress_backward  torch autograd over lib/gpu_tensor_funcs.py:37-99
+ *   fpc_mask_losses              lib/loss.py:26-98 (CE, CCE, Focal: forward sums and the combined logit gradient)
  *   fpc_lookahead_radam_step     lib/pose_regressor.py:417-423 (catalyst Lookahead(RAdam)), F/train.py gradient_clip_val,
  *                                lib/pose_regressor.py:341-415 (inf / NaN guard)
  * The Python-side bindings a maintainer would add are shown in INTEGRATION.md.
@@ -203,6 +204,13 @@ int fpc_vote_refine_backward(const float* mask, const float* vertex, int64_t vs_
 int fpc_class_compress_backward(const int64_t* cat_mask, const float* quat, const float* xy, const float* go_q,
                                 const float* go_s, const float* go_xy, const float* go_z, int B, int C, int HW,
                                 float* g_q, float* g_s, float* g_xy, float* g_z, fpc_stream_t stream);
+/* The three mask losses of lib/loss.py:26-98 (CE, CCE, Focal on log-softmax outputs) on logits f32 [B,C,HW] and target
+ * i64 [B,HW], one pass.  grad == NULL: forward, sums6 f64 [6] (caller zeroes) += CE sum, CE count, CCE sum, CCE count,
+ * Focal sum, Focal count (each loss = sum / count).  grad != NULL: backward, grad f32 [B,C,HW] = d/dlogits of
+ * w3[0] * (CE sum) + w3[1] * (CCE sum) + w3[2] * (Focal sum), w3 DEVICE f32 [3] (upstream gradient / count). */
+int fpc_mask_losses(const float* logits, const int64_t* target, int B, int C, int HW, int64_t ignore_ce,
+                    int64_t ignore_cce, float alpha, float gamma, double* sums6, const float* w3, float* grad,
+                    fpc_stream_t stream);
 /* out2 f64 [2] (caller zeroes): [0] += sum g^2, [1] += 1 when a non-finite element was seen.  g 16-byte aligned. */
 int fpc_grad_sumsq(const float* g, size_t n, double* out2, fpc_stream_t stream);
 /* One Lookahead(RAdam) step on a flat f32 shard (p, g, m, v, slow: n elements each; step counts from 1).

@@ -258,3 +258,47 @@ def test_train_step_bench_line_and_two_ranks_on_one_gpu():
     for task in ("mask", "quaternion", "xy", "z", "scales"):
         assert chk["losses"][task]["task_total_loss"] is not None
     assert line["config"]["buckets"] >= 2
+
+
+def test_fused_mask_losses_match_torch_forms(monkeypatch):
+    """k_mask_losses (CE + CCE + Focal, forward sums and combined gradient) against the torch-op forms of lib/loss.py
+    (CE / CCE pinned by the reference's goldens, Focal = pytorch_toolbelt's published formula) incl. ignored pixels."""
+    import fastposecnn_amd.lib  # noqa: F401
+    import loss as L
+    g = torch.Generator().manual_seed(11)
+    B, C, H, W = 3, 7, 37, 53
+    x0 = torch.randn((B, C, H, W), generator=g) * 3
+    t = torch.randint(0, C, (B, H, W), generator=g)
+    res = {}
+    for fused in ("0", "1"):
+        monkeypatch.setenv("FPC_FUSED_MASK_LOSSES", fused)
+        x = x0.clone().cuda().requires_grad_(True)
+        pred, gt = {"logits": {"mask": x}}, {"mask": t.cuda()}
+        vals = [L.CE()(pred, gt), L.CCE()(pred, gt), L.Focal()(pred, gt)]
+        (5.0 * vals[0] + 3.0 * vals[1] + 7.0 * vals[2]).backward()
+        res[fused] = ([float(v.detach()) for v in vals], x.grad.clone())
+    for a, b in zip(res["0"][0], res["1"][0]):
+        assert abs(a - b) <= 2e-6 * max(1.0, abs(a)), (res["0"][0], res["1"][0])
+    g0, g1 = res["0"][1], res["1"][1]
+    assert (g0 - g1).abs().max().item() <= 2e-5 * g0.abs().max().item()
+    # the three objects share one forward launch per (logits, target)
+    monkeypatch.setenv("FPC_FUSED_MASK_LOSSES", "1")
+    x = x0.clone().cuda().requires_grad_(True)
+    pred, gt = {"logits": {"mask": x}}, {"mask": t.cuda()}
+    L.CE()(pred, gt)
+    first = x._fpc_mask_losses[3][2]
+    L.CCE()(pred, gt); L.Focal()(pred, gt)
+    assert x._fpc_mask_losses[3][2] is first
+    # ignored pixels (target -1) leave CCE and Focal, as nn.NLLLoss(ignore_index=-1) / toolbelt do
+    t2 = t.clone(); t2[0, :5] = -1
+    monkeypatch.setenv("FPC_FUSED_MASK_LOSSES", "0")
+    xa = x0.clone().cuda().requires_grad_(True)
+    want = [L.CCE()({"logits": {"mask": xa}}, {"mask": t2.cuda()}), L.Focal()({"logits": {"mask": xa}}, {"mask": t2.cuda()})]
+    (want[0] + want[1]).backward()
+    monkeypatch.setenv("FPC_FUSED_MASK_LOSSES", "1")
+    xb = x0.clone().cuda().requires_grad_(True)
+    got = [L.CCE()({"logits": {"mask": xb}}, {"mask": t2.cuda()}), L.Focal()({"logits": {"mask": xb}}, {"mask": t2.cuda()})]
+    (got[0] + got[1]).backward()
+    for a, b in zip(want, got):
+        assert abs(float(a) - float(b)) <= 2e-6 * max(1.0, abs(float(a)))
+    assert (xa.grad - xb.grad).abs().max().item() <= 2e-5 * xa.grad.abs().max().item()
