@@ -334,6 +334,62 @@ def test_frame_streamer_matches_forward(lib, dev, kw):
         assert out["aggregated"]["class_ids"].shape[0] == 3
 
 
+def test_frame_streamer_async_consumers_and_dropped_inputs(lib, dev):
+    """The ownership rule of FrameStreamer.collect under allocator pressure: every input tensor is created right before
+    submit() and dropped right after it, every output is consumed by kernels queued asynchronously on the caller's stream
+    and dropped at once, and other allocations churn the caller's pool in between.  The accumulated device-side checksums
+    must equal those of a run that synchronises after every frame (a block handed out again while a queued reader or
+    the frame's first kernel still uses it would change them)."""
+    from fastposecnn_amd import config, synth
+    from fastposecnn_amd.streaming import FrameStreamer
+    hp = config.INFERENCE()
+    hp.RUNTIME_TIMING = False
+    hp.HV_NUM_OF_HYPOTHESES = 64
+    torch.manual_seed(0)
+    m = lib.pose_regressor.MODELS['PoseRegressor'].load_from_ckpt(None, hp).to(dev).eval()
+    H, W = 96, 128
+    imgs = [synth.make_image(i, H, W)[None] for i in range(3)]
+    cats = []
+    for i in range(3):
+        c, _ = synth.make_vote_frame(i, K=3, H=H, W=W, rmin=8, rmax=20)
+        cats.append({k: v.to(dev) for k, v in c.items()})
+    st = FrameStreamer(m)
+    st.prepare(imgs[0].to(dev), categorical_override=cats[0])
+    nplan = len(st.models)
+
+    def run(n, sync_each):
+        acc = torch.zeros(4, dtype=torch.float64, device=dev)
+        pending = []
+        st._n = 0                                               # the same frame -> plan assignment in both runs
+
+        def consume(out):
+            # asynchronous readers on the caller's stream; the outputs are dropped when this returns
+            acc[0] += out["logits"]["quaternion"].double().sum()
+            acc[1] += out["categorical"]["mask"].double().sum()
+            acc[2] += out["aggregated"]["xy"].double().sum()
+            acc[3] += out["aggregated"]["RT"].double().sum()
+
+        for i in range(n):
+            torch.manual_seed(1000 + i)
+            x = imgs[i % 3].to(dev, non_blocking=True)          # fresh block every frame ...
+            pending.append(st.submit(x, categorical_override=cats[i % 3]))
+            del x                                               # ... dropped while its frame is still queued
+            junk = [torch.full((H * W * 24,), float(i), device=dev) for _ in range(3)]      # churn: the sizes of the logits
+            del junk
+            if len(pending) > nplan:
+                consume(st.collect(pending.pop(0)))
+                if sync_each:
+                    torch.cuda.synchronize()
+        while pending:
+            consume(st.collect(pending.pop(0)))
+        torch.cuda.synchronize()
+        return acc.cpu()
+
+    want = run(60, True)
+    got = run(60, False)
+    assert torch.equal(got, want), (got, want)
+
+
 def test_forward_with_runtime_timing_and_report(lib, dev, capsys):
     """config.INFERENCE defaults (RUNTIME_TIMING=True): the stage-by-stage path with the reference's six
     timers; whole forward() on a small frame with random weights (many tiny instances), schema check."""
