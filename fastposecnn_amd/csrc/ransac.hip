@@ -129,7 +129,8 @@ struct Ws {
     double* partial;      // [n, nbx, kRec] k_vote_final per-task records
     float4* list;         // [n, HW]        {x, y, dx, dy} of the foreground pixels, compacted per chunk (k_vote_scan)
     float4* clist;        // [n, HW]        {ey, -ex, cs, ct}: their filter constants (NaN cs: never an inlier)
-    int2* units;          // [n * nbx]      (instance, block of 512 list entries) of every block that has entries (k_vote_plan)
+    int4* units;          // [n * nbx]      {instance, block of 512 list entries, fg | thinned << 31, ox | oy << 16} of every
+                          //                block that has entries (k_vote_plan): all a count task needs to start loading
     int32_t* n_units;     // [1]            how many; zeroed by k_vote_scan
     int nch, nwords, hnp, nbx;
     size_t total;
@@ -165,7 +166,7 @@ static Ws carve(void* base, int n, int H, int W, int hn) {
     w.partial = (double*)take(sizeof(double) * (size_t)n * w.nbx * kRec);
     w.list = (float4*)take(sizeof(float4) * (size_t)n * HW);
     w.clist = (float4*)take(sizeof(float4) * (size_t)n * HW);
-    w.units = (int2*)take(sizeof(int2) * (size_t)n * w.nbx);
+    w.units = (int4*)take(sizeof(int4) * (size_t)n * w.nbx);
     w.n_units = (int32_t*)take(sizeof(int32_t));
     w.total = off;
     return w;
@@ -423,7 +424,7 @@ __global__ __launch_bounds__(1024) void k_vote_plan(const uint8_t* __restrict__ 
                                                     float* __restrict__ hxs, float* __restrict__ hys,
                                                     float* __restrict__ eg, float* __restrict__ hyp,
                                                     int32_t* __restrict__ upper, int32_t* __restrict__ tickets,
-                                                    int2* __restrict__ units, int32_t* __restrict__ n_units) {
+                                                    int4* __restrict__ units, int32_t* __restrict__ n_units) {
     extern __shared__ __attribute__((aligned(16))) int s_tab[];      // [2][nch + 1] when lds_table
     __shared__ int s_w[20];
     __shared__ int s_ubase;
@@ -442,15 +443,16 @@ __global__ __launch_bounds__(1024) void k_vote_plan(const uint8_t* __restrict__ 
         uint64_t* bwK = bitsK + (size_t)inst * nch * kChunkWords;
         for (int h = threadIdx.x; h < hnp; h += blockDim.x) upper[(size_t)inst * hnp + h] = 0;
         if (threadIdx.x == 0) { tickets[inst] = 0; s_box[0] = 0x7fffffff; s_box[1] = -1; s_box[2] = 0x7fffffff; s_box[3] = -1; }
-        const int fg = block_scan_chunks(cfg, cpre, s_cpre, nch, s_w);
         // bounding box of the instance -> the origin the filter's coordinates are measured from, and the largest
-        // |x - ox| + |y - oy| of its pixels (both only scale the rounding allowance: any values are sound)
+        // |x - ox| + |y - oy| of its pixels (both only scale the rounding allowance: any values are sound).  Its loads are
+        // issued before the chunk scan so that both memory round trips overlap.
+        int b0 = 0x7fffffff, b1 = -1, b2 = 0x7fffffff, b3 = -1;
+        for (int c = threadIdx.x; c < nch; c += blockDim.x) {
+            const int4 bx = *reinterpret_cast<const int4*>(chunk_box + ((size_t)inst * nch + c) * 4);
+            b0 = min(b0, bx.x); b1 = max(b1, bx.y); b2 = min(b2, bx.z); b3 = max(b3, bx.w);
+        }
+        const int fg = block_scan_chunks(cfg, cpre, s_cpre, nch, s_w);
         {
-            int b0 = 0x7fffffff, b1 = -1, b2 = 0x7fffffff, b3 = -1;
-            for (int c = threadIdx.x; c < nch; c += blockDim.x) {
-                const int32_t* bx = chunk_box + ((size_t)inst * nch + c) * 4;
-                b0 = min(b0, bx[0]); b1 = max(b1, bx[1]); b2 = min(b2, bx[2]); b3 = max(b3, bx[3]);
-            }
 #pragma unroll
             for (int o = kWave / 2; o > 0; o >>= 1) {
                 b0 = min(b0, __shfl_xor(b0, o, kWave)); b1 = max(b1, __shfl_xor(b1, o, kWave));
@@ -517,7 +519,8 @@ __global__ __launch_bounds__(1024) void k_vote_plan(const uint8_t* __restrict__ 
             s_ubase = nb_i ? atomicAdd(n_units, nb_i) : 0;
         }
         __syncthreads();               // the tables of this instance are complete (same CU: visible)
-        for (int b = threadIdx.x; b * kBlockPx < (tn > 0 ? fg : 0); b += blockDim.x) units[s_ubase + b] = make_int2(inst, b);
+        for (int b = threadIdx.x; b * kBlockPx < (tn > 0 ? fg : 0); b += blockDim.x)
+            units[s_ubase + b] = make_int4(inst, b, fg | (thin ? (int)0x80000000 : 0), (ox & 0xffff) | (oy << 16));
 
         const int32_t* tab = lds_table ? s_cpre : cpre;
         const int32_t* tabK = lds_table ? s_cpreK : cpreK;
@@ -671,7 +674,7 @@ struct TilePair {                    // one lane's two list entries: filter cons
 enum { kModeCones = 0, kModeReference = 1 };
 
 template <int MODE, int WAVES /* waves per SIMD the register allocation aims at */>
-__global__ __launch_bounds__(256, WAVES) void k_vote_count(int W, int HW, int nch, const int2* __restrict__ units,
+__global__ __launch_bounds__(256, WAVES) void k_vote_count(int W, int HW, int nch, const int4* __restrict__ units,
                                                     const int32_t* __restrict__ n_units, int hn, int hnp,
                                                     int task_target /* tasks the launch wants: slices are cut to reach it */,
                                                     int s_fixed /* > 0: that many slices (tuning aid) */, float kappa1,
@@ -705,11 +708,11 @@ __global__ __launch_bounds__(256, WAVES) void k_vote_count(int W, int HW, int nc
         const int s = rem >> 3;
         const int u = (int)(grp * 8 + (rem & 7));
         if (u >= nu) continue;
-        const int2 ub = units[u];
+        const int4 ub = units[u];
         const int inst = ub.x, b = ub.y;
-        const int fg = plan[inst * kPlanI + 0];
-        const bool thin = plan[inst * kPlanI + 2] != 0;
-        const float fox = (float)plan[inst * kPlanI + 3], foy = (float)plan[inst * kPlanI + 4];
+        const int fg = ub.z & 0x7fffffff;
+        const bool thin = ub.z < 0;
+        const float fox = (float)(ub.w & 0xffff), foy = (float)(ub.w >> 16);
         const int nent = fg;                                        // list entries of the instance (all foreground pixels)
         const int g_lo = s * gps, g_hi = min(ngroups, g_lo + gps);
         if (g_lo >= g_hi) continue;                                 // uniform
@@ -882,7 +885,7 @@ typedef unsigned long long __attribute__((address_space(1))) gu64;
 // dynamic LDS: the chunk prefix [nch + 1] when lds_table.
 template <int MODE>
 __global__ __launch_bounds__(256) void k_vote_final(int W, int HW, int nch, int n, const int32_t* __restrict__ n_dev,
-                                                    const int2* __restrict__ units, const int32_t* __restrict__ n_units,
+                                                    const int4* __restrict__ units, const int32_t* __restrict__ n_units,
                                                     int hn, int hnp, int nbx, float thresh, float kappa1,
                                                     float kappa2, float efac_ref, int max_num, uint64_t seed,
                                                     const uint8_t* __restrict__ keep, int lds_table,
@@ -914,7 +917,7 @@ __global__ __launch_bounds__(256) void k_vote_final(int W, int HW, int nch, int 
         }
     const int nu = *n_units;
     for (int t = blockIdx.x; t < nu; t += gridDim.x) {
-        const int2 ub = units[t];
+        const int4 ub = units[t];
         const int inst = ub.x, b0 = ub.y;
         const int fg = plan[inst * kPlanI + 0], tn = plan[inst * kPlanI + 1];
         const bool thin = plan[inst * kPlanI + 2] != 0;
