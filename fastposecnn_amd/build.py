@@ -20,6 +20,12 @@ FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-ffp-contract=
          "-Wall", "-Wno-unused-function", "-I", os.path.join(HERE, "..", "include")]
 
 
+# per-file additions.  ransac.hip: the MFMA results of k_vote_count are consumed by the VALU at once, so they must land
+# in VGPRs (the default AGPR form costs one v_accvgpr_read per element), and SLP-packing its f32 subtractions into
+# v_pk_add_f32 loses the |.| source modifier (52 extra v_and per step).
+FILE_FLAGS = {"ransac.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form", "-fno-slp-vectorize"]}
+
+
 def sources():
     return sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hip"))
 
@@ -35,7 +41,7 @@ def _compile(src, objdir, dep_mtime, force, extra):
     obj = os.path.join(objdir, os.path.basename(src)[:-4] + ".o")
     if not force and os.path.exists(obj) and os.path.getmtime(obj) >= max(os.path.getmtime(src), dep_mtime):
         return obj
-    subprocess.check_call([HIPCC, *FLAGS, *extra, "-c", src, "-o", obj])
+    subprocess.check_call([HIPCC, *FLAGS, *FILE_FLAGS.get(os.path.basename(src), []), *extra, "-c", src, "-o", obj])
     return obj
 
 
@@ -43,7 +49,7 @@ def build(force=False, verbose=False, extra=()):
     """Objects are cached per flag set (a diagnostic build with -DFPC_STAMP_* never shares objects with the product
     build), and the library records the flag set it was linked from: a different one relinks."""
     extra = list(extra)
-    tag = hashlib.sha256(" ".join([HIPCC, *FLAGS, *extra]).encode()).hexdigest()[:12]
+    tag = hashlib.sha256(" ".join([HIPCC, *FLAGS, repr(sorted(FILE_FLAGS.items())), *extra]).encode()).hexdigest()[:12]
     objdir = os.path.join(OBJ, tag)
     os.makedirs(objdir, exist_ok=True)
     srcs = sources()

@@ -300,15 +300,19 @@ struct OptArgs {
     int rectified, la_sync, la_init;
 };
 
-// ctl (device, f32[2]): [0] gradient scale (clip coefficient, 1 / world already in), [1] != 0: skip this step (inf guard)
+// ctl (device, f32[2]): [0] gradient scale (clip coefficient, 1 / world already in); [1] != 0: the inf / NaN guard fired.
+// The reference's guard (F/lib/pose_regressor.py:341-415) clears the gradients (`model.zero_grad()`: zeros, not None, in its
+// torch) and lets the optimiser step run: m and v decay, weight decay applies, the parameters keep moving along the
+// momentum, RAdam's and Lookahead's step counters advance.  Same here: the step runs with g = 0 (selected, not multiplied:
+// the gradient holds inf / NaN), so the host-side step count and the device state can never disagree.
 __global__ __launch_bounds__(256) void k_lookahead_radam(float* __restrict__ p, const float* __restrict__ g,
                                                          float* __restrict__ m, float* __restrict__ v,
                                                          float* __restrict__ slow, size_t n, OptArgs a,
                                                          const float* __restrict__ ctl) {
     const float scale = ctl ? ctl[0] : 1.0f;
-    if (ctl && ctl[1] != 0.0f) return;
+    const bool guarded = ctl && ctl[1] != 0.0f;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
-        const float gi = g[i] * scale;
+        const float gi = guarded ? 0.0f : g[i] * scale;
         const float vi = v[i] * a.beta2 + (1.0f - a.beta2) * gi * gi;
         const float mi = m[i] * a.beta1 + (1.0f - a.beta1) * gi;
         float pi = p[i];

@@ -74,7 +74,12 @@ class NetEngine:
     def stale(self):
         """True when a bound parameter was rewritten or replaced since it was packed (packed conv weights and folded
         BatchNorm are a snapshot; biases / GroupNorm / head weights are read in place)."""
-        return self._fingerprint() != self._stamp
+        return self._stamp is None or self._fingerprint() != self._stamp
+
+    def mark_stale(self):
+        """Force a repack at the next forward: for writers PyTorch does not version (kernels that update parameters
+        through raw pointers, collectives into a flat buffer the parameters are views of)."""
+        self._stamp = None
 
     def conv_plans(self):
         out = []

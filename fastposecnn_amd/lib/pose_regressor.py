@@ -261,6 +261,16 @@ class PoseRegressor(Model, torch.nn.Module):
         self._engines = {}
         self._fused = None
 
+    def train(self, mode: bool = True):
+        # Leaving training: whatever updated the weights may have written them through raw pointers (the native
+        # Lookahead(RAdam) kernel, an all-gather into the flat buffer the parameters are views of) and BatchNorm's
+        # running statistics moved: tensor versions do not show either.  The plans repack at their next forward
+        # (bind() keeps the tuned tilings and the workspace: no re-tune).
+        if self.training and not mode:
+            for eng in self._engines.values():
+                eng.mark_stale()
+        return super().train(mode)
+
     def _apply(self, fn, *args, **kwargs):
         # .to() / .cuda() / .float(): the parameters become new tensors, possibly on another device
         self._drop_engines()

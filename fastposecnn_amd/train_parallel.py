@@ -89,10 +89,11 @@ class ShardedLookaheadRAdam:
             soff += b["shard"]
             b["pending"] = len(b["params"])
             b["launched"] = False
+        self._next = 0                     # first bucket whose reduction has not been launched this step
         self.comm_stream = torch.cuda.Stream(device=self.device) if self.device.type == "cuda" else None
         self.stat = torch.zeros(2, dtype=torch.float64, device=self.device)
         self.ctl = torch.zeros(2, **f32)
-        self.skipped = torch.zeros(1, dtype=torch.int64, device=self.device)     # steps dropped by the inf / NaN guard
+        self.skipped = torch.zeros(1, dtype=torch.int64, device=self.device)     # steps whose gradients the inf / NaN guard zeroed
 
     # ---- backward-time reduction -------------------------------------------------------------------------------
     def _make_hook(self, bi):
@@ -100,8 +101,17 @@ class ShardedLookaheadRAdam:
             b = self.buckets[bi]
             b["pending"] -= 1
             if b["pending"] == 0:
-                self._reduce_bucket(b)
+                self._launch_ready()
         return hook
+
+    def _launch_ready(self):
+        # Collectives pair up across ranks by CALL ORDER, so every rank must issue the buckets in the same order whatever
+        # order its backward completes them in (a rank with no matched instance produces no gradient for the rotation /
+        # translation / scales branches at all: those buckets complete only in step()).  Bucket i is launched once buckets
+        # 0..i-1 have been launched, as DDP does; step() flushes the remainder in index order.
+        while self._next < len(self.buckets) and self.buckets[self._next]["pending"] == 0:
+            self._reduce_bucket(self.buckets[self._next])
+            self._next += 1
 
     def _bucket_grad(self, b):
         return self.flat_g[b["offset"]:b["offset"] + b["numel"]]
@@ -127,6 +137,7 @@ class ShardedLookaheadRAdam:
 
     def zero_grad(self):
         self.flat_g.zero_()
+        self._next = 0
         for b in self.buckets:
             b["pending"] = len(b["params"])
             b["launched"] = False
@@ -144,9 +155,9 @@ class ShardedLookaheadRAdam:
         return p, g, self.m[so:so + sh], self.v[so:so + sh], self.slow[so:so + sh]
 
     def step(self):
-        for b in self.buckets:              # heads without a gradient this step (no matched instance): zeros
-            if not b["launched"]:
-                self._reduce_bucket(b)
+        while self._next < len(self.buckets):   # buckets whose gradients never all arrived (no matched instance): zeros
+            self._reduce_bucket(self.buckets[self._next])
+            self._next += 1
         if self.comm_stream is not None:
             torch.cuda.current_stream(self.device).wait_stream(self.comm_stream)
         self.step_count += 1
@@ -187,6 +198,9 @@ class ShardedLookaheadRAdam:
             for b in self.buckets:
                 p = self._shard_views(b)[0]
                 dist.all_gather_into_tensor(self._bucket_param(b), p, group=self.group)
+        # the kernel and the all-gather wrote the parameters through raw pointers / the flat buffer: tell autograd's
+        # version counters, which is what NetEngine.stale() (and torch's own saved-tensor checks) look at
+        torch.autograd.graph.increment_version([p for b in self.buckets for p in b["params"]])
         return norm
 
     def grad_norm_and_flag(self):

@@ -42,6 +42,14 @@ FPC_HD int32_t fpc_rand_index(uint64_t seed, uint32_t inst, uint32_t hyp, uint32
     return (int32_t)(((uint64_t)r * (uint64_t)n) >> 32);
 }
 
+/* Pair sampling of a THINNED instance (fg > max_num, RV/ransac_voting_gpu.py:541-552).  The reference compacts the kept
+ * pixels and draws ranks among them; an equivalent draw that needs no kept-rank table: draw a rank among ALL fg foreground
+ * pixels (raster order) and reject it while that pixel is thinned out, attempt a = 0, 1, ... using the stream word
+ * `which + 2 a` (which = 0 / 1: first / second point of the pair); after FPC_SAMPLE_MAX_TRIES rejected attempts the last
+ * draw is used as it is (probability (1 - max_num / fg)^256).  An instance that is not thinned takes attempt 0:
+ * fpc_rand_index(seed, inst, hyp, which, fg), the same draw as before this rule existed. */
+#define FPC_SAMPLE_MAX_TRIES 256
+
 /* Bernoulli keep decision for the > max_num thinning: keep iff u < max_num/fg,
  * evaluated in integers as  r * fg < max_num * 2^32  (r uniform 32-bit). */
 FPC_HD int fpc_rand_keep(uint64_t seed, uint32_t inst, uint32_t pixel, uint32_t fg, uint32_t max_num) {

@@ -213,15 +213,43 @@ int fpco_ransac_voting_v3(const float* mask, const float* vertex,
         if (out_tn) out_tn[bi] = tn;
         if (tn == 0) { oxy[0] = 0.0f; oxy[1] = 0.0f; continue; }
 
-        /* :552 pair indices */
-        for (int hi = 0; hi < hn; ++hi)
-            for (int k = 0; k < 2; ++k)
-                pair[2 * hi + k] = idxs ? idxs[((size_t)bi * hn + hi) * 2 + k]
-                                        : fpc_rand_index(seed, (uint32_t)bi, (uint32_t)hi, (uint32_t)k, (uint32_t)tn);
-
-        /* :559 */
-        rc = fpco_generate_hypothesis(direct, coords, pair, hyp, tn, 1, hn);
-        if (rc != FPCO_OK) break;
+        /* :552 pair indices.  Injected, or our own stream (include/fpc_rng.h).  For a thinned instance the stream draws a
+         * rank among ALL foreground pixels and rejects thinned-out ones (FPC_SAMPLE_MAX_TRIES, then the last draw as it
+         * is): the same distribution as the reference's draw among the kept pixels, without a kept-rank table. */
+        if (idxs || !thin) {
+            for (int hi = 0; hi < hn; ++hi)
+                for (int k = 0; k < 2; ++k)
+                    pair[2 * hi + k] = idxs ? idxs[((size_t)bi * hn + hi) * 2 + k]
+                                            : fpc_rand_index(seed, (uint32_t)bi, (uint32_t)hi, (uint32_t)k, (uint32_t)tn);
+            /* :559 */
+            rc = fpco_generate_hypothesis(direct, coords, pair, hyp, tn, 1, hn);
+            if (rc != FPCO_OK) break;
+        } else {
+            int32_t* fgpix = (int32_t*)malloc(sizeof(int32_t) * (size_t)fg);
+            if (!fgpix) { rc = FPCO_ENOMEM; break; }
+            int r = 0;
+            for (size_t p = 0; p < HW; ++p) if (m[p] != 0.0f) fgpix[r++] = (int32_t)p;
+            for (int hi = 0; hi < hn && rc == FPCO_OK; ++hi) {
+                float c2[4], d2[4];
+                const int32_t two[2] = {0, 1};
+                for (int k = 0; k < 2; ++k) {
+                    int32_t px = 0;
+                    for (int a = 0; a < FPC_SAMPLE_MAX_TRIES; ++a) {
+                        px = fgpix[fpc_rand_index(seed, (uint32_t)bi, (uint32_t)hi, (uint32_t)(k + 2 * a), (uint32_t)fg)];
+                        int kept = keep ? (keep[(size_t)bi * HW + px] != 0)
+                                        : fpc_rand_keep(seed, (uint32_t)bi, (uint32_t)px, (uint32_t)fg, (uint32_t)max_num);
+                        if (kept) break;
+                    }
+                    int y = px / W, x = px - y * W;
+                    c2[2 * k] = (float)x; c2[2 * k + 1] = (float)y;
+                    d2[2 * k] = v[(int64_t)y * vs_h + (int64_t)x * vs_w];
+                    d2[2 * k + 1] = v[(int64_t)y * vs_h + (int64_t)x * vs_w + vs_c];
+                }
+                rc = fpco_generate_hypothesis(d2, c2, two, hyp + 2 * hi, 2, 1, 1);        /* :559 */
+            }
+            free(fgpix);
+            if (rc != FPCO_OK) break;
+        }
         if (out_hyp) memcpy(out_hyp + 2 * (size_t)bi * hn, hyp, sizeof(float) * 2 * (size_t)hn);
 
         /* :562-567 counts and arg-max; torch.max returns the first maximal index */
