@@ -20,10 +20,11 @@ FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-ffp-contract=
          "-Wall", "-Wno-unused-function", "-I", os.path.join(HERE, "..", "include")]
 
 
-# per-file additions.  ransac.hip: the MFMA results of k_vote_count are consumed by the VALU at once, so they must land
-# in VGPRs (the default AGPR form costs one v_accvgpr_read per element), and SLP-packing its f32 subtractions into
-# v_pk_add_f32 loses the |.| source modifier (52 extra v_and per step).
-FILE_FLAGS = {"ransac.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form", "-fno-slp-vectorize"]}
+# per-file additions.  vote_count.hip: the MFMA results of k_vote_count are consumed by the VALU at once, so they must
+# land in VGPRs (the default AGPR form costs one v_accvgpr_read per element), and SLP-packing its f32 subtractions into
+# v_pk_add_f32 loses the |.| source modifier (52 extra v_and per step).  The flag is experimental: it is kept away from
+# every other kernel (k_vote_plan built with it faulted on a null `keep` it had checked for).
+FILE_FLAGS = {"vote_count.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form", "-fno-slp-vectorize"]}
 
 
 def sources():

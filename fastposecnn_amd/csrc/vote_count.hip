@@ -1,0 +1,226 @@
+// vote_count.hip — k_vote_count, the exact inlier counts of the fused hough vote (pipeline and filter: csrc/ransac.hip).
+#include "vote.hpp"
+
+namespace fpc {
+
+// ---- k_vote_count ------------------------------------------------------------------
+// EXACT inlier count of every hypothesis.  Task -> (count unit, slice of hypothesis tiles); the slicing is chosen on the
+// device from the unit count so that the tasks fill one resident round of workgroups.  256 threads; wave w owns the
+// unit's 64-entry groups w and w + 4.  Per group the wave builds the A fragments of the two forms (prologue, once per
+// task); per hypothesis tile it loads ONE B fragment (16 bytes per lane) and issues two MFMAs per 32 entries; the
+// result registers hold, per lane, ONE hypothesis (column lane & 31) against 16 entries (rows), so counts stay lane-local:
+//     r = F_t - |F_s| ;  row = (row << 2) | (r >> 30) ;  after 16: neg += popc(row & 0xAAAAAAAA), undecided = odd bit set & even clear.
+// The unit record and the entries of the NEXT task are requested while the current one computes (a task is ~1 us of
+// arithmetic behind ~3 us of dependent loads otherwise), and undecided pairs wait in the wave's queue ACROSS tasks.
+// Error budget of r (units of the unscaled margin, M = |gx - ox| + |gy - oy| + radius, |e| = 1):
+//     unit vote by v_rsq_f32 (1 ulp) and two products ............................ 4e-7 M   (s and t forms alike)
+//     gx - ox, sigma (gx - ox): two roundings; c_s / c_t: three at <= radius ........ 3e-7 M
+//     kappa2 e, kappa2 c_t: one rounding each ....................................... 1.2e-7 kappa M
+//     dropped piece products ......................................................... 1.2e-7 M
+//     f32 accumulation of 16 exact products inside the MFMA (any order, any rounding mode) ... <= 16 x 1.2e-7 M
+//  => |r_computed - r_exact| / sigma <= 2.8e-6 (1 + kappa2) M  <  E = efac M  with efac = 3.2e-6 (1 + kappa1);
+//     measured worst over 2 M random pairs: 4.2e-7 M (tools_dev/mfma_vote_probe.hip).
+// dynamic LDS: [gps * 32] counts of the slice.
+
+// The parameter block for out-of-line helpers: read from the kernel-argument segment (constant address space: scalar
+// loads) through a pointer the kernel hands over, so no copy of the block is materialised for the call.
+// (__builtin_amdgcn_kernarg_segment_ptr() is only meaningful inside the kernel function itself.)
+typedef const VoteParams __attribute__((address_space(4)))* KParams;
+__device__ __forceinline__ KParams kernel_params() {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return (KParams)__builtin_amdgcn_kernarg_segment_ptr();               // the kernels' ONLY argument, at offset 0
+#else
+    return nullptr;                                                       // host pass: never called
+#endif
+}
+
+struct UnitRef { int inst, c, k, cnt; bool thin; float fox, foy; };
+__device__ __forceinline__ UnitRef decode_unit(int4 ub) {
+    UnitRef u;
+    u.inst = ub.x & 0xffff; u.k = (ub.x >> 16) & 7; u.thin = (ub.x >> 19) & 1; u.cnt = ((unsigned)ub.x >> 20) + 1;
+    u.c = ub.y; u.fox = (float)(ub.w & 0xffff); u.foy = (float)((unsigned)ub.w >> 16);
+    return u;
+}
+
+// the pairs the filter could not decide: {hypothesis | entry-in-unit << 16, unit}; evaluated 64 at a time, one per lane
+template <bool KEEP>
+__device__ __attribute__((noinline)) void band_flush(int nq, const int2* __restrict__ queue, KParams kp) {
+    const auto& p = *kp;
+    const int lane = threadIdx.x & (kWave - 1), hn = p.hn;
+    for (int base = 0; base < nq; base += kWave) {                           // uniform
+        if (base + lane >= nq) continue;
+        const int2 e = queue[base + lane];
+        const int h = e.x & 0xffff, ent = e.x >> 16;
+        const UnitRef u = decode_unit(p.units[e.y]);
+        const int nvalid = min(kUnitEntries, u.cnt - u.k * kUnitEntries);
+        if (ent >= nvalid || h >= hn) continue;
+        const float4 q = p.list[(size_t)u.inst * p.ls + (size_t)u.c * kChunkPx + (size_t)u.k * kUnitEntries + ent];
+        if (u.thin && !pixel_kept<KEEP>(q.x, q.y, p.W, p.HW, u.inst, p.plan[(size_t)u.inst * kPlanI], p.max_num, p.seed, p.keep)) continue;
+        const float gx = p.hyp[((size_t)u.inst * hn + h) * 2], gy = p.hyp[((size_t)u.inst * hn + h) * 2 + 1];
+        if (pair_is_inlier(q.x, q.y, q.z, q.w, sqrtf(q.z * q.z + q.w * q.w), gx, gy, p.thresh))
+            atomicAdd(p.counts + (size_t)u.inst * p.hnp + h, 1);
+    }
+}
+
+struct GroupFrags { u32x4 s[2], t[2]; };          // A fragments of one 64-entry group: forms s / t, row tiles 0 / 1
+
+// the A fragments of this lane's entry, exchanged so that tile 0 = entries 0-31 and tile 1 = entries 32-63 of the group
+__device__ __forceinline__ void build_group(GroupFrags& g, bool valid, float4 q, float fox, float foy, float kappa2) {
+    float a_s = 0.f, b_s = 0.f, c_s = kNeverS, a_t = 0.f, b_t = 0.f, c_t = 0.f;
+    const float n2 = q.z * q.z + q.w * q.w;
+    // .cu:121 skips a vote with |d| < 1e-6 (compared in double): n1 <= 1e-6f in f32 (common.hpp); near that bound the
+    // correctly rounded sqrt decides.  A non-finite or overflowing |d|^2 never votes either (NaN / 0 cosine).
+    bool votes = valid && n2 <= 3.0e38f && n2 >= 4.0e-12f;
+    if (__builtin_amdgcn_ballot_w64(valid && n2 < 4.0e-12f)) votes = votes || (valid && n2 < 4.0e-12f && !below_eps(sqrtf(n2)));
+    if (votes) {
+        const float inv = __builtin_amdgcn_rsqf(n2);
+        const float ex = q.z * inv, ey = q.w * inv;
+        const float xs = q.x - fox, ys = q.y - foy;
+        a_s = ey; b_s = -ex; c_s = -(xs * ey - ys * ex);
+        a_t = kappa2 * ex; b_t = kappa2 * ey; c_t = kappa2 * -(xs * ex + ys * ey);
+    }
+    u32x4 slo, shi, tlo, thi;
+    a_fragment(a_s, b_s, c_s, 0.0f, slo, shi);
+    a_fragment(a_t, b_t, c_t, -1.0f, tlo, thi);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        // lanes 32-63 of `lo` <-> lanes 0-31 of `hi`: lo' = slots 0-7 | 8-15 of entries 0-31, hi' = the same of entries 32-63
+        const auto a = __builtin_amdgcn_permlane32_swap(slo[r], shi[r], false, false);
+        g.s[0][r] = a[0]; g.s[1][r] = a[1];
+        const auto b = __builtin_amdgcn_permlane32_swap(tlo[r], thi[r], false, false);
+        g.t[0][r] = b[0]; g.t[1][r] = b[1];
+    }
+}
+
+// one row tile (32 entries) against one hypothesis tile: two MFMAs, 16 x (v_sub, v_alignbit); returns the 2-bit rows
+__device__ __forceinline__ unsigned tile_rows(const u32x4& As, const u32x4& At, const bf16x8 B) {
+    f32x16 Fs = {0}, Ft = {0};
+    Fs = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, As), B, Fs, 0, 0, 0);
+    Ft = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, At), B, Ft, 0, 0, 0);
+    unsigned row = 0;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) row = __builtin_amdgcn_alignbit(row, __float_as_uint(Ft[i] - fabsf(Fs[i])), 30);
+    return row;
+}
+
+template <int WAVES /* waves per SIMD the register allocation aims at */, bool KEEP>
+__global__ __launch_bounds__(256, WAVES) void k_vote_count(const VoteParams p) {
+    extern __shared__ __attribute__((aligned(16))) int s_cnt[];      // [gps * 32]
+    __shared__ int2 s_bandq[4][kBandQ];
+    const int lane = threadIdx.x & (kWave - 1), wv = threadIdx.x / kWave;
+    const int nu = p.ctrl[0];
+    const int ntiles = p.ntiles;
+    // units x S slices ~ the task count the launch was sized for: one round of equal tasks over the chip
+    const int S0 = max(1, min(ntiles, p.task_target / max(nu, 1)));
+    const int gps = min(kMaxSliceTiles, (ntiles + S0 - 1) / S0);
+    const int S = (ntiles + gps - 1) / gps;
+    const long long total = (long long)nu * S;
+    const long long G = gridDim.x;
+    int2* bq = s_bandq[wv];
+    int qn = 0;
+    long long t = blockIdx.x;
+    if (t >= total) return;                                                  // uniform
+    // software pipeline over this workgroup's tasks: unit records two tasks ahead, entries one task ahead
+    auto load_entries = [&](int4 ub, float4& qa, float4& qb) {
+        const UnitRef u = decode_unit(ub);
+        const int nvalid = min(kUnitEntries, u.cnt - u.k * kUnitEntries);
+        const float4* U = p.list + (size_t)u.inst * p.ls + (size_t)u.c * kChunkPx + (size_t)u.k * kUnitEntries;
+        const int ea = wv * kWave + lane, eb = (wv + 4) * kWave + lane;
+        qa = ea < nvalid ? U[ea] : make_float4(0.f, 0.f, 0.f, 0.f);
+        qb = eb < nvalid ? U[eb] : make_float4(0.f, 0.f, 0.f, 0.f);
+    };
+    int4 ub = p.units[t / S];
+    int4 ub1 = (t + G < total) ? p.units[(t + G) / S] : make_int4(0, 0, 0, 0);
+    float4 qa, qb;
+    load_entries(ub, qa, qb);
+    for (;;) {
+        const bool more = t + G < total;
+        const int4 ub2 = (t + 2 * G < total) ? p.units[(t + 2 * G) / S] : make_int4(0, 0, 0, 0);
+        float4 qan = make_float4(0.f, 0.f, 0.f, 0.f), qbn = qan;
+        if (more) load_entries(ub1, qan, qbn);
+        const int uidx = (int)(t / S), s = (int)(t - (long long)uidx * S);
+        const UnitRef u = decode_unit(ub);
+        const int inst = u.inst;
+        const int nvalid = min(kUnitEntries, u.cnt - u.k * kUnitEntries);
+        const int T0 = s * gps, T1 = min(ntiles, T0 + gps);
+        // this wave's groups: w and w + 4 of the unit's eight
+        const int ng = (wv * kWave < nvalid ? 1 : 0) + ((wv + 4) * kWave < nvalid ? 1 : 0);
+        GroupFrags Gf[2];
+        {
+            const int fg = u.thin ? p.plan[(size_t)inst * kPlanI] : 0;
+            bool va = wv * kWave + lane < nvalid, vb = (wv + 4) * kWave + lane < nvalid;
+            if (u.thin) {
+                va = va && pixel_kept<KEEP>(qa.x, qa.y, p.W, p.HW, inst, fg, p.max_num, p.seed, p.keep);
+                vb = vb && pixel_kept<KEEP>(qb.x, qb.y, p.W, p.HW, inst, fg, p.max_num, p.seed, p.keep);
+            }
+            build_group(Gf[0], va, qa, u.fox, u.foy, p.kappa2);
+            build_group(Gf[1], vb, qb, u.fox, u.foy, p.kappa2);
+        }
+        for (int i = threadIdx.x; i < (T1 - T0) * kHypTile; i += blockDim.x) s_cnt[i] = 0;
+        __syncthreads();
+        if (ng > 0) {                                                       // uniform per wave
+            const u32x4* Bp = p.hypB + ((size_t)inst * ntiles + T0) * kWave + lane;
+            u32x4 Bn = *Bp;
+            for (int T = T0; T < T1; ++T) {
+                const bf16x8 B = __builtin_bit_cast(bf16x8, Bn);
+                if (T + 1 < T1) Bn = Bp[(size_t)(T + 1 - T0) * kWave];
+                unsigned bm[4] = {0u, 0u, 0u, 0u};
+                int neg = 0;
+#pragma unroll
+                for (int gi = 0; gi < 2; ++gi) {
+                    if (gi < ng) {
+#pragma unroll
+                        for (int rt = 0; rt < 2; ++rt) {
+                            const unsigned row = tile_rows(Gf[gi].s[rt], Gf[gi].t[rt], B);
+                            neg += __popc(row & 0xAAAAAAAAu);
+                            bm[gi * 2 + rt] = (row >> 1) & ~row & 0x55555555u;
+                        }
+                    }
+                }
+                // lane-local: column (lane & 31) of tile T against 16 rows x 2 tiles x ng groups
+                atomicAdd(&s_cnt[(T - T0) * kHypTile + (lane & 31)], ng * 32 - neg);
+                // undecided pairs -> the wave's queue (a handful per step)
+                while (__builtin_amdgcn_ballot_w64((bm[0] | bm[1] | bm[2] | bm[3]) != 0u)) {        // uniform
+                    const bool has = (bm[0] | bm[1] | bm[2] | bm[3]) != 0u;
+                    int j = 0;
+                    unsigned m = bm[0];
+                    if (!m) { j = 1; m = bm[1]; }
+                    if (!m) { j = 2; m = bm[2]; }
+                    if (!m) { j = 3; m = bm[3]; }
+                    const int bit = has ? __ffs((int)m) - 1 : 0;
+                    const unsigned cl = m & (m - 1u);
+                    if (j == 0) bm[0] = cl; else if (j == 1) bm[1] = cl; else if (j == 2) bm[2] = cl; else bm[3] = cl;
+                    const int i = 15 - (bit >> 1);                           // register index: the last one shifted in is bit 0
+                    const int row = (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5);
+                    const int ent = ((wv + 4 * (j >> 1)) * kWave) + (j & 1) * 32 + row;
+                    const int code = (T * kHypTile + (lane & 31)) | (ent << 16);
+                    const unsigned long long mk = __builtin_amdgcn_ballot_w64(has);
+                    if (qn + __popcll(mk) > kBandQ) {
+                        band_flush<KEEP>(qn, bq, kernel_params());
+                        qn = 0;
+                    }
+                    if (has) bq[qn + __builtin_amdgcn_mbcnt_hi((unsigned)(mk >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mk, 0))] = make_int2(code, uidx);
+                    qn += __popcll(mk);
+                }
+            }
+        }
+        __syncthreads();
+        // one integer atomic per (unit, hypothesis) with any count: order-independent result
+        for (int i = threadIdx.x; i < (T1 - T0) * kHypTile; i += blockDim.x) {
+            const int h = T0 * kHypTile + i, cv = s_cnt[i];
+            if (cv && h < p.hn) atomicAdd(&p.counts[(size_t)inst * p.hnp + h], cv);
+        }
+        __syncthreads();
+        if (!more) break;
+        t += G; ub = ub1; ub1 = ub2; qa = qan; qb = qbn;
+    }
+    if (qn) band_flush<KEEP>(qn, bq, kernel_params());
+}
+
+
+void launch_vote_count(const VoteParams& p, int grid, size_t lds_bytes, hipStream_t s) {
+    if (p.keep) hipLaunchKernelGGL((k_vote_count<4, true>), dim3(grid), dim3(256), lds_bytes, s, p);
+    else hipLaunchKernelGGL((k_vote_count<4, false>), dim3(grid), dim3(256), lds_bytes, s, p);
+}
+
+}  // namespace fpc
