@@ -115,18 +115,43 @@ __global__ void k_b1_vote(const float* __restrict__ direct, const float* __restr
 // grid-stride over (instance, chunk) tasks; 256 threads; a chunk = 4096 pixels = 4 float4 of the mask per lane.
 // Writes the chunk's count and bounding box, and compacts its foreground pixels (vote gathered from the caller's
 // strided planes) into the chunk's own slots of the list.
+// A parameter block of its own: with the whole VoteParams the compiler held 98 VGPRs (5 waves per SIMD) for this
+// latency-bound streaming kernel, with these sixteen values 52 (8 waves).
+struct ScanParams {
+    const float* mask; const float* vertex; int64_t vs_n, vs_h, vs_w, vs_c;
+    int n; const int32_t* n_dev; int W, HW, nch;
+    size_t ls;
+    int32_t* ctrl; int32_t* chunk_fg; int32_t* chunk_box; float4* list;
+    unsigned long long* stamps;
+};
+
 template <bool VEC4, bool VGATHER4>
-__global__ __launch_bounds__(256) void k_vote_scan(const VoteParams p) {
+__global__ __launch_bounds__(256) void k_vote_scan(const ScanParams p) {
     __shared__ __attribute__((aligned(16))) uint8_t s_nib[kChunkPx / 4];
     __shared__ uint64_t s_word[kChunkWords];
     __shared__ int s_wpre[kChunkWords];
     __shared__ int s_box[4];
+    FPC_STAMP(0, 0);
     if (blockIdx.x == 0 && threadIdx.x < 2) p.ctrl[threadIdx.x] = 0;       // k_vote_plan appends this call's units and runs
     const int W = p.W, HW = p.HW, nch = p.nch;
     const int total = active_instances(p.n, p.n_dev) * nch;
+    // the mask of the NEXT task is requested before the current one is processed (VEC4): a task is two dependent memory
+    // round trips (mask, then the votes under it) and the grid is a few resident rounds deep
+    float4 cur[4], nxt[4];
+    auto load_mask = [&](int t, float4 (&mv)[4]) {
+        const int inst = t / nch, c = t - inst * nch;
+        const float* m = p.mask + (size_t)inst * HW;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int px = c * kChunkPx + (k * 256 + threadIdx.x) * 4;
+            mv[k] = px < HW ? *reinterpret_cast<const float4*>(m + px) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    if (VEC4 && (int)blockIdx.x < total) load_mask(blockIdx.x, cur);
     for (int t = blockIdx.x; t < total; t += gridDim.x) {
         const int inst = t / nch, c = t - inst * nch;
         const float* m = p.mask + (size_t)inst * HW;
+        if (VEC4 && t + (int)gridDim.x < total) load_mask(t + gridDim.x, nxt);
         unsigned nb[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
@@ -134,10 +159,8 @@ __global__ __launch_bounds__(256) void k_vote_scan(const VoteParams p) {
             const int px = c * kChunkPx + fi * 4;
             nb[k] = 0;
             if (VEC4) {                                     // HW % 4 == 0 and a 16-byte aligned plane
-                if (px < HW) {
-                    const float4 v = *reinterpret_cast<const float4*>(m + px);
-                    nb[k] = (v.x != 0.0f ? 1u : 0u) | (v.y != 0.0f ? 2u : 0u) | (v.z != 0.0f ? 4u : 0u) | (v.w != 0.0f ? 8u : 0u);
-                }
+                const float4 v = cur[k];
+                nb[k] = (v.x != 0.0f ? 1u : 0u) | (v.y != 0.0f ? 2u : 0u) | (v.z != 0.0f ? 4u : 0u) | (v.w != 0.0f ? 8u : 0u);
             } else {
 #pragma unroll
                 for (int q = 0; q < 4; ++q)
@@ -219,6 +242,11 @@ __global__ __launch_bounds__(256) void k_vote_scan(const VoteParams p) {
         __syncthreads();
         if (threadIdx.x < 4) p.chunk_box[((size_t)inst * nch + c) * 4 + threadIdx.x] = s_box[threadIdx.x];
         __syncthreads();
+        FPC_STAMP(0, 1);
+        if (VEC4) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) cur[k] = nxt[k];
+        }
     }
 }
 
@@ -247,7 +275,7 @@ __device__ __forceinline__ int block_scan(F f, int32_t* out, int cnt, int* s_w /
     return carry;
 }
 
-// One 1024-thread workgroup per instance.  dynamic LDS: [3][nch + 1] ints when p.lds_table.
+// One 1024-thread workgroup per instance.  dynamic LDS: [2][nch + 1] ints when p.lds_table.
 // INJ: the caller injected pair indices or a keep selection, or wants the out_tn diagnostic (tests and goldens): only that
 // variant carries the kept-pixel tables.  KEEP: see pixel_kept.
 template <bool INJ, bool KEEP>
@@ -260,11 +288,12 @@ __global__ __launch_bounds__(1024) void k_vote_plan(const VoteParams p) {
     const int lane = threadIdx.x & (kWave - 1), wv = threadIdx.x / kWave, nw = blockDim.x / kWave;
     for (int inst = blockIdx.x; inst < n_act; inst += gridDim.x) {
         const int32_t* cfg = p.chunk_fg + (size_t)inst * nch;
-        int32_t* cpre = p.lds_table ? s_tab : p.chunk_pre + (size_t)inst * (nch + 1);
-        int32_t* upre = p.lds_table ? s_tab + (nch + 1) : p.unit_pre + (size_t)inst * (nch + 1);
-        int32_t* kpre = p.lds_table ? s_tab + 2 * (nch + 1) : p.kept_pre + (size_t)inst * (nch + 1);
+        int32_t* gpre = p.chunk_pre + (size_t)inst * (nch + 1);                    // k_vote_count / k_vote_final read it
+        int32_t* cpre = p.lds_table ? s_tab : gpre;
+        int32_t* kpre = p.lds_table ? s_tab + (nch + 1) : p.kept_pre + (size_t)inst * (nch + 1);
         const float4* E = p.list + (size_t)inst * p.ls;
 
+        FPC_STAMP(1, 0);
         for (int h = threadIdx.x; h < p.hnp; h += blockDim.x) p.counts[(size_t)inst * p.hnp + h] = 0;
         if (threadIdx.x == 0) p.tickets[inst] = 0;
         if (threadIdx.x < 4) s_misc[threadIdx.x] = (threadIdx.x & 1) ? -1 : 0x7fffffff;
@@ -276,6 +305,9 @@ __global__ __launch_bounds__(1024) void k_vote_plan(const VoteParams p) {
             b0 = min(b0, bx.x); b1 = max(b1, bx.y); b2 = min(b2, bx.z); b3 = max(b3, bx.w);
         }
         const int fg = block_scan([&](int c) { return cfg[c]; }, cpre, nch, s_w);
+        FPC_STAMP(1, 1);
+        if (p.lds_table)
+            for (int c = threadIdx.x; c <= nch; c += blockDim.x) gpre[c] = cpre[c];
 #pragma unroll
         for (int o = kWave / 2; o > 0; o >>= 1) {
             b0 = min(b0, __shfl_xor(b0, o, kWave)); b1 = max(b1, __shfl_xor(b1, o, kWave));
@@ -283,6 +315,7 @@ __global__ __launch_bounds__(1024) void k_vote_plan(const VoteParams p) {
         }
         if (lane == 0 && b1 >= 0) { atomicMin(&s_misc[0], b0); atomicMax(&s_misc[1], b1); atomicMin(&s_misc[2], b2); atomicMax(&s_misc[3], b3); }
         __syncthreads();
+        FPC_STAMP(1, 2);
         const int x0 = s_misc[0], x1 = s_misc[1], y0 = s_misc[2], y1 = s_misc[3];
         int ox = 0, oy = 0, rad = W + HW / W;
         if (x1 >= 0) {
@@ -320,37 +353,21 @@ __global__ __launch_bounds__(1024) void k_vote_plan(const VoteParams p) {
             tn = block_scan([&](int c) { return kpre[c]; }, kpre, nch, s_w);
         }
         const bool votes = fg >= p.min_num && tn > 0;     // :536-539
-        // count units: blocks of <= 512 entries inside one chunk, in chunk order
-        const int nunits = block_scan([&](int c) { return (cpre[c + 1] - cpre[c] + kUnitEntries - 1) / kUnitEntries; }, upre, nch, s_w);
-        // refinement runs: groups of kRunChunks chunks that hold at least one entry; the ordinal indexes the records
-        const int nrx = (nch + kRunChunks - 1) / kRunChunks;
-        int nruns = 0;
-        for (int r = 0; r < nrx; ++r) nruns += (cpre[min(nch, (r + 1) * kRunChunks)] - cpre[r * kRunChunks]) > 0 ? 1 : 0;   // nrx is small
+        // count units: 512 consecutive foreground ranks; refinement runs: 8192 (the run number indexes the records)
+        const int nunits = votes ? (fg + kUnitEntries - 1) / kUnitEntries : 0;
+        const int nruns = votes ? (fg + kRunEntries - 1) / kRunEntries : 0;
         if (threadIdx.x == 0) {
             int32_t* pl = p.plan + (size_t)inst * kPlanI;
             pl[0] = fg; pl[1] = votes ? tn : 0; pl[2] = thin ? 1 : 0; pl[3] = ox; pl[4] = oy; pl[5] = rad;
-            pl[6] = votes ? nruns : 0; pl[7] = votes ? 1 : 0;
-            s_misc[4] = (votes && nunits) ? atomicAdd(p.ctrl, nunits) : 0;
-            s_misc[5] = (votes && nruns) ? atomicAdd(p.ctrl + 1, nruns) : 0;
+            pl[6] = nruns; pl[7] = votes ? 1 : 0;
+            // the two list bases: requested here, consumed after the hypotheses (their latency hides behind that loop)
+            s_misc[4] = nunits ? atomicAdd(p.ctrl, nunits) : 0;
+            s_misc[5] = nruns ? atomicAdd(p.ctrl + 1, nruns) : 0;
         }
-        __syncthreads();
         if (!votes) {                                     // uniform: no unit, no run; k_vote_final writes the zeros
             for (int i = threadIdx.x; i < 2 * hn; i += blockDim.x) p.hyp[(size_t)inst * hn * 2 + i] = 0.0f;   // the out_hyp diagnostic
             __syncthreads();
             continue;
-        }
-        const int ubase = s_misc[4], rbase = s_misc[5];
-        for (int c = threadIdx.x; c < nch; c += blockDim.x) {
-            const int cnt = cpre[c + 1] - cpre[c], u0 = upre[c];
-            for (int k = 0; k * kUnitEntries < cnt; ++k)
-                p.units[ubase + u0 + k] = make_int4(inst | (k << 16) | (thin ? 1 << 19 : 0) | ((cnt - 1) << 20), c, 0, (ox & 0xffff) | (oy << 16));
-        }
-        if (threadIdx.x == 0) {
-            int ord = 0;
-            for (int r = 0; r < nrx; ++r) {
-                const int c0 = r * kRunChunks, c1 = min(nch, c0 + kRunChunks);
-                if (cpre[c1] - cpre[c0] > 0) { p.runs[rbase + ord] = make_int4(inst, c0, c1, ord); ++ord; }
-            }
         }
 
         // list slot of the t-th foreground pixel (raster order) / of the t-th KEPT one
@@ -378,6 +395,7 @@ __global__ __launch_bounds__(1024) void k_vote_plan(const VoteParams p) {
             }
             return slot;
         };
+        FPC_STAMP(1, 3);
         const float bx0 = (float)x0, bx1 = (float)x1, by0 = (float)y0, by1 = (float)y1;
         for (int h0 = 0; h0 < p.hnp; h0 += blockDim.x) {
             const int hi = h0 + threadIdx.x;
@@ -424,6 +442,18 @@ __global__ __launch_bounds__(1024) void k_vote_plan(const VoteParams p) {
             B[hi % kHypTile] = lo;
             B[hi % kHypTile + kHypTile] = hi4;
         }
+        FPC_STAMP(1, 4);
+        __syncthreads();               // s_misc[4], [5]: the list bases
+        FPC_STAMP(1, 5);
+        const int ubase = s_misc[4], rbase = s_misc[5];
+        for (int u = threadIdx.x; u < nunits; u += blockDim.x) {
+            const int nvalid = min(kUnitEntries, fg - u * kUnitEntries);
+            p.units[ubase + u] = make_int4(inst | (thin ? 1 << 16 : 0) | ((nvalid - 1) << 17), u, rank_chunk(cpre, nch, u * kUnitEntries),
+                                           (ox & 0xffff) | (oy << 16));
+        }
+        for (int rr = threadIdx.x; rr < nruns; rr += blockDim.x)
+            p.runs[rbase + rr] = make_int4(inst, rr, rank_chunk(cpre, nch, rr * kRunEntries), 0);
+        FPC_STAMP(1, 6);
         __syncthreads();               // s_tab / s_misc are reused by the next instance
     }
 }
@@ -451,13 +481,15 @@ __device__ __forceinline__ void solve2_sym(double a00, double a01, double a11, d
 constexpr int kFinWaves = 4;         // 256-thread workgroups
 
 // Winner (largest count, lowest index: torch.max, RV/ransac_voting_gpu.py:567), its inliers voted again (:583-589) with
-// the reference's arithmetic, the fp64 normal equations and the 2x2 solve (:592-599).  Task = one run of chunks (their
-// entries are contiguous per chunk: 256 lanes stream them four loads deep); the run of an instance whose arrival ticket
-// comes last combines the instance's records (Guideline 16, counter form: records stored write-through (sc1), the
-// storing wave drained, one agent-scope add per workgroup; the last arriver reads them back with sc1 loads, in ordinal
-// order: bit-reproducible).
+// the reference's arithmetic, the fp64 normal equations and the 2x2 solve (:592-599).  Task = one run of 8192 consecutive
+// foreground ranks of an instance: 256 lanes stream the entries eight loads deep.  An instance of one run (the usual
+// case) is solved by its task; otherwise the run whose arrival ticket comes last combines the instance's records
+// (Guideline 16, counter form: records stored write-through (sc1), the storing wave drained, one agent-scope add per
+// workgroup; the last arriver reads them back with sc1 loads, in run order: bit-reproducible).
+// dynamic LDS: the instance's chunk prefix [nch + 1] when p.lds_table.
 template <bool KEEP>
 __global__ __launch_bounds__(256) void k_vote_final(const VoteParams p) {
+    extern __shared__ __attribute__((aligned(16))) int s_cpre[];
     __shared__ int s_red[2 * kFinWaves];
     __shared__ int s_last;
     __shared__ double s_part[kFinWaves][kRec];
@@ -475,15 +507,15 @@ __global__ __launch_bounds__(256) void k_vote_final(const VoteParams p) {
             if (p.out_refine)
                 for (int i = 0; i < 8; ++i) p.out_refine[(size_t)inst * 8 + i] = 0.0;
         }
+    FPC_STAMP(3, 0);
     const int nr = p.ctrl[1];
     for (int t = blockIdx.x; t < nr; t += gridDim.x) {
         const int4 rb = p.runs[t];
-        const int inst = rb.x, c0 = rb.y, c1 = rb.z, ord = rb.w;
+        const int inst = rb.x, run = rb.y, c_lo = rb.z;
         const int32_t* pl = p.plan + (size_t)inst * kPlanI;
         const int fg = pl[0], tn = pl[1], nrec = pl[6];
         const bool thin = pl[2] != 0;
-        // the chunk counts of the run (a lane each) while the winner is being found
-        const int my_cnt = (lane < c1 - c0) ? p.chunk_fg[(size_t)inst * nch + c0 + lane] : 0;
+        const int32_t* gpre = p.chunk_pre + (size_t)inst * (nch + 1);
         // winner: every task of the instance finds the same one
         int wc = -1, wi = 0x7fffffff;
         for (int h = threadIdx.x; h < hn; h += blockDim.x) {
@@ -497,6 +529,8 @@ __global__ __launch_bounds__(256) void k_vote_final(const VoteParams p) {
         }
         __syncthreads();                                               // LDS of the previous task is free
         if (lane == 0) { s_red[wv] = wc; s_red[kFinWaves + wv] = wi; }
+        if (p.lds_table)
+            for (int c = threadIdx.x; c <= nch; c += blockDim.x) s_cpre[c] = gpre[c];
         __syncthreads();
         wc = s_red[0]; wi = s_red[kFinWaves];
 #pragma unroll
@@ -509,48 +543,54 @@ __global__ __launch_bounds__(256) void k_vote_final(const VoteParams p) {
         float wx = 0.0f, wy = 0.0f;
         if (wc > 0) { wx = hp[2 * wi]; wy = hp[2 * wi + 1]; } else { wi = -1; wc = 0; }
 
+        FPC_STAMP(3, 1);
+        const int32_t* cpre = p.lds_table ? s_cpre : gpre;
+        const float4* L = p.list + (size_t)inst * p.ls;
+        const int r_end = min(fg, (run + 1) * kRunEntries);
         double v[kRec] = {0, 0, 0, 0, 0, 0};                            // inliers, a00, a01, a11, b0, b1
-        auto vote = [&](float4 q, bool valid) {
-            if (valid && thin) valid = pixel_kept<KEEP>(q.x, q.y, p.W, p.HW, inst, fg, p.max_num, p.seed, p.keep);
-            if (valid && pair_is_inlier(q.x, q.y, q.z, q.w, sqrtf(q.z * q.z + q.w * q.w), wx, wy, p.thresh)) {
-                const double nx = (double)q.w, ny = -(double)q.z;      // normal = (dy, -dx) :584-586
-                const double bb = nx * (double)q.x + ny * (double)q.y;
-                v[0] += 1.0; v[1] += nx * nx; v[2] += nx * ny; v[3] += ny * ny; v[4] += nx * bb; v[5] += ny * bb;
+        int c = c_lo;                                                   // this lane's chunk cursor: its ranks only grow
+        for (int r0 = run * kRunEntries + threadIdx.x; r0 < r_end; r0 += 8 * 256) {
+            float4 q[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {                               // eight independent loads per lane in flight
+                const int rk = r0 + j * 256;
+                q[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (rk < r_end) q[j] = L[rank_slot_from(cpre, c, rk)];
             }
-        };
-        for (int c = c0; c < c1; ++c) {                                 // uniform
-            const int cnt = __shfl(my_cnt, c - c0, kWave);
-            const float4* L = p.list + (size_t)inst * p.ls + (size_t)c * kChunkPx;
-            const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
-            for (int e0 = 0; e0 < cnt; e0 += 4 * 256) {                 // four independent loads per lane in flight
-                const int e = e0 + threadIdx.x;
-                const float4 q0 = e < cnt ? L[e] : zero, q1 = e + 256 < cnt ? L[e + 256] : zero;
-                const float4 q2 = e + 512 < cnt ? L[e + 512] : zero, q3 = e + 768 < cnt ? L[e + 768] : zero;
-                vote(q0, e < cnt); vote(q1, e + 256 < cnt); vote(q2, e + 512 < cnt); vote(q3, e + 768 < cnt);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                bool valid = r0 + j * 256 < r_end;
+                if (valid && thin) valid = pixel_kept<KEEP>(q[j].x, q[j].y, p.W, p.HW, inst, fg, p.max_num, p.seed, p.keep);
+                if (valid && pair_is_inlier(q[j].x, q[j].y, q[j].z, q[j].w, sqrtf(q[j].z * q[j].z + q[j].w * q[j].w), wx, wy, p.thresh)) {
+                    const double nx = (double)q[j].w, ny = -(double)q[j].z;      // normal = (dy, -dx) :584-586
+                    const double bb = nx * (double)q[j].x + ny * (double)q[j].y;
+                    v[0] += 1.0; v[1] += nx * nx; v[2] += nx * ny; v[3] += ny * ny; v[4] += nx * bb; v[5] += ny * bb;
+                }
             }
         }
+        FPC_STAMP(3, 2);
 #pragma unroll
         for (int a = 0; a < kRec; ++a) {
             const double r = wave_reduce_add(v[a]);
             if (lane == 0) s_part[wv][a] = r;
         }
         __syncthreads();
-        if (threadIdx.x < kRec) {
-            const double r = s_part[0][threadIdx.x] + s_part[1][threadIdx.x] + s_part[2][threadIdx.x] + s_part[3][threadIdx.x];
-            store_wt64(p.partial + ((size_t)inst * p.nrx + ord) * kRec + threadIdx.x, __builtin_bit_cast(unsigned long long, r));
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // the storing wave drains its sc1 stores
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            const int tk = __hip_atomic_fetch_add(p.tickets + inst, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            s_last = (tk == nrec - 1);
-        }
-        __syncthreads();
-        if (!s_last) continue;                                         // uniform
-
-        // last arriver of the instance: the records in ordinal order (independent sc1 loads)
-        if (wv == 0) {
-            double tot[kRec] = {0, 0, 0, 0, 0, 0};
+        FPC_STAMP(3, 3);
+        double tot[kRec];
+#pragma unroll
+        for (int a = 0; a < kRec; ++a) tot[a] = s_part[0][a] + s_part[1][a] + s_part[2][a] + s_part[3][a];
+        if (nrec > 1) {                                                 // uniform
+            if (threadIdx.x < kRec)
+                store_wt64(p.partial + ((size_t)inst * p.nrx + run) * kRec + threadIdx.x, __builtin_bit_cast(unsigned long long, tot[threadIdx.x]));
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // the storing wave drains its sc1 stores
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                const int tk = __hip_atomic_fetch_add(p.tickets + inst, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                s_last = (tk == nrec - 1);
+            }
+            __syncthreads();
+            if (!s_last) continue;                                     // uniform
+            // last arriver of the instance: the records in run order (independent sc1 loads)
             // lane = (record slot r8 = lane / 8, value a = lane % 8): eight records per sweep, then a fixed-order lane tree
             const int a = lane & 7, r8 = lane >> 3;
             double acc = 0.0;
@@ -565,22 +605,23 @@ __global__ __launch_bounds__(256) void k_vote_final(const VoteParams p) {
             acc += __shfl_xor(acc, 8, kWave); acc += __shfl_xor(acc, 16, kWave); acc += __shfl_xor(acc, 32, kWave);
 #pragma unroll
             for (int i = 0; i < kRec; ++i) tot[i] = __shfl(acc, i, kWave);
-            if (lane == 0) {
-                double x0, x1;
-                solve2_sym(tot[1], tot[2], tot[3], tot[4], tot[5], x0, x1);
-                p.out_xy[inst * 2] = (float)x0;
-                p.out_xy[inst * 2 + 1] = (float)x1;
-                if (p.out_tn) p.out_tn[inst] = tn;
-                if (p.out_win_idx) p.out_win_idx[inst] = wi;
-                if (p.out_win_count) p.out_win_count[inst] = wc;
-                if (p.out_inl) p.out_inl[inst] = (int)tot[0];
-                if (p.out_refine) {      // what the refinement's backward needs (fpc_vote_refine_backward)
-                    double* r = p.out_refine + (size_t)inst * 8;
-                    r[0] = (double)wx; r[1] = (double)wy; r[2] = tot[1]; r[3] = tot[2]; r[4] = tot[3]; r[5] = tot[4];
-                    r[6] = tot[5]; r[7] = tot[0];
-                }
+        }
+        if (threadIdx.x == 0) {
+            double x0, x1;
+            solve2_sym(tot[1], tot[2], tot[3], tot[4], tot[5], x0, x1);
+            p.out_xy[inst * 2] = (float)x0;
+            p.out_xy[inst * 2 + 1] = (float)x1;
+            if (p.out_tn) p.out_tn[inst] = tn;
+            if (p.out_win_idx) p.out_win_idx[inst] = wi;
+            if (p.out_win_count) p.out_win_count[inst] = wc;
+            if (p.out_inl) p.out_inl[inst] = (int)tot[0];
+            if (p.out_refine) {      // what the refinement's backward needs (fpc_vote_refine_backward)
+                double* r = p.out_refine + (size_t)inst * 8;
+                r[0] = (double)wx; r[1] = (double)wy; r[2] = tot[1]; r[3] = tot[2]; r[4] = tot[3]; r[5] = tot[4];
+                r[6] = tot[5]; r[7] = tot[0];
             }
         }
+        FPC_STAMP(3, 4);
     }
 }
 
@@ -655,8 +696,8 @@ extern "C" int fpc_ransac_voting_v3(const float* mask, const float* vertex, int6
     p.dkappa = (kappa1 - kappa2) * (1.0f + 1e-6f);
     // rounding allowance of the margin per unit of magnitude M = |gx - ox| + |gy - oy| + radius (k_vote_count's header)
     p.efac = 3.2e-6f * (1.0f + kappa1);
-    p.lds_table = p.nch + 1 <= 2048 ? 1 : 0;              // the three chunk tables of an instance in LDS (<= 24 KB)
-    const size_t table_lds = p.lds_table ? 3 * (size_t)(p.nch + 1) * sizeof(int) : 0;
+    p.lds_table = p.nch + 1 <= 2048 ? 1 : 0;              // the chunk tables of an instance in LDS (<= 8 KB each)
+    const size_t table_lds = p.lds_table ? (size_t)(p.nch + 1) * sizeof(int) : 0;
 
 #ifdef FPC_VOTE_TRACE     // diagnostic build only (python -c "build(extra=['-DFPC_VOTE_TRACE'])"): name the launch that faults
 #define FPC_TRACE(what) do { hipError_t te = hipStreamSynchronize(s); fprintf(stderr, "[fpc vote] %s done: %s\n", what, hipGetErrorString(te)); fflush(stderr); } while (0)
@@ -667,17 +708,18 @@ extern "C" int fpc_ransac_voting_v3(const float* mask, const float* vertex, int6
     const bool vec4 = (HW % 4 == 0) && (((uintptr_t)mask & 15) == 0);
     const bool vg4 = vec4 && W % 4 == 0 && vs_w == 1 && vs_h % 4 == 0 && vs_n % 4 == 0 && vs_c % 4 == 0 &&
                      (((uintptr_t)vertex & 15) == 0);
-    const int scan_grid = (int)std::min<long long>((long long)n * p.nch, 8192);
-#define FPC_LAUNCH_SCAN(A, B) hipLaunchKernelGGL((k_vote_scan<A, B>), dim3(scan_grid), dim3(256), 0, s, p)
+    const int scan_grid = (int)std::min<long long>((long long)n * p.nch, 256 * 4);       // resident: the loop prefetches
+    const ScanParams sp{mask, vertex, vs_n, vs_h, vs_w, vs_c, n, n_dev, W, HW, p.nch, p.ls, p.ctrl, p.chunk_fg, p.chunk_box, p.list, p.stamps};
+#define FPC_LAUNCH_SCAN(A, B) hipLaunchKernelGGL((k_vote_scan<A, B>), dim3(scan_grid), dim3(256), 0, s, sp)
     if (vg4) FPC_LAUNCH_SCAN(true, true); else if (vec4) FPC_LAUNCH_SCAN(true, false); else FPC_LAUNCH_SCAN(false, false);
 #undef FPC_LAUNCH_SCAN
     FPC_TRACE("scan");
 
     // 2. per instance: prefix, origin, units and runs, hypotheses (+ their B fragments), zeroed count row and ticket
     const dim3 plan_grid(std::min(n, 2048));
-    if (keep) hipLaunchKernelGGL((k_vote_plan<true, true>), plan_grid, dim3(1024), table_lds, s, p);
-    else if (idxs || out_tn) hipLaunchKernelGGL((k_vote_plan<true, false>), plan_grid, dim3(1024), table_lds, s, p);
-    else hipLaunchKernelGGL((k_vote_plan<false, false>), plan_grid, dim3(1024), table_lds, s, p);
+    if (keep) hipLaunchKernelGGL((k_vote_plan<true, true>), plan_grid, dim3(1024), 2 * table_lds, s, p);
+    else if (idxs || out_tn) hipLaunchKernelGGL((k_vote_plan<true, false>), plan_grid, dim3(1024), 2 * table_lds, s, p);
+    else hipLaunchKernelGGL((k_vote_plan<false, false>), plan_grid, dim3(1024), 2 * table_lds, s, p);
     FPC_TRACE("plan");
 
     // 3. exact inlier counts of every hypothesis.  One resident round of workgroups (four per CU); the kernel reads how
@@ -692,8 +734,8 @@ extern "C" int fpc_ransac_voting_v3(const float* mask, const float* vertex, int6
 
     // 4. winner, its inliers, refinement: one task per run of chunks
     const int fin_grid = (int)std::min<long long>(std::max<long long>((long long)n * p.nrx, 1), 2048);
-    if (keep) hipLaunchKernelGGL(k_vote_final<true>, dim3(fin_grid), dim3(256), 0, s, p);
-    else hipLaunchKernelGGL(k_vote_final<false>, dim3(fin_grid), dim3(256), 0, s, p);
+    if (keep) hipLaunchKernelGGL(k_vote_final<true>, dim3(fin_grid), dim3(256), table_lds, s, p);
+    else hipLaunchKernelGGL(k_vote_final<false>, dim3(fin_grid), dim3(256), table_lds, s, p);
     FPC_TRACE("final");
 
     // diagnostics (never on the product path): copies of the hypotheses and of the count rows

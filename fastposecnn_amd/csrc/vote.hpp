@@ -7,15 +7,14 @@ namespace fpc {
 
 constexpr int kChunkPx = 4096;       // pixels per k_vote_scan task; a chunk owns list slots [c * 4096, c * 4096 + its count)
 constexpr int kChunkWords = 64;      // 64-pixel words per chunk
-constexpr int kUnitEntries = 512;    // list entries per count unit (4 waves x 2 groups of 64), always inside one chunk
-constexpr int kUnitsPerChunk = kChunkPx / kUnitEntries;
-constexpr int kRunChunks = 8;        // chunks per refinement run (k_vote_final task)
+constexpr int kUnitEntries = 512;    // foreground ranks per count unit (4 waves x 2 groups of 64): [512 u, 512 u + 512) of an instance
+constexpr int kRunEntries = 8192;    // foreground ranks per refinement run (k_vote_final task)
 constexpr int kHypTile = 32;         // hypotheses per MFMA tile
 constexpr int kMaxSliceTiles = 64;   // hypothesis tiles per k_vote_count task at most (LDS count rows)
 constexpr int kPlanI = 8;            // i32 per instance: fg, tn, thin, origin x, origin y, radius, runs, votes
 constexpr int kMaxHn = 65536;
 constexpr int kRec = 6;              // doubles per refinement record: inliers, a00, a01, a11, b0, b1
-constexpr int kBandQ = 320;          // queued undecided pairs per wave (one step adds at most 4 x 64)
+constexpr int kBandQ = 192;          // queued undecided-pair records per wave (one step adds at most 64)
 constexpr float kNeverS = 1.0e30f;   // |s| of an entry that never votes
 
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
@@ -32,9 +31,6 @@ struct VoteParams {
     float* out_xy; int32_t* out_tn; int32_t* out_win_idx; int32_t* out_win_count; int32_t* out_inl; double* out_refine;
     // derived
     int nch, ntiles, hnp, nux, nrx, lds_table, want_tn, all_wild, task_target;
-#ifdef FPC_DBG_STOP
-    int dbg_stop;
-#endif
     size_t ls;                        // list slots per instance = nch * kChunkPx
     float kappa2, dkappa, efac;
     // workspace
@@ -43,8 +39,8 @@ struct VoteParams {
     int32_t* plan;        // [n, kPlanI]
     int32_t* chunk_fg;    // [n, nch]       foreground count per chunk
     int32_t* chunk_box;   // [n, nch, 4]    x min / max, y min / max of the chunk's foreground pixels
-    int32_t* chunk_pre;   // [n, nch + 1]   exclusive prefix of the counts (when the tables do not fit LDS)
-    int32_t* unit_pre;    // [n, nch + 1]   exclusive prefix of the count units per chunk                (same condition)
+    int32_t* chunk_pre;   // [n, nch + 1]   exclusive prefix of the counts: rank r of an instance sits in chunk c with
+                          //                chunk_pre[c] <= r < chunk_pre[c + 1], at list slot c * 4096 + r - chunk_pre[c]
     int32_t* kept_pre;    // [n, nch + 1]   prefix over the KEPT entries (thinned instance with injected idxs / out_tn only)
     uint32_t* kept_wpre;  // [n, nch * 64]  kept entries before each 64-entry group inside its chunk     (same case)
     uint64_t* kept_bits;  // [n, nch * 64]  keep decisions of each 64-entry group                        (same case)
@@ -53,9 +49,17 @@ struct VoteParams {
     int32_t* counts;      // [n, hnp]       exact inlier count of every hypothesis; zeroed by k_vote_plan
     double* partial;      // [n, nrx, kRec] k_vote_final per-run records
     float4* list;         // [n, ls]        {x, y, dx, dy} of the foreground pixels, compacted per chunk (k_vote_scan)
-    int4* units;          // [n * nux]      {instance | block << 16 | thin << 19 | (chunk count - 1) << 20, chunk, -, ox | oy << 16}
-    int4* runs;           // [n * nrx]      {instance, first chunk, end chunk, ordinal inside the instance}
+    int4* units;          // [n * nux]      {instance | thin << 16 | (entries - 1) << 17, block u, chunk of rank 512 u, ox | oy << 16}
+    int4* runs;           // [n * nrx]      {instance, run r (= its record ordinal), chunk of rank 8192 r, -}
+    unsigned long long* stamps;   // [4, 32]  s_memrealtime (100 MHz) at the phases of workgroup 0 of each kernel: written only by a
+                                  //          diagnostic build (-DFPC_STAMP_VOTE, tools_dev/vote_stamps.py); never read by a kernel
 };
+
+#ifdef FPC_STAMP_VOTE
+#define FPC_STAMP(kernel, slot) do { if (blockIdx.x == 0 && threadIdx.x == 0) p.stamps[(kernel) * 32 + (slot)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define FPC_STAMP(kernel, slot) do { } while (0)
+#endif
 
 struct Ws {
     VoteParams p;
@@ -69,8 +73,8 @@ inline Ws carve(void* base, int n, int H, int W, int hn) {
     p.nch = cdiv((int)HW, kChunkPx);
     p.ntiles = cdiv(hn, kHypTile);
     p.hnp = p.ntiles * kHypTile;
-    p.nux = p.nch * kUnitsPerChunk;
-    p.nrx = cdiv(p.nch, kRunChunks);
+    p.nux = cdiv((int)HW, kUnitEntries);
+    p.nrx = cdiv((int)HW, kRunEntries);
     p.ls = (size_t)p.nch * kChunkPx;
     char* b = (char*)base;
     size_t off = 0;
@@ -81,7 +85,6 @@ inline Ws carve(void* base, int n, int H, int W, int hn) {
     p.chunk_fg = (int32_t*)take(sizeof(int32_t) * (size_t)n * p.nch);
     p.chunk_box = (int32_t*)take(sizeof(int32_t) * (size_t)n * p.nch * 4);
     p.chunk_pre = (int32_t*)take(sizeof(int32_t) * (size_t)n * (p.nch + 1));
-    p.unit_pre = (int32_t*)take(sizeof(int32_t) * (size_t)n * (p.nch + 1));
     p.kept_pre = (int32_t*)take(sizeof(int32_t) * (size_t)n * (p.nch + 1));
     p.kept_wpre = (uint32_t*)take(sizeof(uint32_t) * (size_t)n * p.nch * kChunkWords);
     p.kept_bits = (uint64_t*)take(sizeof(uint64_t) * (size_t)n * p.nch * kChunkWords);
@@ -92,6 +95,7 @@ inline Ws carve(void* base, int n, int H, int W, int hn) {
     p.list = (float4*)take(sizeof(float4) * (size_t)n * p.ls);
     p.units = (int4*)take(sizeof(int4) * (size_t)n * p.nux);
     p.runs = (int4*)take(sizeof(int4) * (size_t)n * p.nrx);
+    p.stamps = (unsigned long long*)take(sizeof(unsigned long long) * 4 * 32);
     w.total = off;
     return w;
 }
@@ -154,6 +158,13 @@ __device__ __forceinline__ int rank_chunk(const int32_t* cpre, int nch, int e) {
         if (cpre[mid] <= e) lo = mid; else hi = mid;
     }
     return lo;
+}
+
+// list slot of foreground rank r, walking the instance's chunk prefix forward from chunk c (cpre[c] <= r): a count unit or
+// a refinement run starts in a known chunk and its ranks sit in that chunk or the next few
+__device__ __forceinline__ int rank_slot_from(const int32_t* __restrict__ cpre, int& c, int r) {
+    while (cpre[c + 1] <= r) ++c;
+    return c * kChunkPx + (r - cpre[c]);
 }
 
 // Is pixel (x, y) of a THINNED instance kept (RV/ransac_voting_gpu.py:541-545)?  KEEP: the caller injected the selection.

@@ -4,14 +4,16 @@
 namespace fpc {
 
 // ---- k_vote_count ------------------------------------------------------------------
-// EXACT inlier count of every hypothesis.  Task -> (count unit, slice of hypothesis tiles); the slicing is chosen on the
-// device from the unit count so that the tasks fill one resident round of workgroups.  256 threads; wave w owns the
-// unit's 64-entry groups w and w + 4.  Per group the wave builds the A fragments of the two forms (prologue, once per
-// task); per hypothesis tile it loads ONE B fragment (16 bytes per lane) and issues two MFMAs per 32 entries; the
-// result registers hold, per lane, ONE hypothesis (column lane & 31) against 16 entries (rows), so counts stay lane-local:
+// EXACT inlier count of every hypothesis.  Task -> (count unit = 512 consecutive foreground ranks of an instance, slice of
+// hypothesis tiles); the slicing is chosen on the device from the unit count so that the tasks fill one resident round of
+// workgroups.  256 threads; wave w owns the unit's 64-entry groups w and w + 4.  Per group the wave builds the A
+// fragments of the two forms (prologue, once per task); per hypothesis tile it loads ONE B fragment (16 bytes per lane)
+// and issues two MFMAs per 32 entries; the result registers hold, per lane, ONE hypothesis (column lane & 31) against 16
+// entries (rows), so counts stay lane-local:
 //     r = F_t - |F_s| ;  row = (row << 2) | (r >> 30) ;  after 16: neg += popc(row & 0xAAAAAAAA), undecided = odd bit set & even clear.
-// The unit record and the entries of the NEXT task are requested while the current one computes (a task is ~1 us of
-// arithmetic behind ~3 us of dependent loads otherwise), and undecided pairs wait in the wave's queue ACROSS tasks.
+// The unit record of the task after next and the entries of the NEXT task are requested while the current one computes
+// (a task is ~1 us of arithmetic behind ~3 us of dependent loads otherwise); undecided pairs wait in the wave's queue
+// ACROSS tasks, one 16-byte record per (lane, hypothesis tile) that has any.
 // Error budget of r (units of the unscaled margin, M = |gx - ox| + |gy - oy| + radius, |e| = 1):
 //     unit vote by v_rsq_f32 (1 ulp) and two products ............................ 4e-7 M   (s and t forms alike)
 //     gx - ox, sigma (gx - ox): two roundings; c_s / c_t: three at <= radius ........ 3e-7 M
@@ -34,31 +36,55 @@ __device__ __forceinline__ KParams kernel_params() {
 #endif
 }
 
-struct UnitRef { int inst, c, k, cnt; bool thin; float fox, foy; };
+struct UnitRef { int inst, u, c_lo, nvalid; bool thin; float fox, foy; };
 __device__ __forceinline__ UnitRef decode_unit(int4 ub) {
-    UnitRef u;
-    u.inst = ub.x & 0xffff; u.k = (ub.x >> 16) & 7; u.thin = (ub.x >> 19) & 1; u.cnt = ((unsigned)ub.x >> 20) + 1;
-    u.c = ub.y; u.fox = (float)(ub.w & 0xffff); u.foy = (float)((unsigned)ub.w >> 16);
-    return u;
+    UnitRef r;
+    r.inst = ub.x & 0xffff; r.thin = (ub.x >> 16) & 1; r.nvalid = ((ub.x >> 17) & 0x1ff) + 1;
+    r.u = ub.y; r.c_lo = ub.z; r.fox = (float)(ub.w & 0xffff); r.foy = (float)((unsigned)ub.w >> 16);
+    return r;
 }
 
-// the pairs the filter could not decide: {hypothesis | entry-in-unit << 16, unit}; evaluated 64 at a time, one per lane
+// entry `ent` (0..511) of a unit
+__device__ __forceinline__ float4 unit_entry(const float4* __restrict__ list, size_t ls, const int32_t* __restrict__ chunk_pre,
+                                             int nch, const UnitRef& u, int ent) {
+    int c = u.c_lo;
+    const int slot = rank_slot_from(chunk_pre + (size_t)u.inst * (nch + 1), c, u.u * kUnitEntries + ent);
+    return list[(size_t)u.inst * ls + slot];
+}
+
+// The pairs the filter could not decide, one record per (lane, hypothesis tile): {bits of row tiles 0 | 1 << 1 (group w),
+// the same of group w + 4, tile | lane << 16 | wave << 22, unit}.  A lane takes a record and walks its bits with the
+// reference's own arithmetic.
 template <bool KEEP>
-__device__ __attribute__((noinline)) void band_flush(int nq, const int2* __restrict__ queue, KParams kp) {
+__device__ __attribute__((noinline)) void band_flush(int nq, const int4* __restrict__ queue, KParams kp) {
     const auto& p = *kp;
     const int lane = threadIdx.x & (kWave - 1), hn = p.hn;
     for (int base = 0; base < nq; base += kWave) {                           // uniform
         if (base + lane >= nq) continue;
-        const int2 e = queue[base + lane];
-        const int h = e.x & 0xffff, ent = e.x >> 16;
-        const UnitRef u = decode_unit(p.units[e.y]);
-        const int nvalid = min(kUnitEntries, u.cnt - u.k * kUnitEntries);
-        if (ent >= nvalid || h >= hn) continue;
-        const float4 q = p.list[(size_t)u.inst * p.ls + (size_t)u.c * kChunkPx + (size_t)u.k * kUnitEntries + ent];
-        if (u.thin && !pixel_kept<KEEP>(q.x, q.y, p.W, p.HW, u.inst, p.plan[(size_t)u.inst * kPlanI], p.max_num, p.seed, p.keep)) continue;
+        const int4 e = queue[base + lane];
+        const UnitRef u = decode_unit(p.units[e.w]);
+        const int T = e.z & 0xffff, src_lane = (e.z >> 16) & 63, src_wave = (e.z >> 22) & 3;
+        const int h = T * kHypTile + (src_lane & 31);
+        if (h >= hn) continue;
         const float gx = p.hyp[((size_t)u.inst * hn + h) * 2], gy = p.hyp[((size_t)u.inst * hn + h) * 2 + 1];
-        if (pair_is_inlier(q.x, q.y, q.z, q.w, sqrtf(q.z * q.z + q.w * q.w), gx, gy, p.thresh))
-            atomicAdd(p.counts + (size_t)u.inst * p.hnp + h, 1);
+        const int fg = u.thin ? p.plan[(size_t)u.inst * kPlanI] : 0;
+        int add = 0;
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            unsigned w = half ? (unsigned)e.y : (unsigned)e.x;
+            while (w) {
+                const int b = __ffs((int)w) - 1;
+                w &= w - 1u;
+                const int i = 15 - (b >> 1);                               // register index: the last one shifted in sits lowest
+                const int row = (i & 3) + 8 * (i >> 2) + 4 * (src_lane >> 5);
+                const int ent = (src_wave + 4 * half) * kWave + (b & 1) * 32 + row;
+                if (ent >= u.nvalid) continue;
+                const float4 q = unit_entry(p.list, p.ls, p.chunk_pre, p.nch, u, ent);
+                if (u.thin && !pixel_kept<KEEP>(q.x, q.y, p.W, p.HW, u.inst, fg, p.max_num, p.seed, p.keep)) continue;
+                add += pair_is_inlier(q.x, q.y, q.z, q.w, sqrtf(q.z * q.z + q.w * q.w), gx, gy, p.thresh) ? 1 : 0;
+            }
+        }
+        if (add) atomicAdd(p.counts + (size_t)u.inst * p.hnp + h, add);
     }
 }
 
@@ -106,8 +132,9 @@ __device__ __forceinline__ unsigned tile_rows(const u32x4& As, const u32x4& At, 
 template <int WAVES /* waves per SIMD the register allocation aims at */, bool KEEP>
 __global__ __launch_bounds__(256, WAVES) void k_vote_count(const VoteParams p) {
     extern __shared__ __attribute__((aligned(16))) int s_cnt[];      // [gps * 32]
-    __shared__ int2 s_bandq[4][kBandQ];
+    __shared__ int4 s_bandq[4][kBandQ];
     const int lane = threadIdx.x & (kWave - 1), wv = threadIdx.x / kWave;
+    FPC_STAMP(2, 0);
     const int nu = p.ctrl[0];
     const int ntiles = p.ntiles;
     // units x S slices ~ the task count the launch was sized for: one round of equal tasks over the chip
@@ -116,23 +143,22 @@ __global__ __launch_bounds__(256, WAVES) void k_vote_count(const VoteParams p) {
     const int S = (ntiles + gps - 1) / gps;
     const long long total = (long long)nu * S;
     const long long G = gridDim.x;
-    int2* bq = s_bandq[wv];
+    int4* bq = s_bandq[wv];
     int qn = 0;
     long long t = blockIdx.x;
     if (t >= total) return;                                                  // uniform
     // software pipeline over this workgroup's tasks: unit records two tasks ahead, entries one task ahead
     auto load_entries = [&](int4 ub, float4& qa, float4& qb) {
         const UnitRef u = decode_unit(ub);
-        const int nvalid = min(kUnitEntries, u.cnt - u.k * kUnitEntries);
-        const float4* U = p.list + (size_t)u.inst * p.ls + (size_t)u.c * kChunkPx + (size_t)u.k * kUnitEntries;
         const int ea = wv * kWave + lane, eb = (wv + 4) * kWave + lane;
-        qa = ea < nvalid ? U[ea] : make_float4(0.f, 0.f, 0.f, 0.f);
-        qb = eb < nvalid ? U[eb] : make_float4(0.f, 0.f, 0.f, 0.f);
+        qa = ea < u.nvalid ? unit_entry(p.list, p.ls, p.chunk_pre, p.nch, u, ea) : make_float4(0.f, 0.f, 0.f, 0.f);
+        qb = eb < u.nvalid ? unit_entry(p.list, p.ls, p.chunk_pre, p.nch, u, eb) : make_float4(0.f, 0.f, 0.f, 0.f);
     };
     int4 ub = p.units[t / S];
     int4 ub1 = (t + G < total) ? p.units[(t + G) / S] : make_int4(0, 0, 0, 0);
     float4 qa, qb;
     load_entries(ub, qa, qb);
+    FPC_STAMP(2, 1);
     for (;;) {
         const bool more = t + G < total;
         const int4 ub2 = (t + 2 * G < total) ? p.units[(t + 2 * G) / S] : make_int4(0, 0, 0, 0);
@@ -141,14 +167,13 @@ __global__ __launch_bounds__(256, WAVES) void k_vote_count(const VoteParams p) {
         const int uidx = (int)(t / S), s = (int)(t - (long long)uidx * S);
         const UnitRef u = decode_unit(ub);
         const int inst = u.inst;
-        const int nvalid = min(kUnitEntries, u.cnt - u.k * kUnitEntries);
         const int T0 = s * gps, T1 = min(ntiles, T0 + gps);
         // this wave's groups: w and w + 4 of the unit's eight
-        const int ng = (wv * kWave < nvalid ? 1 : 0) + ((wv + 4) * kWave < nvalid ? 1 : 0);
+        const int ng = (wv * kWave < u.nvalid ? 1 : 0) + ((wv + 4) * kWave < u.nvalid ? 1 : 0);
         GroupFrags Gf[2];
         {
             const int fg = u.thin ? p.plan[(size_t)inst * kPlanI] : 0;
-            bool va = wv * kWave + lane < nvalid, vb = (wv + 4) * kWave + lane < nvalid;
+            bool va = wv * kWave + lane < u.nvalid, vb = (wv + 4) * kWave + lane < u.nvalid;
             if (u.thin) {
                 va = va && pixel_kept<KEEP>(qa.x, qa.y, p.W, p.HW, inst, fg, p.max_num, p.seed, p.keep);
                 vb = vb && pixel_kept<KEEP>(qb.x, qb.y, p.W, p.HW, inst, fg, p.max_num, p.seed, p.keep);
@@ -158,53 +183,46 @@ __global__ __launch_bounds__(256, WAVES) void k_vote_count(const VoteParams p) {
         }
         for (int i = threadIdx.x; i < (T1 - T0) * kHypTile; i += blockDim.x) s_cnt[i] = 0;
         __syncthreads();
+        FPC_STAMP(2, 2);
         if (ng > 0) {                                                       // uniform per wave
             const u32x4* Bp = p.hypB + ((size_t)inst * ntiles + T0) * kWave + lane;
             u32x4 Bn = *Bp;
             for (int T = T0; T < T1; ++T) {
                 const bf16x8 B = __builtin_bit_cast(bf16x8, Bn);
                 if (T + 1 < T1) Bn = Bp[(size_t)(T + 1 - T0) * kWave];
-                unsigned bm[4] = {0u, 0u, 0u, 0u};
+                unsigned w01 = 0u, w23 = 0u;
                 int neg = 0;
-#pragma unroll
-                for (int gi = 0; gi < 2; ++gi) {
-                    if (gi < ng) {
-#pragma unroll
-                        for (int rt = 0; rt < 2; ++rt) {
-                            const unsigned row = tile_rows(Gf[gi].s[rt], Gf[gi].t[rt], B);
-                            neg += __popc(row & 0xAAAAAAAAu);
-                            bm[gi * 2 + rt] = (row >> 1) & ~row & 0x55555555u;
-                        }
-                    }
+                {
+                    const unsigned r0 = tile_rows(Gf[0].s[0], Gf[0].t[0], B), r1 = tile_rows(Gf[0].s[1], Gf[0].t[1], B);
+                    neg = __popc(r0 & 0xAAAAAAAAu) + __popc(r1 & 0xAAAAAAAAu);
+                    w01 = ((r0 >> 1) & ~r0 & 0x55555555u) | (r1 & ~(r1 << 1) & 0xAAAAAAAAu);
+                }
+                if (ng > 1) {                                               // uniform per wave
+                    const unsigned r2 = tile_rows(Gf[1].s[0], Gf[1].t[0], B), r3 = tile_rows(Gf[1].s[1], Gf[1].t[1], B);
+                    neg += __popc(r2 & 0xAAAAAAAAu) + __popc(r3 & 0xAAAAAAAAu);
+                    w23 = ((r2 >> 1) & ~r2 & 0x55555555u) | (r3 & ~(r3 << 1) & 0xAAAAAAAAu);
                 }
                 // lane-local: column (lane & 31) of tile T against 16 rows x 2 tiles x ng groups
                 atomicAdd(&s_cnt[(T - T0) * kHypTile + (lane & 31)], ng * 32 - neg);
-                // undecided pairs -> the wave's queue (a handful per step)
-                while (__builtin_amdgcn_ballot_w64((bm[0] | bm[1] | bm[2] | bm[3]) != 0u)) {        // uniform
-                    const bool has = (bm[0] | bm[1] | bm[2] | bm[3]) != 0u;
-                    int j = 0;
-                    unsigned m = bm[0];
-                    if (!m) { j = 1; m = bm[1]; }
-                    if (!m) { j = 2; m = bm[2]; }
-                    if (!m) { j = 3; m = bm[3]; }
-                    const int bit = has ? __ffs((int)m) - 1 : 0;
-                    const unsigned cl = m & (m - 1u);
-                    if (j == 0) bm[0] = cl; else if (j == 1) bm[1] = cl; else if (j == 2) bm[2] = cl; else bm[3] = cl;
-                    const int i = 15 - (bit >> 1);                           // register index: the last one shifted in is bit 0
-                    const int row = (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5);
-                    const int ent = ((wv + 4 * (j >> 1)) * kWave) + (j & 1) * 32 + row;
-                    const int code = (T * kHypTile + (lane & 31)) | (ent << 16);
-                    const unsigned long long mk = __builtin_amdgcn_ballot_w64(has);
-                    if (qn + __popcll(mk) > kBandQ) {
+                // undecided pairs -> one record per lane that has any (a handful per step)
+                const bool has = (w01 | w23) != 0u;
+                const unsigned long long mk = __builtin_amdgcn_ballot_w64(has);
+                if (mk) {                                                   // uniform
+                    const int add = __popcll(mk);
+                    if (qn + add > kBandQ) {
                         band_flush<KEEP>(qn, bq, kernel_params());
                         qn = 0;
                     }
-                    if (has) bq[qn + __builtin_amdgcn_mbcnt_hi((unsigned)(mk >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mk, 0))] = make_int2(code, uidx);
-                    qn += __popcll(mk);
+                    if (has)
+                        bq[qn + __builtin_amdgcn_mbcnt_hi((unsigned)(mk >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mk, 0))] =
+                            make_int4((int)w01, (int)w23, T | (lane << 16) | (wv << 22), uidx);
+                    qn += add;
                 }
             }
         }
+        FPC_STAMP(2, 3);
         __syncthreads();
+        FPC_STAMP(2, 4);
         // one integer atomic per (unit, hypothesis) with any count: order-independent result
         for (int i = threadIdx.x; i < (T1 - T0) * kHypTile; i += blockDim.x) {
             const int h = T0 * kHypTile + i, cv = s_cnt[i];
@@ -214,9 +232,10 @@ __global__ __launch_bounds__(256, WAVES) void k_vote_count(const VoteParams p) {
         if (!more) break;
         t += G; ub = ub1; ub1 = ub2; qa = qan; qb = qbn;
     }
+    FPC_STAMP(2, 5);
     if (qn) band_flush<KEEP>(qn, bq, kernel_params());
+    FPC_STAMP(2, 6);
 }
-
 
 void launch_vote_count(const VoteParams& p, int grid, size_t lds_bytes, hipStream_t s) {
     if (p.keep) hipLaunchKernelGGL((k_vote_count<4, true>), dim3(grid), dim3(256), lds_bytes, s, p);

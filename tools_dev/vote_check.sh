@@ -1,0 +1,8 @@
+#!/bin/bash
+# parity tests of the vote, then the per-kernel profile at both bench settings
+cd $GRAFT_REPO_ROOT
+timeout 900 python -m pytest tests/test_gpu_parity.py -x -q -m gpu > gpurun_out/m_t.log 2>&1; rc=$?
+echo "pytest rc=$rc $(tail -1 gpurun_out/m_t.log | cut -c1-80)"
+if grep -q "Memory access fault" gpurun_out/m_t.log; then echo FAULT; exit 1; fi
+[ $rc = 0 ] || { tail -30 gpurun_out/m_t.log | cut -c1-200; exit 1; }
+bash tools_dev/vote_prof_quick.sh 2>&1 | grep -v "^$" | grep -v amdgpu.ids | grep "k_vote\|per-call\|fault"
