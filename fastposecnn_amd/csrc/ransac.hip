@@ -147,6 +147,8 @@ __global__ __launch_bounds__(256) void k_vote_scan(const ScanParams p) {
             mv[k] = px < HW ? *reinterpret_cast<const float4*>(m + px) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
     };
+    // (Tasks handed out by tickets instead of this static round-robin - 16 sharded words, a memset - measured 70 + 5 us
+    // against 68 us at B = 32: the kernel moves 330 MB in 65 us, it is at the memory system's rate, not unbalanced.)
     if (VEC4 && (int)blockIdx.x < total) load_mask(blockIdx.x, cur);
     for (int t = blockIdx.x; t < total; t += gridDim.x) {
         const int inst = t / nch, c = t - inst * nch;
@@ -275,17 +277,21 @@ __device__ __forceinline__ int block_scan(F f, int32_t* out, int cnt, int* s_w /
     return carry;
 }
 
-// One 1024-thread workgroup per instance.  dynamic LDS: [2][nch + 1] ints when p.lds_table.
+// gridDim.y 256-thread workgroups per instance: each repeats the (cheap) prefix and bounding box and takes a share of the
+// hypotheses, part 0 writes the instance's record, units and runs.  dynamic LDS: [2][nch + 1] ints when p.lds_table.
 // INJ: the caller injected pair indices or a keep selection, or wants the out_tn diagnostic (tests and goldens): only that
-// variant carries the kept-pixel tables.  KEEP: see pixel_kept.
+// variant carries the kept-pixel tables, and it runs as ONE part.  KEEP: see pixel_kept.
 template <bool INJ, bool KEEP>
-__global__ __launch_bounds__(1024) void k_vote_plan(const VoteParams p) {
+__global__ __launch_bounds__(256) void k_vote_plan(const VoteParams p) {
     extern __shared__ __attribute__((aligned(16))) int s_tab[];
     __shared__ int s_w[20];
     __shared__ int s_misc[8];
     const int nch = p.nch, W = p.W, HW = p.HW, hn = p.hn;
     const int n_act = active_instances(p.n, p.n_dev);
     const int lane = threadIdx.x & (kWave - 1), wv = threadIdx.x / kWave, nw = blockDim.x / kWave;
+    const int part = blockIdx.y, parts = gridDim.y;
+    const int tiles_pp = (p.ntiles + parts - 1) / parts;                    // hypothesis tiles per part
+    const int h_lo = min(p.hnp, part * tiles_pp * kHypTile), h_hi = min(p.hnp, (part + 1) * tiles_pp * kHypTile);
     for (int inst = blockIdx.x; inst < n_act; inst += gridDim.x) {
         const int32_t* cfg = p.chunk_fg + (size_t)inst * nch;
         int32_t* gpre = p.chunk_pre + (size_t)inst * (nch + 1);                    // k_vote_count / k_vote_final read it
@@ -294,8 +300,8 @@ __global__ __launch_bounds__(1024) void k_vote_plan(const VoteParams p) {
         const float4* E = p.list + (size_t)inst * p.ls;
 
         FPC_STAMP(1, 0);
-        for (int h = threadIdx.x; h < p.hnp; h += blockDim.x) p.counts[(size_t)inst * p.hnp + h] = 0;
-        if (threadIdx.x == 0) p.tickets[inst] = 0;
+        for (int h = h_lo + threadIdx.x; h < h_hi; h += blockDim.x) p.counts[(size_t)inst * p.hnp + h] = 0;
+        if (part == 0 && threadIdx.x == 0) p.tickets[inst] = 0;
         if (threadIdx.x < 4) s_misc[threadIdx.x] = (threadIdx.x & 1) ? -1 : 0x7fffffff;
         // bounding box of the instance -> the origin the filter's coordinates are measured from and the radius
         // max |x - ox| + |y - oy| of its pixels (both only scale the rounding allowance: any values are sound)
@@ -306,7 +312,7 @@ __global__ __launch_bounds__(1024) void k_vote_plan(const VoteParams p) {
         }
         const int fg = block_scan([&](int c) { return cfg[c]; }, cpre, nch, s_w);
         FPC_STAMP(1, 1);
-        if (p.lds_table)
+        if (p.lds_table && part == 0)
             for (int c = threadIdx.x; c <= nch; c += blockDim.x) gpre[c] = cpre[c];
 #pragma unroll
         for (int o = kWave / 2; o > 0; o >>= 1) {
@@ -353,10 +359,10 @@ __global__ __launch_bounds__(1024) void k_vote_plan(const VoteParams p) {
             tn = block_scan([&](int c) { return kpre[c]; }, kpre, nch, s_w);
         }
         const bool votes = fg >= p.min_num && tn > 0;     // :536-539
-        // count units: 512 consecutive foreground ranks; refinement runs: 8192 (the run number indexes the records)
+        // count units: 512 consecutive foreground ranks; refinement runs: p.run_entries (the run number indexes the records)
         const int nunits = votes ? (fg + kUnitEntries - 1) / kUnitEntries : 0;
-        const int nruns = votes ? (fg + kRunEntries - 1) / kRunEntries : 0;
-        if (threadIdx.x == 0) {
+        const int nruns = votes ? (fg + p.run_entries - 1) / p.run_entries : 0;
+        if (part == 0 && threadIdx.x == blockDim.x - kWave) {   // the last wave: its wait for the two list bases delays no hypothesis of a short row
             int32_t* pl = p.plan + (size_t)inst * kPlanI;
             pl[0] = fg; pl[1] = votes ? tn : 0; pl[2] = thin ? 1 : 0; pl[3] = ox; pl[4] = oy; pl[5] = rad;
             pl[6] = nruns; pl[7] = votes ? 1 : 0;
@@ -365,7 +371,7 @@ __global__ __launch_bounds__(1024) void k_vote_plan(const VoteParams p) {
             s_misc[5] = nruns ? atomicAdd(p.ctrl + 1, nruns) : 0;
         }
         if (!votes) {                                     // uniform: no unit, no run; k_vote_final writes the zeros
-            for (int i = threadIdx.x; i < 2 * hn; i += blockDim.x) p.hyp[(size_t)inst * hn * 2 + i] = 0.0f;   // the out_hyp diagnostic
+            for (int i = 2 * h_lo + threadIdx.x; i < 2 * min(hn, h_hi); i += blockDim.x) p.hyp[(size_t)inst * hn * 2 + i] = 0.0f;   // the out_hyp diagnostic
             __syncthreads();
             continue;
         }
@@ -397,9 +403,9 @@ __global__ __launch_bounds__(1024) void k_vote_plan(const VoteParams p) {
         };
         FPC_STAMP(1, 3);
         const float bx0 = (float)x0, bx1 = (float)x1, by0 = (float)y0, by1 = (float)y1;
-        for (int h0 = 0; h0 < p.hnp; h0 += blockDim.x) {
+        for (int h0 = h_lo; h0 < h_hi; h0 += blockDim.x) {
             const int hi = h0 + threadIdx.x;
-            if (hi >= p.hnp) break;
+            if (hi >= h_hi) break;
             // padded hypothesis: margin -4 for every entry (never counted, never undecided)
             float X = 0.0f, Y = 0.0f, S = 0.0f, ES = 4.0f;
             if (hi < hn) {
@@ -445,14 +451,17 @@ __global__ __launch_bounds__(1024) void k_vote_plan(const VoteParams p) {
         FPC_STAMP(1, 4);
         __syncthreads();               // s_misc[4], [5]: the list bases
         FPC_STAMP(1, 5);
-        const int ubase = s_misc[4], rbase = s_misc[5];
-        for (int u = threadIdx.x; u < nunits; u += blockDim.x) {
-            const int nvalid = min(kUnitEntries, fg - u * kUnitEntries);
-            p.units[ubase + u] = make_int4(inst | (thin ? 1 << 16 : 0) | ((nvalid - 1) << 17), u, rank_chunk(cpre, nch, u * kUnitEntries),
-                                           (ox & 0xffff) | (oy << 16));
+        if (part == 0) {
+            const int ubase = s_misc[4], rbase = s_misc[5];
+            for (int u = threadIdx.x; u < nunits; u += blockDim.x) {
+                const int r0 = u * kUnitEntries, c = rank_chunk(cpre, nch, r0);
+                const int nvalid = min(kUnitEntries, fg - r0);
+                p.units[2 * (ubase + u)] = make_int4(inst | (thin ? 1 << 16 : 0) | ((nvalid - 1) << 17), u, c, (ox & 0xffff) | (oy << 16));
+                p.units[2 * (ubase + u) + 1] = make_int4(c * kChunkPx + (r0 - cpre[c]), cpre[c + 1] - r0, fg, 0);
+            }
+            for (int rr = threadIdx.x; rr < nruns; rr += blockDim.x)
+                p.runs[rbase + rr] = make_int4(inst, rr, rank_chunk(cpre, nch, rr * p.run_entries), fg | (thin ? (int)0x80000000 : 0));
         }
-        for (int rr = threadIdx.x; rr < nruns; rr += blockDim.x)
-            p.runs[rbase + rr] = make_int4(inst, rr, rank_chunk(cpre, nch, rr * kRunEntries), 0);
         FPC_STAMP(1, 6);
         __syncthreads();               // s_tab / s_misc are reused by the next instance
     }
@@ -478,19 +487,21 @@ __device__ __forceinline__ void solve2_sym(double a00, double a01, double a11, d
     }
 }
 
-constexpr int kFinWaves = 4;         // 256-thread workgroups
+constexpr int kFinWaves = 8;         // 512-thread workgroups: at 120 VGPRs two fit a CU, i.e. 512 resident tasks (1024 threads: one per CU,
+                                     // and the 370 runs of the B = 32 batch took two rounds)
 
 // Winner (largest count, lowest index: torch.max, RV/ransac_voting_gpu.py:567), its inliers voted again (:583-589) with
-// the reference's arithmetic, the fp64 normal equations and the 2x2 solve (:592-599).  Task = one run of 8192 consecutive
-// foreground ranks of an instance: 256 lanes stream the entries eight loads deep.  An instance of one run (the usual
+// the reference's arithmetic, the fp64 normal equations and the 2x2 solve (:592-599).  Task = one run of p.run_entries
+// consecutive foreground ranks of an instance, 512 lanes, four loads in flight each.  An instance of one run (the usual
 // case) is solved by its task; otherwise the run whose arrival ticket comes last combines the instance's records
 // (Guideline 16, counter form: records stored write-through (sc1), the storing wave drained, one agent-scope add per
 // workgroup; the last arriver reads them back with sc1 loads, in run order: bit-reproducible).
 // dynamic LDS: the instance's chunk prefix [nch + 1] when p.lds_table.
 template <bool KEEP>
-__global__ __launch_bounds__(256) void k_vote_final(const VoteParams p) {
+__global__ __launch_bounds__(64 * kFinWaves) void k_vote_final(const VoteParams p) {
     extern __shared__ __attribute__((aligned(16))) int s_cpre[];
     __shared__ int s_red[2 * kFinWaves];
+    __shared__ float2 s_pt[kFinWaves];
     __shared__ int s_last;
     __shared__ double s_part[kFinWaves][kRec];
     const int n_act = active_instances(p.n, p.n_dev);
@@ -512,54 +523,58 @@ __global__ __launch_bounds__(256) void k_vote_final(const VoteParams p) {
     for (int t = blockIdx.x; t < nr; t += gridDim.x) {
         const int4 rb = p.runs[t];
         const int inst = rb.x, run = rb.y, c_lo = rb.z;
-        const int32_t* pl = p.plan + (size_t)inst * kPlanI;
-        const int fg = pl[0], tn = pl[1], nrec = pl[6];
-        const bool thin = pl[2] != 0;
+        const int fg = rb.w & 0x7fffffff, nrec = (fg + p.run_entries - 1) / p.run_entries;
+        const bool thin = rb.w < 0;
         const int32_t* gpre = p.chunk_pre + (size_t)inst * (nch + 1);
-        // winner: every task of the instance finds the same one
+        // winner: every task of the instance finds the same one; its point travels with it (no dependent load afterwards)
         int wc = -1, wi = 0x7fffffff;
+        float wx = 0.0f, wy = 0.0f;
+        const float* hp = p.hyp + (size_t)inst * hn * 2;
         for (int h = threadIdx.x; h < hn; h += blockDim.x) {
             const int cv = p.counts[(size_t)inst * p.hnp + h];
-            if (cv > wc) { wc = cv; wi = h; }                            // ascending h: first maximum kept
+            const float2 g = *reinterpret_cast<const float2*>(hp + 2 * h);
+            if (cv > wc) { wc = cv; wi = h; wx = g.x; wy = g.y; }        // ascending h: first maximum kept
         }
 #pragma unroll
         for (int o = kWave / 2; o > 0; o >>= 1) {
             const int oc = __shfl_xor(wc, o, kWave), oi = __shfl_xor(wi, o, kWave);
-            if (oc > wc || (oc == wc && oi < wi)) { wc = oc; wi = oi; }
+            const float ox = __shfl_xor(wx, o, kWave), oy = __shfl_xor(wy, o, kWave);
+            if (oc > wc || (oc == wc && oi < wi)) { wc = oc; wi = oi; wx = ox; wy = oy; }
         }
         __syncthreads();                                               // LDS of the previous task is free
-        if (lane == 0) { s_red[wv] = wc; s_red[kFinWaves + wv] = wi; }
+        if (lane == 0) { s_red[wv] = wc; s_red[kFinWaves + wv] = wi; s_pt[wv] = make_float2(wx, wy); }
         if (p.lds_table)
             for (int c = threadIdx.x; c <= nch; c += blockDim.x) s_cpre[c] = gpre[c];
         __syncthreads();
         wc = s_red[0]; wi = s_red[kFinWaves];
-#pragma unroll
-        for (int i = 1; i < kFinWaves; ++i) {
-            const int oc = s_red[i], oi = s_red[kFinWaves + i];
-            if (oc > wc || (oc == wc && oi < wi)) { wc = oc; wi = oi; }
+        {
+            int best = 0;
+            for (int i = 1; i < kFinWaves; ++i) {
+                const int oc = s_red[i], oi = s_red[kFinWaves + i];
+                if (oc > wc || (oc == wc && oi < wi)) { wc = oc; wi = oi; best = i; }
+            }
+            wx = s_pt[best].x; wy = s_pt[best].y;
         }
         // no hypothesis with an inlier: all_win_pts stays (0,0) (:571-574) and the refinement votes for (0,0)
-        const float* hp = p.hyp + (size_t)inst * hn * 2;
-        float wx = 0.0f, wy = 0.0f;
-        if (wc > 0) { wx = hp[2 * wi]; wy = hp[2 * wi + 1]; } else { wi = -1; wc = 0; }
+        if (!(wc > 0)) { wi = -1; wc = 0; wx = 0.0f; wy = 0.0f; }
 
         FPC_STAMP(3, 1);
         const int32_t* cpre = p.lds_table ? s_cpre : gpre;
         const float4* L = p.list + (size_t)inst * p.ls;
-        const int r_end = min(fg, (run + 1) * kRunEntries);
+        const int r_end = min(fg, (run + 1) * p.run_entries);
         double v[kRec] = {0, 0, 0, 0, 0, 0};                            // inliers, a00, a01, a11, b0, b1
         int c = c_lo;                                                   // this lane's chunk cursor: its ranks only grow
-        for (int r0 = run * kRunEntries + threadIdx.x; r0 < r_end; r0 += 8 * 256) {
-            float4 q[8];
+        for (int r0 = run * p.run_entries + threadIdx.x; r0 < r_end; r0 += 4 * 64 * kFinWaves) {
+            float4 q[4];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {                               // eight independent loads per lane in flight
-                const int rk = r0 + j * 256;
+            for (int j = 0; j < 4; ++j) {                               // four independent loads per lane in flight
+                const int rk = r0 + j * 64 * kFinWaves;
                 q[j] = make_float4(0.f, 0.f, 0.f, 0.f);
                 if (rk < r_end) q[j] = L[rank_slot_from(cpre, c, rk)];
             }
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                bool valid = r0 + j * 256 < r_end;
+            for (int j = 0; j < 4; ++j) {
+                bool valid = r0 + j * 64 * kFinWaves < r_end;
                 if (valid && thin) valid = pixel_kept<KEEP>(q[j].x, q[j].y, p.W, p.HW, inst, fg, p.max_num, p.seed, p.keep);
                 if (valid && pair_is_inlier(q[j].x, q[j].y, q[j].z, q[j].w, sqrtf(q[j].z * q[j].z + q[j].w * q[j].w), wx, wy, p.thresh)) {
                     const double nx = (double)q[j].w, ny = -(double)q[j].z;      // normal = (dy, -dx) :584-586
@@ -576,9 +591,15 @@ __global__ __launch_bounds__(256) void k_vote_final(const VoteParams p) {
         }
         __syncthreads();
         FPC_STAMP(3, 3);
-        double tot[kRec];
+        double tot[kRec] = {0, 0, 0, 0, 0, 0};
+        if (wv == 0) {                                                  // wave 0 finishes the task
 #pragma unroll
-        for (int a = 0; a < kRec; ++a) tot[a] = s_part[0][a] + s_part[1][a] + s_part[2][a] + s_part[3][a];
+            for (int a = 0; a < kRec; ++a) {
+                tot[a] = s_part[0][a];
+#pragma unroll
+                for (int w = 1; w < kFinWaves; ++w) tot[a] += s_part[w][a];                 // fixed order
+            }
+        }
         if (nrec > 1) {                                                 // uniform
             if (threadIdx.x < kRec)
                 store_wt64(p.partial + ((size_t)inst * p.nrx + run) * kRec + threadIdx.x, __builtin_bit_cast(unsigned long long, tot[threadIdx.x]));
@@ -590,6 +611,7 @@ __global__ __launch_bounds__(256) void k_vote_final(const VoteParams p) {
             }
             __syncthreads();
             if (!s_last) continue;                                     // uniform
+            if (wv != 0) continue;                                     // wave 0 finishes
             // last arriver of the instance: the records in run order (independent sc1 loads)
             // lane = (record slot r8 = lane / 8, value a = lane % 8): eight records per sweep, then a fixed-order lane tree
             const int a = lane & 7, r8 = lane >> 3;
@@ -611,7 +633,7 @@ __global__ __launch_bounds__(256) void k_vote_final(const VoteParams p) {
             solve2_sym(tot[1], tot[2], tot[3], tot[4], tot[5], x0, x1);
             p.out_xy[inst * 2] = (float)x0;
             p.out_xy[inst * 2 + 1] = (float)x1;
-            if (p.out_tn) p.out_tn[inst] = tn;
+            if (p.out_tn) p.out_tn[inst] = p.plan[(size_t)inst * kPlanI + 1];
             if (p.out_win_idx) p.out_win_idx[inst] = wi;
             if (p.out_win_count) p.out_win_count[inst] = wc;
             if (p.out_inl) p.out_inl[inst] = (int)tot[0];
@@ -716,10 +738,10 @@ extern "C" int fpc_ransac_voting_v3(const float* mask, const float* vertex, int6
     FPC_TRACE("scan");
 
     // 2. per instance: prefix, origin, units and runs, hypotheses (+ their B fragments), zeroed count row and ticket
-    const dim3 plan_grid(std::min(n, 2048));
-    if (keep) hipLaunchKernelGGL((k_vote_plan<true, true>), plan_grid, dim3(1024), 2 * table_lds, s, p);
-    else if (idxs || out_tn) hipLaunchKernelGGL((k_vote_plan<true, false>), plan_grid, dim3(1024), 2 * table_lds, s, p);
-    else hipLaunchKernelGGL((k_vote_plan<false, false>), plan_grid, dim3(1024), 2 * table_lds, s, p);
+    const dim3 plan_grid(std::min(n, 2048), std::min(p.ntiles, 4)), plan_one(std::min(n, 2048), 1);
+    if (keep) hipLaunchKernelGGL((k_vote_plan<true, true>), plan_one, dim3(256), 2 * table_lds, s, p);
+    else if (idxs || out_tn) hipLaunchKernelGGL((k_vote_plan<true, false>), plan_one, dim3(256), 2 * table_lds, s, p);
+    else hipLaunchKernelGGL((k_vote_plan<false, false>), plan_grid, dim3(256), 2 * table_lds, s, p);
     FPC_TRACE("plan");
 
     // 3. exact inlier counts of every hypothesis.  One resident round of workgroups (four per CU); the kernel reads how
@@ -733,9 +755,9 @@ extern "C" int fpc_ransac_voting_v3(const float* mask, const float* vertex, int6
     FPC_TRACE("count");
 
     // 4. winner, its inliers, refinement: one task per run of chunks
-    const int fin_grid = (int)std::min<long long>(std::max<long long>((long long)n * p.nrx, 1), 2048);
-    if (keep) hipLaunchKernelGGL(k_vote_final<true>, dim3(fin_grid), dim3(256), table_lds, s, p);
-    else hipLaunchKernelGGL(k_vote_final<false>, dim3(fin_grid), dim3(256), table_lds, s, p);
+    const int fin_grid = (int)std::min<long long>(std::max<long long>((long long)n * p.nrx, 1), 512);
+    if (keep) hipLaunchKernelGGL(k_vote_final<true>, dim3(fin_grid), dim3(64 * kFinWaves), table_lds, s, p);
+    else hipLaunchKernelGGL(k_vote_final<false>, dim3(fin_grid), dim3(64 * kFinWaves), table_lds, s, p);
     FPC_TRACE("final");
 
     // diagnostics (never on the product path): copies of the hypotheses and of the count rows

@@ -8,13 +8,12 @@ namespace fpc {
 constexpr int kChunkPx = 4096;       // pixels per k_vote_scan task; a chunk owns list slots [c * 4096, c * 4096 + its count)
 constexpr int kChunkWords = 64;      // 64-pixel words per chunk
 constexpr int kUnitEntries = 512;    // foreground ranks per count unit (4 waves x 2 groups of 64): [512 u, 512 u + 512) of an instance
-constexpr int kRunEntries = 8192;    // foreground ranks per refinement run (k_vote_final task)
 constexpr int kHypTile = 32;         // hypotheses per MFMA tile
 constexpr int kMaxSliceTiles = 64;   // hypothesis tiles per k_vote_count task at most (LDS count rows)
 constexpr int kPlanI = 8;            // i32 per instance: fg, tn, thin, origin x, origin y, radius, runs, votes
 constexpr int kMaxHn = 65536;
 constexpr int kRec = 6;              // doubles per refinement record: inliers, a00, a01, a11, b0, b1
-constexpr int kBandQ = 192;          // queued undecided-pair records per wave (one step adds at most 64)
+constexpr int kBandQ = 128;          // queued undecided-pair records per wave and task (one step adds at most 64)
 constexpr float kNeverS = 1.0e30f;   // |s| of an entry that never votes
 
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
@@ -31,6 +30,7 @@ struct VoteParams {
     float* out_xy; int32_t* out_tn; int32_t* out_win_idx; int32_t* out_win_count; int32_t* out_inl; double* out_refine;
     // derived
     int nch, ntiles, hnp, nux, nrx, lds_table, want_tn, all_wild, task_target;
+    int run_entries;                  // foreground ranks per refinement run (k_vote_final task)
     size_t ls;                        // list slots per instance = nch * kChunkPx
     float kappa2, dkappa, efac;
     // workspace
@@ -49,8 +49,9 @@ struct VoteParams {
     int32_t* counts;      // [n, hnp]       exact inlier count of every hypothesis; zeroed by k_vote_plan
     double* partial;      // [n, nrx, kRec] k_vote_final per-run records
     float4* list;         // [n, ls]        {x, y, dx, dy} of the foreground pixels, compacted per chunk (k_vote_scan)
-    int4* units;          // [n * nux]      {instance | thin << 16 | (entries - 1) << 17, block u, chunk of rank 512 u, ox | oy << 16}
-    int4* runs;           // [n * nrx]      {instance, run r (= its record ordinal), chunk of rank 8192 r, -}
+    int4* units;          // [n * nux, 2]   {instance | thin << 16 | (entries - 1) << 17, block u, chunk c of rank 512 u, ox | oy << 16},
+                          //                {list slot of rank 512 u, ranks of the unit inside chunk c, fg, -}
+    int4* runs;           // [n * nrx]      {instance, run r (= its record ordinal), chunk of rank r * run_entries, fg | thin << 31}
     unsigned long long* stamps;   // [4, 32]  s_memrealtime (100 MHz) at the phases of workgroup 0 of each kernel: written only by a
                                   //          diagnostic build (-DFPC_STAMP_VOTE, tools_dev/vote_stamps.py); never read by a kernel
 };
@@ -66,6 +67,10 @@ struct Ws {
     size_t total;
 };
 
+// 8192: at B = 32 the 370 runs are one resident round of 512-thread workgroups (4096: two rounds, 38 us; whole instances:
+// the 35 000-pixel one alone takes 25 us; measured); a handful of instances are cut finer so that more CUs share them
+inline int run_entries_for(int n) { return n <= 16 ? 2048 : 8192; }
+
 inline Ws carve(void* base, int n, int H, int W, int hn) {
     Ws w;
     VoteParams& p = w.p;
@@ -74,7 +79,8 @@ inline Ws carve(void* base, int n, int H, int W, int hn) {
     p.ntiles = cdiv(hn, kHypTile);
     p.hnp = p.ntiles * kHypTile;
     p.nux = cdiv((int)HW, kUnitEntries);
-    p.nrx = cdiv((int)HW, kRunEntries);
+    p.run_entries = run_entries_for(n);
+    p.nrx = cdiv((int)HW, p.run_entries);
     p.ls = (size_t)p.nch * kChunkPx;
     char* b = (char*)base;
     size_t off = 0;
@@ -93,7 +99,7 @@ inline Ws carve(void* base, int n, int H, int W, int hn) {
     p.counts = (int32_t*)take(sizeof(int32_t) * (size_t)n * p.hnp);
     p.partial = (double*)take(sizeof(double) * (size_t)n * p.nrx * kRec);
     p.list = (float4*)take(sizeof(float4) * (size_t)n * p.ls);
-    p.units = (int4*)take(sizeof(int4) * (size_t)n * p.nux);
+    p.units = (int4*)take(sizeof(int4) * 2 * (size_t)n * p.nux);
     p.runs = (int4*)take(sizeof(int4) * (size_t)n * p.nrx);
     p.stamps = (unsigned long long*)take(sizeof(unsigned long long) * 4 * 32);
     w.total = off;

@@ -24,67 +24,64 @@ namespace fpc {
 //     measured worst over 2 M random pairs: 4.2e-7 M (tools_dev/mfma_vote_probe.hip).
 // dynamic LDS: [gps * 32] counts of the slice.
 
-// The parameter block for out-of-line helpers: read from the kernel-argument segment (constant address space: scalar
-// loads) through a pointer the kernel hands over, so no copy of the block is materialised for the call.
-// (__builtin_amdgcn_kernarg_segment_ptr() is only meaningful inside the kernel function itself.)
-typedef const VoteParams __attribute__((address_space(4)))* KParams;
-__device__ __forceinline__ KParams kernel_params() {
-#if defined(__HIP_DEVICE_COMPILE__)
-    return (KParams)__builtin_amdgcn_kernarg_segment_ptr();               // the kernels' ONLY argument, at offset 0
-#else
-    return nullptr;                                                       // host pass: never called
-#endif
-}
-
-struct UnitRef { int inst, u, c_lo, nvalid; bool thin; float fox, foy; };
-__device__ __forceinline__ UnitRef decode_unit(int4 ub) {
+struct UnitRef { int inst, u, c_lo, nvalid, slot0, fic, fg; bool thin; float fox, foy; };
+__device__ __forceinline__ UnitRef decode_unit(int4 a, int4 b) {
     UnitRef r;
-    r.inst = ub.x & 0xffff; r.thin = (ub.x >> 16) & 1; r.nvalid = ((ub.x >> 17) & 0x1ff) + 1;
-    r.u = ub.y; r.c_lo = ub.z; r.fox = (float)(ub.w & 0xffff); r.foy = (float)((unsigned)ub.w >> 16);
+    r.inst = a.x & 0xffff; r.thin = (a.x >> 16) & 1; r.nvalid = ((a.x >> 17) & 0x1ff) + 1;
+    r.u = a.y; r.c_lo = a.z; r.fox = (float)(a.w & 0xffff); r.foy = (float)((unsigned)a.w >> 16);
+    r.slot0 = b.x; r.fic = b.y; r.fg = b.z;
     return r;
 }
 
-// entry `ent` (0..511) of a unit
+// entry `ent` (0..511) of a unit: its first `fic` ranks sit in the unit's first chunk at consecutive slots
 __device__ __forceinline__ float4 unit_entry(const float4* __restrict__ list, size_t ls, const int32_t* __restrict__ chunk_pre,
                                              int nch, const UnitRef& u, int ent) {
-    int c = u.c_lo;
-    const int slot = rank_slot_from(chunk_pre + (size_t)u.inst * (nch + 1), c, u.u * kUnitEntries + ent);
+    int slot = u.slot0 + ent;
+    if (ent >= u.fic) {
+        int c = u.c_lo + 1;
+        slot = rank_slot_from(chunk_pre + (size_t)u.inst * (nch + 1), c, u.u * kUnitEntries + ent);
+    }
     return list[(size_t)u.inst * ls + slot];
 }
 
-// The pairs the filter could not decide, one record per (lane, hypothesis tile): {bits of row tiles 0 | 1 << 1 (group w),
-// the same of group w + 4, tile | lane << 16 | wave << 22, unit}.  A lane takes a record and walks its bits with the
-// reference's own arithmetic.
+__device__ __forceinline__ float lane_fetch(float v, int src_lane) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(src_lane << 2, __builtin_bit_cast(int, v)));
+}
+
+// The pairs the filter could not decide, one record per (lane, hypothesis tile) of THIS wave and THIS task:
+// {bits of row tiles 0 | 1 << 1 of group w, the same of group w + 4, tile, lane}.  A lane takes a record and walks its bits
+// with the reference's own arithmetic; the entry comes from the lane that holds it (ds_bpermute), the point from memory;
+// the inliers go to the slice's LDS counts.
 template <bool KEEP>
-__device__ __attribute__((noinline)) void band_flush(int nq, const int4* __restrict__ queue, KParams kp) {
-    const auto& p = *kp;
+__device__ __forceinline__ void band_flush(int nq, const int4* __restrict__ queue, float4 qa, float4 qb, const UnitRef& u, int wv,
+                                           int T0, int* __restrict__ s_cnt, const VoteParams& p) {
     const int lane = threadIdx.x & (kWave - 1), hn = p.hn;
     for (int base = 0; base < nq; base += kWave) {                           // uniform
-        if (base + lane >= nq) continue;
-        const int4 e = queue[base + lane];
-        const UnitRef u = decode_unit(p.units[e.w]);
-        const int T = e.z & 0xffff, src_lane = (e.z >> 16) & 63, src_wave = (e.z >> 22) & 3;
+        const bool on = base + lane < nq;
+        const int4 e = on ? queue[base + lane] : make_int4(0, 0, 0, 0);
+        const int T = e.z, src_lane = e.w;
         const int h = T * kHypTile + (src_lane & 31);
-        if (h >= hn) continue;
-        const float gx = p.hyp[((size_t)u.inst * hn + h) * 2], gy = p.hyp[((size_t)u.inst * hn + h) * 2 + 1];
-        const int fg = u.thin ? p.plan[(size_t)u.inst * kPlanI] : 0;
+        float gx = 0.f, gy = 0.f;
+        if (on && h < hn) { gx = p.hyp[((size_t)u.inst * hn + h) * 2]; gy = p.hyp[((size_t)u.inst * hn + h) * 2 + 1]; }
+        unsigned w0 = (on && h < hn) ? (unsigned)e.x : 0u, w1 = (on && h < hn) ? (unsigned)e.y : 0u;
         int add = 0;
-#pragma unroll
-        for (int half = 0; half < 2; ++half) {
-            unsigned w = half ? (unsigned)e.y : (unsigned)e.x;
-            while (w) {
-                const int b = __ffs((int)w) - 1;
-                w &= w - 1u;
-                const int i = 15 - (b >> 1);                               // register index: the last one shifted in sits lowest
-                const int row = (i & 3) + 8 * (i >> 2) + 4 * (src_lane >> 5);
-                const int ent = (src_wave + 4 * half) * kWave + (b & 1) * 32 + row;
-                if (ent >= u.nvalid) continue;
-                const float4 q = unit_entry(p.list, p.ls, p.chunk_pre, p.nch, u, ent);
-                if (u.thin && !pixel_kept<KEEP>(q.x, q.y, p.W, p.HW, u.inst, fg, p.max_num, p.seed, p.keep)) continue;
-                add += pair_is_inlier(q.x, q.y, q.z, q.w, sqrtf(q.z * q.z + q.w * q.w), gx, gy, p.thresh) ? 1 : 0;
-            }
+        while (__builtin_amdgcn_ballot_w64((w0 | w1) != 0u)) {              // uniform: every lane takes part in the fetches
+            const bool has = (w0 | w1) != 0u;
+            const int half = w0 ? 0 : 1;
+            const unsigned w = w0 ? w0 : w1;
+            const int b = has ? __ffs((int)w) - 1 : 0;
+            if (w0) w0 &= w0 - 1u; else w1 &= w1 - 1u;
+            const int i = 15 - (b >> 1);                                   // register index: the last one shifted in sits lowest
+            const int eg = (b & 1) * 32 + (i & 3) + 8 * (i >> 2) + 4 * (src_lane >> 5);   // entry inside its 64-entry group
+            const int src = has ? eg : lane;
+            const float ax = lane_fetch(qa.x, src), ay = lane_fetch(qa.y, src), az = lane_fetch(qa.z, src), aw = lane_fetch(qa.w, src);
+            const float bx = lane_fetch(qb.x, src), by = lane_fetch(qb.y, src), bz = lane_fetch(qb.z, src), bw = lane_fetch(qb.w, src);
+            const float qx = half ? bx : ax, qy = half ? by : ay, qz = half ? bz : az, qw = half ? bw : aw;
+            bool valid = has && (wv + 4 * half) * kWave + eg < u.nvalid;
+            if (u.thin && valid) valid = pixel_kept<KEEP>(qx, qy, p.W, p.HW, u.inst, u.fg, p.max_num, p.seed, p.keep);
+            if (valid && pair_is_inlier(qx, qy, qz, qw, sqrtf(qz * qz + qw * qw), gx, gy, p.thresh)) ++add;
         }
-        if (add) atomicAdd(p.counts + (size_t)u.inst * p.hnp + h, add);
+        if (add) atomicAdd(&s_cnt[(T - T0) * kHypTile + (src_lane & 31)], add);
     }
 }
 
@@ -141,42 +138,44 @@ __global__ __launch_bounds__(256, WAVES) void k_vote_count(const VoteParams p) {
     const int S0 = max(1, min(ntiles, p.task_target / max(nu, 1)));
     const int gps = min(kMaxSliceTiles, (ntiles + S0 - 1) / S0);
     const int S = (ntiles + gps - 1) / gps;
-    const long long total = (long long)nu * S;
-    const long long G = gridDim.x;
+    // task t = (unit t / S, slice t % S), t = blockIdx.x + k gridDim.x: unit and slice advance without a division per task
+    const int G = gridDim.x, Gu = G / S, Gs = G - Gu * S;
     int4* bq = s_bandq[wv];
-    int qn = 0;
-    long long t = blockIdx.x;
-    if (t >= total) return;                                                  // uniform
+    if ((long long)blockIdx.x >= (long long)nu * S) return;                  // uniform
+    auto advance = [&](int& uu, int& ss) { uu += Gu; ss += Gs; if (ss >= S) { ss -= S; ++uu; } };
     // software pipeline over this workgroup's tasks: unit records two tasks ahead, entries one task ahead
-    auto load_entries = [&](int4 ub, float4& qa, float4& qb) {
-        const UnitRef u = decode_unit(ub);
+    auto load_entries = [&](const UnitRef& u, float4& qa, float4& qb) {
         const int ea = wv * kWave + lane, eb = (wv + 4) * kWave + lane;
         qa = ea < u.nvalid ? unit_entry(p.list, p.ls, p.chunk_pre, p.nch, u, ea) : make_float4(0.f, 0.f, 0.f, 0.f);
         qb = eb < u.nvalid ? unit_entry(p.list, p.ls, p.chunk_pre, p.nch, u, eb) : make_float4(0.f, 0.f, 0.f, 0.f);
     };
-    int4 ub = p.units[t / S];
-    int4 ub1 = (t + G < total) ? p.units[(t + G) / S] : make_int4(0, 0, 0, 0);
+    const int4 zero4 = make_int4(0, 0, 0, 0);
+    int uidx = blockIdx.x / S, s = blockIdx.x - uidx * S;                    // this task
+    int u1 = uidx, s1 = s; advance(u1, s1);                                   // the next
+    int u2 = u1, s2 = s1; advance(u2, s2);                                    // the one after
+    int4 ua = p.units[2 * uidx], ub = p.units[2 * uidx + 1];
+    int4 ua1 = zero4, ub1 = zero4;
+    if (u1 < nu) { ua1 = p.units[2 * u1]; ub1 = p.units[2 * u1 + 1]; }
     float4 qa, qb;
-    load_entries(ub, qa, qb);
+    load_entries(decode_unit(ua, ub), qa, qb);
     FPC_STAMP(2, 1);
     for (;;) {
-        const bool more = t + G < total;
-        const int4 ub2 = (t + 2 * G < total) ? p.units[(t + 2 * G) / S] : make_int4(0, 0, 0, 0);
+        const bool more = u1 < nu;
+        int4 ua2 = zero4, ub2 = zero4;
+        if (u2 < nu) { ua2 = p.units[2 * u2]; ub2 = p.units[2 * u2 + 1]; }
         float4 qan = make_float4(0.f, 0.f, 0.f, 0.f), qbn = qan;
-        if (more) load_entries(ub1, qan, qbn);
-        const int uidx = (int)(t / S), s = (int)(t - (long long)uidx * S);
-        const UnitRef u = decode_unit(ub);
+        if (more) load_entries(decode_unit(ua1, ub1), qan, qbn);
+        const UnitRef u = decode_unit(ua, ub);
         const int inst = u.inst;
         const int T0 = s * gps, T1 = min(ntiles, T0 + gps);
         // this wave's groups: w and w + 4 of the unit's eight
         const int ng = (wv * kWave < u.nvalid ? 1 : 0) + ((wv + 4) * kWave < u.nvalid ? 1 : 0);
         GroupFrags Gf[2];
         {
-            const int fg = u.thin ? p.plan[(size_t)inst * kPlanI] : 0;
             bool va = wv * kWave + lane < u.nvalid, vb = (wv + 4) * kWave + lane < u.nvalid;
             if (u.thin) {
-                va = va && pixel_kept<KEEP>(qa.x, qa.y, p.W, p.HW, inst, fg, p.max_num, p.seed, p.keep);
-                vb = vb && pixel_kept<KEEP>(qb.x, qb.y, p.W, p.HW, inst, fg, p.max_num, p.seed, p.keep);
+                va = va && pixel_kept<KEEP>(qa.x, qa.y, p.W, p.HW, inst, u.fg, p.max_num, p.seed, p.keep);
+                vb = vb && pixel_kept<KEEP>(qb.x, qb.y, p.W, p.HW, inst, u.fg, p.max_num, p.seed, p.keep);
             }
             build_group(Gf[0], va, qa, u.fox, u.foy, p.kappa2);
             build_group(Gf[1], vb, qb, u.fox, u.foy, p.kappa2);
@@ -187,6 +186,7 @@ __global__ __launch_bounds__(256, WAVES) void k_vote_count(const VoteParams p) {
         if (ng > 0) {                                                       // uniform per wave
             const u32x4* Bp = p.hypB + ((size_t)inst * ntiles + T0) * kWave + lane;
             u32x4 Bn = *Bp;
+            int qn = 0;
             for (int T = T0; T < T1; ++T) {
                 const bf16x8 B = __builtin_bit_cast(bf16x8, Bn);
                 if (T + 1 < T1) Bn = Bp[(size_t)(T + 1 - T0) * kWave];
@@ -210,15 +210,16 @@ __global__ __launch_bounds__(256, WAVES) void k_vote_count(const VoteParams p) {
                 if (mk) {                                                   // uniform
                     const int add = __popcll(mk);
                     if (qn + add > kBandQ) {
-                        band_flush<KEEP>(qn, bq, kernel_params());
+                        band_flush<KEEP>(qn, bq, qa, qb, u, wv, T0, s_cnt, p);
                         qn = 0;
                     }
                     if (has)
                         bq[qn + __builtin_amdgcn_mbcnt_hi((unsigned)(mk >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mk, 0))] =
-                            make_int4((int)w01, (int)w23, T | (lane << 16) | (wv << 22), uidx);
+                            make_int4((int)w01, (int)w23, T, lane);
                     qn += add;
                 }
             }
+            if (qn) band_flush<KEEP>(qn, bq, qa, qb, u, wv, T0, s_cnt, p);
         }
         FPC_STAMP(2, 3);
         __syncthreads();
@@ -230,11 +231,10 @@ __global__ __launch_bounds__(256, WAVES) void k_vote_count(const VoteParams p) {
         }
         __syncthreads();
         if (!more) break;
-        t += G; ub = ub1; ub1 = ub2; qa = qan; qb = qbn;
+        uidx = u1; s = s1; u1 = u2; s1 = s2; advance(u2, s2);
+        ua = ua1; ub = ub1; ua1 = ua2; ub1 = ub2; qa = qan; qb = qbn;
     }
     FPC_STAMP(2, 5);
-    if (qn) band_flush<KEEP>(qn, bq, kernel_params());
-    FPC_STAMP(2, 6);
 }
 
 void launch_vote_count(const VoteParams& p, int grid, size_t lds_bytes, hipStream_t s) {
