@@ -29,6 +29,7 @@ class NetEngine:
             self._ws = torch.empty(nbytes, dtype=torch.uint8, device=device)
             assert self._ws.data_ptr() % 256 == 0
         self.reloads = 0
+        self.generation = 0          # the owner's count of unversioned writes when this plan was last bound (pose_regressor.py)
         self.bind(model)
         if split_precision:
             nat.check(L.fpc_net_set_split_precision(h, 1), "fpc_net_set_split_precision")
@@ -74,12 +75,7 @@ class NetEngine:
     def stale(self):
         """True when a bound parameter was rewritten or replaced since it was packed (packed conv weights and folded
         BatchNorm are a snapshot; biases / GroupNorm / head weights are read in place)."""
-        return self._stamp is None or self._fingerprint() != self._stamp
-
-    def mark_stale(self):
-        """Force a repack at the next forward: for writers PyTorch does not version (kernels that update parameters
-        through raw pointers, collectives into a flat buffer the parameters are views of)."""
-        self._stamp = None
+        return self._fingerprint() != self._stamp
 
     def conv_plans(self):
         out = []

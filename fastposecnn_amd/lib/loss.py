@@ -29,8 +29,10 @@ class _MaskLossFn(torch.autograd.Function):
     objects stay independent autograd nodes (csrc/train.hip: k_mask_losses)."""
 
     @staticmethod
-    def forward(ctx, logits, target, sums, which, ignore_cce, alpha, gamma):
-        ctx.save_for_backward(logits, target, sums)
+    def forward(ctx, logits, x, target, sums, which, ignore_cce, alpha, gamma):
+        # x: the contiguous NCHW copy the forward sums were taken from (== logits when those are contiguous): the kernel
+        # indexes plain NCHW, so the backward reads x, never a strided / channels_last `logits`
+        ctx.save_for_backward(x, target, sums)
         ctx.args = (int(which), int(ignore_cce), float(alpha), float(gamma))
         return (sums[2 * which] / sums[2 * which + 1]).float()
 
@@ -41,11 +43,11 @@ class _MaskLossFn(torch.autograd.Function):
         which, ignore_cce, alpha, gamma = ctx.args
         w3 = torch.zeros(3, dtype=torch.float32, device=x.device)
         w3[which] = (g.double() / sums[2 * which + 1]).float()
-        grad = torch.empty_like(x)
+        grad = torch.empty_like(x, memory_format=torch.contiguous_format)
         with torch.cuda.device(x.device):
             nat.check(nat.lib().fpc_mask_losses(nat.ptr(x), nat.ptr(t), x.shape[0], x.shape[1], x[0, 0].numel(), -100, ignore_cce,
                                                 alpha, gamma, None, nat.ptr(w3), nat.ptr(grad), nat.stream()), "fpc_mask_losses")
-        return grad, None, None, None, None, None, None
+        return grad, None, None, None, None, None, None, None
 
 
 def _fused_mask_loss(which, logits, target, ignore_cce=-1, alpha=0.5, gamma=2):
@@ -65,12 +67,14 @@ def _fused_mask_loss(which, logits, target, ignore_cce=-1, alpha=0.5, gamma=2):
         x = logits.detach()
         x = x if x.is_contiguous() else x.contiguous()
         t = target.to(torch.int64).contiguous()
+        # (a target outside [0, C) other than the ignore indices contributes nothing here, where torch's own losses raise:
+        # checking would cost a host synchronisation per training step; F/tools/dataset.py only produces class ids)
         sums = torch.zeros(6, dtype=torch.float64, device=x.device)
         with torch.cuda.device(x.device):
             nat.check(nat.lib().fpc_mask_losses(nat.ptr(x), nat.ptr(t), x.shape[0], x.shape[1], x[0, 0].numel(), -100, key[0], key[1],
                                                 key[2], nat.ptr(sums), None, None, nat.stream()), "fpc_mask_losses")
         logits._fpc_mask_losses = (target, key, logits._version, (x, t, sums))
-    return _MaskLossFn.apply(logits, t, sums, which, *key)
+    return _MaskLossFn.apply(logits, x, t, sums, which, *key)
 
 
 class CE(_Loss):

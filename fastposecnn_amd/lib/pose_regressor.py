@@ -179,6 +179,7 @@ class PoseRegressor(Model, torch.nn.Module):
         torch.nn.Module.__init__(self)
         self._engines = {}
         self._fused = None
+        self._weights_gen = [0]         # shared (by reference) with copy.copy()'d instances: see note_unversioned_write
         self.HPARAM = HPARAM
         self.classes = classes  # includes background
         self.intrinsics = torch.from_numpy(np.asarray(HPARAM.NUMPY_INTRINSICS)).float()
@@ -249,27 +250,26 @@ class PoseRegressor(Model, torch.nn.Module):
                             tune_mode=int(getattr(self.HPARAM, 'ENGINE_TUNE_MODE', 0)),
                             graph=bool(getattr(self.HPARAM, 'ENGINE_GRAPH', True)),
                             split_precision=bool(getattr(self.HPARAM, 'ENGINE_SPLIT_PRECISION', False)))
+            eng.generation = self._weights_gen[0]
             self._engines[key] = eng
-        elif eng.stale():
+        elif eng.stale() or eng.generation != self._weights_gen[0]:
             # a parameter changed since the plan packed it (load_state_dict on the model or a sub-module, an optimizer
             # or EMA step, p.copy_()): repack; the tuned tilings and the workspace stay.  Checked per forward, by every
             # FrameStreamer copy for its own plans; train()/eval() alone no longer costs a re-tune.
             eng.bind(self)
+            eng.generation = self._weights_gen[0]
         return eng
 
     def _drop_engines(self):
         self._engines = {}
         self._fused = None
 
-    def train(self, mode: bool = True):
-        # Leaving training: whatever updated the weights may have written them through raw pointers (the native
-        # Lookahead(RAdam) kernel, an all-gather into the flat buffer the parameters are views of) and BatchNorm's
-        # running statistics moved: tensor versions do not show either.  The plans repack at their next forward
-        # (bind() keeps the tuned tilings and the workspace: no re-tune).
-        if self.training and not mode:
-            for eng in self._engines.values():
-                eng.mark_stale()
-        return super().train(mode)
+    def note_unversioned_write(self):
+        """Something rewrote parameters or buffers without PyTorch's version counters seeing it (BatchNorm's running
+        statistics in a training-mode forward, a kernel writing through raw pointers): every native plan bound to these
+        tensors - this module's and its FrameStreamer copies', which share the counter - repacks at its next forward
+        (bind() keeps the tuned tilings and the workspace: no re-tune)."""
+        self._weights_gen[0] += 1
 
     def _apply(self, fn, *args, **kwargs):
         # .to() / .cuda() / .float(): the parameters become new tensors, possibly on another device
@@ -283,6 +283,8 @@ class PoseRegressor(Model, torch.nn.Module):
             logits, cat = eng.forward(x)
             self._fused = (logits, cat)
             return logits
+        if self.training:
+            self.note_unversioned_write()   # BatchNorm moves its running statistics in place, unversioned
         features = self.encoder(x)
         mask_logits = self.segmentation_head(self.mask_decoder(*features))
         quat_logits = self.rotation_head(self.rotation_decoder(*features))

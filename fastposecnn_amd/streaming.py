@@ -89,10 +89,15 @@ class FrameStreamer:
         the caller's current stream."""
         k = self._n % len(self.models)
         self._n += 1
+        # the frame stream always waits for everything queued so far on the caller's stream: that is what collect()'s
+        # ownership rule rests on (readers of earlier outputs finish before a later frame can reuse their blocks)
+        caller_done = torch.cuda.Event()
+        caller_done.record(torch.cuda.current_stream(self.device))
         x_ready = ready
         if x_ready is None:
-            x_ready = torch.cuda.Event()
-            x_ready.record(torch.cuda.current_stream(self.device))
+            x_ready = caller_done
+        else:
+            self.net_streams[k].wait_event(caller_done)
         seed = int(torch.randint(0, 2 ** 62, (1,)).item())    # the vote's sampler seed: drawn here, in submission order
         key = (k, tuple(x.shape))
         if key not in self._warm:

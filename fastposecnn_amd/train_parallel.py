@@ -37,6 +37,7 @@ class ShardedLookaheadRAdam:
         self.clip_norm = clip_norm
         self.step_count = 0
         self.step_fn = step_fn
+        self._model = model
         params = [p for p in model.parameters() if p.requires_grad]
         if not params:
             raise ValueError("no trainable parameters")
@@ -201,6 +202,9 @@ class ShardedLookaheadRAdam:
         # the kernel and the all-gather wrote the parameters through raw pointers / the flat buffer: tell autograd's
         # version counters, which is what NetEngine.stale() (and torch's own saved-tensor checks) look at
         torch.autograd.graph.increment_version([p for b in self.buckets for p in b["params"]])
+        note = getattr(self._model, "note_unversioned_write", None)
+        if note is not None:
+            note()
         return norm
 
     def grad_norm_and_flag(self):

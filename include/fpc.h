@@ -214,7 +214,8 @@ int fpc_mask_losses(const float* logits, const int64_t* target, int B, int C, in
 /* out2 f64 [2] (caller zeroes): [0] += sum g^2, [1] += 1 when a non-finite element was seen.  g 16-byte aligned. */
 int fpc_grad_sumsq(const float* g, size_t n, double* out2, fpc_stream_t stream);
 /* One Lookahead(RAdam) step on a flat f32 shard (p, g, m, v, slow: n elements each; step counts from 1).
- * ctl (device f32[2] or NULL): [0] multiplies every gradient (clip coefficient / world size), [1] != 0 skips the step. */
+ * ctl (device f32[2] or NULL): [0] multiplies every gradient (clip coefficient / world size); [1] != 0 (the inf / NaN guard):
+ * the step runs with a ZERO gradient, as the reference's zero_grad() + optimizer.step() does. */
 int fpc_lookahead_radam_step(float* p, const float* g, float* m, float* v, float* slow, size_t n, float lr, float beta1,
                              float beta2, float eps, float weight_decay, int64_t step, int la_k, float la_alpha,
                              const float* ctl, fpc_stream_t stream);

@@ -289,6 +289,42 @@ def test_engine_invalidation(lib, dev):
     assert not m2._engines
 
 
+def test_engine_follows_training_steps(lib, dev):
+    """eval (plan built) -> training steps with the sharded native optimiser -> eval: the optimiser kernel writes the
+    parameters through raw pointers and a training-mode forward moves BatchNorm's running statistics in place, neither
+    of which PyTorch versions; the plan (and a FrameStreamer copy's) must still serve the NEW weights."""
+    from fastposecnn_amd import synth
+    from fastposecnn_amd.streaming import FrameStreamer
+    from fastposecnn_amd.train_parallel import ShardedLookaheadRAdam
+    m, hp = _model(lib, dev, "resnet18")
+    m = m.to(dev)
+    x = synth.make_image(1, 64, 64)[None].to(dev)
+    with torch.no_grad():
+        before = m(x)["logits"]["mask"].clone()
+    eng = next(iter(m._engines.values()))
+    st = FrameStreamer(m, net_streams=2)
+    for _ in range(2):
+        st.collect(st.submit(x))
+    m.train()
+    opt = ShardedLookaheadRAdam(m, lr=1e-2, weight_decay=0.0)
+    for step in range(3):
+        opt.zero_grad()
+        out = m.pure_model_forward(x)
+        sum(v.square().mean() for v in out.values()).backward()
+        opt.step()
+    m.eval()
+    with torch.no_grad():
+        after = m(x)["logits"]["mask"].clone()
+        ref = _torch_path(m, x)["mask"]
+        outs = [st.collect(st.submit(x))["logits"]["mask"] for _ in range(2)]
+    assert next(iter(m._engines.values())) is eng and eng.reloads >= 2            # repacked, not rebuilt
+    assert (after - before).abs().max().item() > 1e-3                             # the steps changed the output at all
+    tol = 2e-4 * max(1.0, ref.abs().max().item())
+    assert (after - ref).abs().max().item() <= tol
+    for o in outs:
+        assert (o - ref).abs().max().item() <= tol
+
+
 @pytest.mark.parametrize("kw", [dict(), dict(net_streams=2, post_inline=False)], ids=["4-streams-inline", "2-streams+post-stream"])
 def test_frame_streamer_matches_forward(lib, dev, kw):
     """Three frames in flight on the streaming runtime give, frame by frame, what forward() gives."""

@@ -214,11 +214,16 @@ def test_lookahead_radam_kernel():
     nat.check(L.fpc_lookahead_radam_step(nat.ptr(p2), nat.ptr(gh), nat.ptr(z[3]), nat.ptr(z[4]), nat.ptr(z[5]), n, 1e-3, 0.9, 0.999,
                                          1e-8, 0.0, 1, 5, 0.5, None, nat.stream()), "radam")
     torch.testing.assert_close(p1, p2)
+    # the guard (ctl[1] != 0): the step runs with a ZERO gradient, as the reference's zero_grad() + optimizer.step() does
+    # (F/lib/pose_regressor.py:341-415) - the gradient it is given holds inf / NaN and must not leak through a product
     ctl[1] = 1.0
-    before = p1.clone()
-    nat.check(L.fpc_lookahead_radam_step(nat.ptr(p1), nat.ptr(gd), nat.ptr(z[0]), nat.ptr(z[1]), nat.ptr(z[2]), n, 1e-3, 0.9, 0.999,
-                                         1e-8, 0.0, 2, 5, 0.5, nat.ptr(ctl), nat.stream()), "radam")
-    assert torch.equal(p1, before)
+    bad = gd.clone(); bad[::7] = float("inf"); bad[3::11] = float("nan")
+    zero = torch.zeros_like(gd)
+    nat.check(L.fpc_lookahead_radam_step(nat.ptr(p1), nat.ptr(bad), nat.ptr(z[0]), nat.ptr(z[1]), nat.ptr(z[2]), n, 1e-3, 0.9, 0.999,
+                                         1e-8, 3e-4, 2, 5, 0.5, nat.ptr(ctl), nat.stream()), "radam")
+    nat.check(L.fpc_lookahead_radam_step(nat.ptr(p2), nat.ptr(zero), nat.ptr(z[3]), nat.ptr(z[4]), nat.ptr(z[5]), n, 1e-3, 0.9, 0.999,
+                                         1e-8, 3e-4, 2, 5, 0.5, None, nat.stream()), "radam")
+    assert torch.isfinite(p1).all() and torch.equal(p1, p2) and torch.equal(z[0], z[3]) and torch.equal(z[1], z[4])
 
 
 def test_grad_sumsq_kernel():

@@ -17,9 +17,7 @@ def _tiny_model():
 
 def _step_fn(p, g, m, v, slow, step, ctl, hp):
     """RAdam + Lookahead (published algorithms) on one shard, honouring ctl = [gradient scale, skip]."""
-    if float(ctl[1]) != 0:
-        return
-    g = g * ctl[0]
+    g = torch.zeros_like(g) if float(ctl[1]) != 0 else g * ctl[0]     # the guard: step with a zero gradient
     b1, b2 = hp["beta1"], hp["beta2"]
     v.mul_(b2).add_((1 - b2) * g * g)
     m.mul_(b1).add_((1 - b1) * g)
@@ -94,18 +92,99 @@ def test_sharded_step_matches_single_process_gloo_world2():
     assert res[0][4] * 2 <= opt1.state_bytes() + 3 * 4 * 8 * len(opt1.buckets)    # optimiser state is sharded
 
 
-def test_guard_skips_non_finite_step_and_views_stay_attached():
+class _TwoHeads(torch.nn.Module):
+    """A trunk and two heads: a rank whose loss uses only head a produces no gradient for head b at all, like a rank of
+    the real model with no matched instance (total_loss skips the NaN matched losses)."""
+
+    def __init__(self):
+        super().__init__()
+        torch.manual_seed(6)
+        self.trunk = torch.nn.Conv2d(3, 8, 3, padding=1)
+        self.a = torch.nn.Conv2d(8, 5, 1)
+        self.b = torch.nn.Conv2d(8, 5, 1)
+
+    def forward(self, x):
+        f = torch.relu(self.trunk(x))
+        return self.a(f), self.b(f)
+
+
+def _train_heads(world, rank, steps):
     from fastposecnn_amd.train_parallel import ShardedLookaheadRAdam
-    model = _tiny_model()
-    opt = ShardedLookaheadRAdam(model, step_fn=_step_fn, lr=1e-2)
-    before = torch.cat([p.detach().reshape(-1) for p in model.parameters()]).clone()
-    opt.zero_grad()
-    x, y = _data(0, 0)
-    torch.nn.functional.cross_entropy(model(x), y).backward()
-    next(model.parameters()).grad.view(-1)[0] = float("inf")
-    opt.step()
-    after = torch.cat([p.detach().reshape(-1) for p in model.parameters()])
-    assert torch.equal(before, after) and int(opt.skipped) == 1     # F/lib/pose_regressor.py:341-415: the step is dropped
+    model = _TwoHeads()
+    opt = ShardedLookaheadRAdam(model, step_fn=_step_fn, lr=1e-2, weight_decay=0.0, clip_norm=0.0, bucket_mb=0.0001)
+    ce = torch.nn.functional.cross_entropy
+    for s in range(steps):
+        opt.zero_grad()
+        if world == 1:       # mean of: rank 0 = both heads, rank 1 = head a only
+            (x0, y0), (x1, y1) = _data(0, s), _data(1, s)
+            a0, b0 = model(x0); a1, _ = model(x1)
+            loss = (ce(a0, y0) + ce(b0, y0) + ce(a1, y1)) / 2
+        else:
+            x, y = _data(rank, s)
+            a, b = model(x)
+            loss = ce(a, y) + ce(b, y) if rank == 0 else ce(a, y)
+        loss.backward()
+        opt.step()
+    return torch.cat([p.detach().reshape(-1) for p in model.parameters()]), len(opt.buckets)
+
+
+def _worker_heads(rank, world, port, q):
+    import torch.distributed as dist
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    flat, nb = _train_heads(world, rank, 3)
+    q.put((rank, flat.tolist(), nb))
+    dist.destroy_process_group()
+
+
+def test_buckets_reduce_in_one_order_when_a_rank_has_no_gradient_for_a_branch():
+    """Collectives pair up by call order: rank 1 never completes head b's buckets during backward, so a launch-on-
+    completion policy would issue them in another order than rank 0 does (hang or mismatched sizes)."""
+    import torch.multiprocessing as mp
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker_heads, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=180) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    want, _ = _train_heads(1, 0, 3)
+    r0, r1 = torch.tensor(res[0][1]), torch.tensor(res[1][1])
+    assert torch.equal(r0, r1) and res[0][2] >= 3      # head b, head a, trunk: head b's bucket comes first and never completes on rank 1
+    torch.testing.assert_close(r0, want, rtol=1e-5, atol=1e-6)
+
+
+def test_guard_steps_with_zero_gradient_and_views_stay_attached():
+    """F/lib/pose_regressor.py:341-415: on a non-finite gradient the reference clears the gradients and lets the
+    optimiser step run (weight decay, moment decay, Lookahead's counters).  The guarded step must equal a step with a
+    zero gradient - also across the Lookahead synchronisation that follows (a dropped step 1 used to leave the slow
+    weights at zero and halve every parameter at the next sync)."""
+    from fastposecnn_amd.train_parallel import ShardedLookaheadRAdam
+
+    def run(poison):
+        model = _tiny_model()
+        opt = ShardedLookaheadRAdam(model, step_fn=_step_fn, lr=1e-2, la_k=2)
+        for s in range(4):
+            opt.zero_grad()
+            x, y = _data(0, s)
+            torch.nn.functional.cross_entropy(model(x), y).backward()
+            if s == 0:
+                if poison:
+                    next(model.parameters()).grad.view(-1)[0] = float("inf")
+                else:
+                    opt.flat_g.zero_()
+            opt.step()
+        return torch.cat([p.detach().reshape(-1) for p in model.parameters()]).clone(), opt, model
+
+    start = torch.cat([p.detach().reshape(-1) for p in _tiny_model().parameters()])
+    got, opt, model = run(True)
+    want, _, _ = run(False)
+    torch.testing.assert_close(got, want, rtol=1e-6, atol=1e-7)
+    assert int(opt.skipped) == 1 and (got - start).abs().max() < 0.2 * start.abs().max()      # nobody was halved
     # parameters and gradients are views of the flat buffers
     for p in model.parameters():
         assert opt.flat_p.data_ptr() <= p.data_ptr() < opt.flat_p.data_ptr() + 4 * opt.total
