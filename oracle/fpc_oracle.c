@@ -40,10 +40,17 @@
 #ifdef _OPENMP
 #include <omp.h>
 #endif
-/* Threads used by the parallel loops (bench.py's cpu_baseline): n <= 0 = all cores.  Returns the count in effect. */
+/* Threads used by the parallel loops (bench.py's cpu_baseline): n <= 0 = the cores this process may use, capped at
+ * FPCO_MAX_THREADS (default 16: a GPU box gives one GPU's job 16 of its 256 logical CPUs, and 256 threads on that share
+ * ran the vote 3.7x SLOWER than one).  Returns the count in effect. */
 int fpco_set_threads(int n) {
 #ifdef _OPENMP
-    if (n <= 0) n = omp_get_num_procs();
+    if (n <= 0) {
+        const char* cap = getenv("FPCO_MAX_THREADS");
+        int lim = cap ? atoi(cap) : 16;
+        n = omp_get_num_procs();
+        if (lim > 0 && n > lim) n = lim;
+    }
     omp_set_num_threads(n);
     return n;
 #else
@@ -257,7 +264,7 @@ int fpco_ransac_voting_v3(const float* mask, const float* vertex,
         /* the hn x tn decisions are independent: OpenMP over the hypotheses when the library is built with it
          * (bench.py's all-cores baseline; fpco_set_threads(1) = the scalar port); the arg-max stays sequential */
 #ifdef _OPENMP
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(dynamic, 8)
 #endif
         for (int hi = 0; hi < hn; ++hi) {
             int cnt = 0;
