@@ -55,8 +55,6 @@ if REPO not in sys.path:
 HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured float4 copy)
 MFMA_F32_PEAK_TFLOPS = 157.3    # MI355X_MICROARCH.md: f32-input MFMA = f32 vector peak (155 measured)
 VALU_PEAK_WAVE_INSTR_PER_S = 1024 * 2.4e9 / 2      # 1024 SIMD-32 units, a wave64 instruction issues over 2 cycles (the guide)
-VALU_MEASURED_F32_PER_S = 1024 * 2.4e9 / 4         # what plain f32 VALU streams sustained here: 4 cycles per wave64 instruction
-                                                   # at 5 waves/SIMD (tools_dev/vote_step_bench.hip; DESIGN.md, k_vote_count)
 H, W = 480, 640
 
 
@@ -71,6 +69,9 @@ def parse(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-config3", action="store_true", help="skip the ResNet34 batch-32 section (configs[2])")
     ap.add_argument("--no-hn128", action="store_true", help="skip the hn=128 / 32-frame vote roofline")
+    ap.add_argument("--no-train-line", action="store_true", help="skip the `train` object (configs[4] at B=8 on this GPU, 1-GPU runs only)")
+    ap.add_argument("--min-seconds", type=float, default=0.5, help="the K-step timed region is repeated until this much time is covered; `value` is the median repeat")
+    ap.add_argument("--gather-every", type=int, default=0, help="frames per pose all-gather on the side stream (0 = frames in flight)")
     ap.add_argument("--vote-only", action="store_true", help="time only the post-network stages (profiling aid)")
     ap.add_argument("--tune-mode", type=int, default=0, help="conv autotune objective: 0 latency, 1 latency x sqrt(chip share)")
     ap.add_argument("--net-streams", type=int, default=4, help="frame streams: native plans on their own HIP streams that take consecutive frames")
@@ -148,10 +149,12 @@ def cpu_baseline(model_cpu, image, cat_cpu, hn, inv_k, encoder):
         post_t[label] = (used, ts)
     orc.set_threads(1)
     t_net, t_post1, t_postn = median(net), median(post_t["1"][1]), median(post_t["all"][1])
-    return {"value": round(1.0 / (t_net + t_postn), 4), "unit": "img/s", "cores": max(threads, post_t["all"][0]), "kind": "port",
+    t_post, post_threads = (t_postn, post_t["all"][0]) if t_postn <= t_post1 else (t_post1, 1)      # the better of the two: a baseline is the host's best
+    return {"value": round(1.0 / (t_net + t_post), 4), "unit": "img/s", "cores": max(threads, post_threads), "kind": "port",
             "sample": f"1 frame x 3 samples (medians): torch-CPU {encoder}-FPN forward + class compression on {threads} threads "
-                      f"({t_net * 1e3:.0f} ms) + oracle/fpc_oracle.c aggregation, hn={hn} voting and RT on {post_t['all'][0]} threads "
-                      f"({t_postn * 1e3:.0f} ms; 1 thread: {t_post1 * 1e3:.0f} ms); host has {os.cpu_count()} logical CPUs",
+                      f"({t_net * 1e3:.0f} ms) + oracle/fpc_oracle.c aggregation, hn={hn} voting and RT on {post_threads} thread(s) "
+                      f"({t_post * 1e3:.0f} ms; 1 thread {t_post1 * 1e3:.0f} ms, {post_t['all'][0]} threads {t_postn * 1e3:.0f} ms); host has "
+                      f"{os.cpu_count()} logical CPUs, the oracle's OpenMP loops are capped at FPCO_MAX_THREADS (16: the job's CPU share)",
             "net_ms": [round(t * 1e3, 1) for t in net], "post_ms_1_thread": [round(t * 1e3, 1) for t in post_t["1"][1]],
             "post_ms_all_threads": [round(t * 1e3, 1) for t in post_t["all"][1]],
             "value_1_thread_post": round(1.0 / (t_net + t_post1), 4)}
@@ -182,6 +185,42 @@ def vote_roofline(model_gpu, cat, n_inst, reps, label, calls=10):
             "traffic": None, "kernel": "fpc_ransac_voting_v3 launch sequence (k_vote_scan, k_vote_plan, k_vote_count, k_vote_final)",
             "workload": label, "algorithmic_bytes_per_launch": alg, "launch_ms": round(t * 1e3, 4),
             "timing": f"HIP events around {calls} back-to-back calls on the launch stream / {calls}, median of {reps}"}
+
+
+def post_network_rates(model_gpu, cat1, n1, cat32, n32, reps=15, calls=6):
+    """Connected components + aggregation (the post-network stages in front of the vote) at B = 1 and B = 32, as a deferred
+    enqueue (instance count kept on the device): HIP events around `calls` back-to-back enqueues, median of `reps`.
+    Algorithmic bytes: CC reads the i64 mask (8 H W) and writes i32 labels (4 H W) per frame; aggregation reads labels + 9
+    categorical planes (40 H W per frame) and writes instance masks + xy fields (12 H W per instance)."""
+    import torch
+    layer = model_gpu.aggregation_layer
+    out = {}
+    for tag, cat, n_inst in (("b1", cat1, n1), ("b32", cat32, n32)):
+        B = cat["mask"].shape[0]
+        cm = cat["mask"].to(torch.int64).contiguous()
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+        t_cc, t_agg = [], []
+        with torch.no_grad():
+            for _ in range(reps):
+                ev[0].record()
+                for _ in range(calls):
+                    labels, n_dev = layer.batchwise_break_segmentation_mask(cm, return_device_count=True)
+                ev[1].record()
+                for _ in range(calls):
+                    layer._aggregate(cat, cm, labels, n_inst, n_dev)
+                ev[2].record()
+                ev[2].synchronize()
+                t_cc.append(ev[0].elapsed_time(ev[1]) / calls)
+                t_agg.append(ev[1].elapsed_time(ev[2]) / calls)
+        cc_s, agg_s = median(t_cc) * 1e-3, median(t_agg) * 1e-3
+        cc_b, agg_b = B * 12 * H * W, B * 40 * H * W + n_inst * 12 * H * W
+        out[tag] = {"frames": B, "instances": n_inst,
+                    "cc": {"us": round(cc_s * 1e6, 2), "bytes": cc_b, "GBps": round(cc_b / cc_s / 1e9, 1), "frac": round(cc_b / cc_s / 1e9 / HBM_PEAK_GBPS, 4)},
+                    "aggregate": {"us": round(agg_s * 1e6, 2), "bytes": agg_b, "GBps": round(agg_b / agg_s / 1e9, 1),
+                                  "frac": round(agg_b / agg_s / 1e9 / HBM_PEAK_GBPS, 4)},
+                    "us": round((cc_s + agg_s) * 1e6, 2)}
+    out["timing"] = f"HIP events around {calls} back-to-back enqueues / {calls}, median of {reps}; fractions of the 8 TB/s HBM peak"
+    return out
 
 
 def measure_copy_ceiling(dev):
@@ -231,12 +270,13 @@ def run_inference(args, encoder, Bq, hn, steps, warmup, world, rank, dev, want_b
     s_net = streamer.net_streams[0]
     depth = 0 if args.no_pipeline else len(streamer.models)
     pending = []
-    gather_buf = [None]
+    # pose records of `gather_every` frames per RCCL all-gather, issued on a side stream: no frame waits for it
+    gatherer = parallel.PoseGatherer(cap, every=args.gather_every or max(1, depth + 1), device=dev) if world > 1 else None
 
     def finish(ticket):
         out = {"aggregated": model_gpu.post_network_finish(ticket)} if args.vote_only else streamer.collect(ticket)
-        if world > 1:      # ONE fixed-capacity RCCL all-gather of pose records per step: pack = one native launch
-            gather_buf[0] = parallel.all_gather_pose_records(out["aggregated"], rank * Bq, cap, out=gather_buf[0])
+        if gatherer is not None:
+            gatherer.add(out["aggregated"], rank * Bq)       # pack = one native launch; the collective follows on the side stream
         return out
 
     def step(pipelined=True):
@@ -254,6 +294,8 @@ def run_inference(args, encoder, Bq, hn, steps, warmup, world, rank, dev, want_b
     def drain():
         while pending:
             finish(pending.pop(0))
+        if gatherer is not None:
+            gatherer.flush()
 
     def barrier():
         if world > 1:
@@ -269,17 +311,34 @@ def run_inference(args, encoder, Bq, hn, steps, warmup, world, rank, dev, want_b
     for _ in range(warmup):
         step()
     drain()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        step()
-    drain()
-    barrier()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    # EXACTLY `steps` steps between barrier + synchronize on both sides, max over ranks; the region is repeated until
+    # `--min-seconds` are covered (20 steps are 16 ms, a quarter of it pipeline fill and drain) and the MEDIAN repeat is reported
+    def timed_region():
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        drain()
+        barrier()
+        d = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([d], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            d = float(t.item())
+        return d
+
+    dts = [timed_region()]
+    repeats = 1
+    if args.min_seconds > 0:
+        want = int(min(200, max(1, -(-args.min_seconds // max(dts[0], 1e-6)))))
+        if world > 1:                                         # every rank must run the same number of regions
+            t = torch.tensor([want], dtype=torch.int64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            want = int(t.item())
+        while repeats < want:
+            dts.append(timed_region())
+            repeats += 1
+    dt = median(dts)
 
     # per-frame latency with ONE frame in flight (not the headline number)
     nlat = max(5, min(steps, 20))
@@ -291,6 +350,9 @@ def run_inference(args, encoder, Bq, hn, steps, warmup, world, rank, dev, want_b
     latency_ms = (time.perf_counter() - t1) / nlat * 1e3
 
     res = {"value": round(world * Bq * steps / dt, 3), "ms_per_step": round(dt / steps * 1e3, 4), "steps": steps, "warmup": warmup,
+           "repeats": repeats, "ms_per_step_min_max": [round(min(dts) / steps * 1e3, 4), round(max(dts) / steps * 1e3, 4)],
+           "pose_gather": None if gatherer is None else {"frames_per_collective": gatherer.every, "collectives": gatherer.collectives,
+                                                         "stream": "side", "record_bytes": 160, "capacity_per_frame": cap},
            "workload": f"{encoder}-FPN + all heads, batch={Bq} 640x480 per GPU per step, {1 + depth} frames in flight on "
                        f"{len(streamer.models)} streams, hn={hn}, {n_inst} instances per step (vote-bench fixture), random-init weights",
            "global_batch": world * Bq, "frames_in_flight": 1 + depth, "net_streams": len(streamer.models),
@@ -349,6 +411,24 @@ def run_inference(args, encoder, Bq, hn, steps, warmup, world, rank, dev, want_b
     return res, dict(model=model, model_gpu=model_gpu, image=image, cat_cpu=cat_cpu, cat=cat, n_inst=n_inst, hp=hp)
 
 
+def attach_profiled_counters(roof, name):
+    """`traffic` (HBM bytes per launch, FETCH_SIZE doubled per the guide's gfx950 note + WRITE_SIZE) and the VALU instruction
+    rate come from PMC passes that rocprofv3 runs in its own processes (tools_dev/vote_traffic.py -> profiles/<name>): they
+    are attached LABELLED, never as if measured by this run."""
+    prof = load_profile_json(name) if name else None
+    if not prof:
+        return
+    roof["traffic"] = prof.get("traffic_bytes_per_launch")
+    roof["from_profile"] = {"file": "profiles/" + name, "commit": prof.get("commit"), "fields": ["traffic", "valu.wave_instructions_per_launch"]}
+    vinst = prof.get("valu_wave_instructions_per_launch")
+    if vinst:
+        rate = vinst / (roof["launch_ms"] * 1e-3)
+        roof["valu"] = {"bound": "valu", "achieved": round(rate / 1e9, 2), "peak": round(VALU_PEAK_WAVE_INSTR_PER_S / 1e9, 1),
+                        "unit": "G wave-instr/s", "frac": round(rate / VALU_PEAK_WAVE_INSTR_PER_S, 4), "wave_instructions_per_launch": vinst,
+                        "note": "SQ_INSTS_VALU of the four kernels (the profile) / the live launch time; peak = 1024 SIMD-32 x 2.4 GHz / 2 "
+                                "cycles per wave64 instruction (tools_dev/mfma_vote_probe.hip measured 2.6 for v_sub + v_alignbit at >= 2 waves per SIMD)"}
+
+
 def load_profile_json(name):
     path = os.path.join(REPO, "profiles", name)
     if os.path.exists(path):
@@ -405,29 +485,21 @@ def main():
         roof = vote_roofline(ctx["model_gpu"], ctx["cat"], ctx["n_inst"], max(5, min(args.steps, 20)),
                              f"batch {args.batch}, hn {args.hn}, {ctx['n_inst']} instances")
         roof["measured_copy_GBps"] = measure_copy_ceiling(dev)
-        prof = load_profile_json("r02_vote_traffic.json") if (args.hn == 1000 and args.batch == 1) else None
-        if prof:
-            roof["traffic"] = prof.get("traffic_bytes_per_launch")
-            vinst = prof.get("valu_wave_instructions_per_launch")
-            if vinst:
-                rate = vinst / (roof["launch_ms"] * 1e-3)
-                roof["valu"] = {"bound": "valu", "achieved": round(rate / 1e9, 2), "peak": round(VALU_PEAK_WAVE_INSTR_PER_S / 1e9, 1),
-                                "unit": "G wave-instr/s", "frac": round(rate / VALU_PEAK_WAVE_INSTR_PER_S, 4),
-                                "frac_of_measured_plain_f32_rate": round(rate / VALU_MEASURED_F32_PER_S, 4),
-                                "wave_instructions_per_launch": vinst,
-                                "note": "SQ_INSTS_VALU of the four kernels (profiles/r02_vote_traffic.json, separate --pmc pass) / the "
-                                        "live launch time; peak = 1024 SIMD-32 x 2.4 GHz / 2 cycles per wave64 instruction"}
-        roof["note"] = ("HIP events on the launch stream around the whole call; at hn=1000 the sequence is VALU-bound (`valu`), "
-                        "the HBM fraction is what the metric's definition gives; traffic from profiles/r02_vote_traffic.json (PMC)")
+        attach_profiled_counters(roof, "r03_vote_traffic_b1_hn1000.json" if (args.hn == 1000 and args.batch == 1) else None)
+        roof["note"] = ("HIP events on the launch stream around the whole call, live in this run; `traffic` and `valu` are PMC "
+                        "counters of a separate profiled run of the same call (`from_profile` names the file and the commit it was "
+                        "taken at): rocprofv3 cannot collect them inside this process")
         line = {
             "metric": "img/s end-to-end 640x480 inference; hough-vote kernel HBM GB/s vs roofline",
             "value": res["value"], "unit": "img/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": res["ms_per_step"], "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "scaling": "weak", "scaling_measured": False, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "repeats": res["repeats"], "ms_per_step_min_max": res["ms_per_step_min_max"],
             "config": {"workload": res["workload"], "global_batch": res["global_batch"],
                        "parallelism": f"image-sharded dp{world}" if world > 1 else "single GPU",
                        "vote_only": bool(args.vote_only), "frames_in_flight": res["frames_in_flight"],
                        "net_streams": res["net_streams"], "ms_per_frame_one_in_flight": res["ms_per_frame_one_in_flight"],
+                       "pose_gather": res["pose_gather"],
                        "post_network_input": "synthetic vote-bench fixture (SURVEY.md 8d), not the random-weight network's output",
                        "img_per_s_from_host_u8_frames": res.get("host_frames_img_per_s"),
                        "img_per_s_from_host_u8_frames_note": "PCIe-inclusive: pinned u8 frames -> H2D -> preprocessing kernels "
@@ -445,7 +517,9 @@ def main():
             hp128.HV_NUM_OF_HYPOTHESES = 128
             cat32_cpu, _ = synth.make_vote_batch(range(32))
             cat32 = {k: v.to(dev) for k, v in cat32_cpu.items()}
-            line["roofline_hn128"] = vote_roofline(ctx["model_gpu"], cat32, 6 * 32, 5, "batch 32, hn 128, 192 instances", calls=4)
+            line["roofline_hn128"] = vote_roofline(ctx["model_gpu"], cat32, 6 * 32, 9, "batch 32, hn 128, 192 instances", calls=4)
+            attach_profiled_counters(line["roofline_hn128"], "r03_vote_traffic_b32_hn128.json")
+            line["post_network"] = post_network_rates(ctx["model_gpu"], ctx["cat"], ctx["n_inst"], cat32, 6 * 32)
             hp128.HV_NUM_OF_HYPOTHESES = args.hn
             del cat32
         if not args.no_cpu_baseline:
@@ -467,6 +541,15 @@ def main():
                 c3["backbone"] = r3["backbone"]
             c3["roofline"] = vote_roofline(ctx3["model_gpu"], ctx3["cat"], ctx3["n_inst"], 5, f"batch 32, hn {args.hn}, 192 instances", calls=4)
             line["configs"] = {"config3": c3}
+    if world == 1 and not args.no_train_line and not args.vote_only:
+        # BASELINE.json configs[4] at its per-GPU share (B = 8) on this GPU, so that the driver's run times it as well
+        try:
+            torch.cuda.empty_cache()
+            from fastposecnn_amd import train_bench
+            targs = parse(["--train", "--steps", "12", "--warmup", "3", "--train-batch", str(args.train_batch), "--bucket-mb", str(args.bucket_mb)])
+            line["train"] = train_bench.run(targs, quiet=True)
+        except Exception as e:                                 # the inference line must not be lost to the extra section
+            line["train"] = {"error": f"{type(e).__name__}: {e}"}
     if rank == 0:
         print(json.dumps(line), flush=True)
     if world > 1:

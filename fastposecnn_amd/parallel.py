@@ -23,16 +23,17 @@ def shard_indices(num_images, rank, world_size):
     return range(start, start + base + (1 if rank < rem else 0))
 
 
-def pack_pose_records(agg, sample_offset, capacity):
+def pack_pose_records(agg, sample_offset, capacity, out=None):
     """AggData (after RT calculation) -> f32 [capacity + 1, 40]; rank-local sample ids are shifted
-    by `sample_offset` (the index of the shard's first image) so ids are global."""
+    by `sample_offset` (the index of the shard's first image) so ids are global.  `out`: a contiguous
+    [capacity + 1, 40] f32 tensor to fill instead of a new one (PoseGatherer's staging slots)."""
     n = int(agg["class_ids"].shape[0])
     if n > capacity:
         raise RuntimeError(f"pose record capacity {capacity} exceeded by {n} instances")
     dev = agg["quaternion"].device
     if dev.type == "cuda":            # one native launch (fpc_pack_pose_records) instead of ~15 small torch ops per frame
         from fastposecnn_amd import _native as nat
-        buf = torch.empty((capacity + 1, RECORD_WIDTH), dtype=torch.float32, device=dev)
+        buf = out if out is not None else torch.empty((capacity + 1, RECORD_WIDTH), dtype=torch.float32, device=dev)
         f = lambda k: agg[k].contiguous().float()
         t = [agg["sample_ids"].contiguous().long(), agg["class_ids"].contiguous().long()] + [f(k) for k, _ in _FIELDS]
         with torch.cuda.device(dev):
@@ -46,6 +47,9 @@ def pack_pose_records(agg, sample_offset, capacity):
                            agg["class_ids"].to(torch.int32)], dim=1)
         cols = [ids.view(torch.float32)] + [agg[k].reshape(n, w).float() for k, w in _FIELDS]
         buf[1:n + 1] = torch.cat(cols, dim=1)
+    if out is not None:
+        out.copy_(buf)
+        return out
     return buf
 
 
@@ -75,3 +79,86 @@ def all_gather_pose_records(agg, sample_offset, capacity, group=None, out=None):
         out = torch.empty((world, capacity + 1, RECORD_WIDTH), dtype=torch.float32, device=buf.device)
     dist.all_gather_into_tensor(out.view(-1), buf.view(-1), group=group)
     return out
+
+
+class PoseGatherer:
+    """The pose gather off the frames' critical path ("issue once per batch on a side stream").
+
+    `add(agg, sample_offset)` packs one frame's records into the next slot of a staging buffer (one native launch on the
+    caller's current stream, no wait); every `every` frames ONE all-gather of the whole staging buffer runs on a side
+    stream behind an event, while the next frames pack into the other staging buffer.  No frame waits for RCCL; a consumer
+    calls `latest()` (waits for the last issued collective only) or `flush()` at the end of a run.  With one rank, or on CPU
+    tensors (gloo tests), the same calls run inline."""
+
+    def __init__(self, capacity, every=4, group=None, device=None):
+        self.capacity, self.every, self.group = int(capacity), max(1, int(every)), group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.device = device
+        self._stage = None            # two staging buffers [every, capacity + 1, 40]
+        self._out = None              # two results [world, every, capacity + 1, 40]
+        self._cur, self._fill = 0, 0
+        self._stream = None
+        self._done = [None, None]     # events: the collective that reads staging buffer i has finished
+        self._last = None             # (index, frames) of the most recent collective
+        self.collectives = 0
+
+    def _ensure(self, dev):
+        if self._stage is None:
+            self.device = dev
+            shape = (self.every, self.capacity + 1, RECORD_WIDTH)
+            self._stage = [torch.zeros(shape, dtype=torch.float32, device=dev) for _ in range(2)]
+            self._out = [torch.zeros((self.world,) + shape, dtype=torch.float32, device=dev) for _ in range(2)]
+            if dev.type == "cuda":
+                self._stream = torch.cuda.Stream(device=dev)
+
+    def add(self, agg, sample_offset):
+        dev = agg["quaternion"].device
+        self._ensure(dev)
+        if self._fill == 0 and self._done[self._cur] is not None:
+            # this staging buffer is being read by the collective issued two rounds ago: order behind it (on the stream, no host wait)
+            torch.cuda.current_stream(dev).wait_event(self._done[self._cur])
+        pack_pose_records(agg, sample_offset, self.capacity, out=self._stage[self._cur][self._fill])
+        self._fill += 1
+        if self._fill == self.every:
+            self._issue()
+
+    def _issue(self):
+        i, frames = self._cur, self._fill
+        if frames == 0:
+            return
+        if frames < self.every:                                   # a partial round (flush): mark the unused slots empty
+            self._stage[i][frames:, 0, 0] = 0
+        src, dst = self._stage[i], self._out[i]
+        if self._stream is not None:
+            ready = torch.cuda.Event()
+            ready.record(torch.cuda.current_stream(self.device))
+            with torch.cuda.stream(self._stream):
+                self._stream.wait_event(ready)
+                if self.world > 1:
+                    dist.all_gather_into_tensor(dst.view(-1), src.view(-1), group=self.group)
+                else:
+                    dst[0].copy_(src)
+                done = torch.cuda.Event()
+                done.record(self._stream)
+            self._done[i] = done
+        else:
+            if self.world > 1:
+                dist.all_gather_into_tensor(dst.view(-1), src.view(-1), group=self.group)
+            else:
+                dst[0].copy_(src)
+        self.collectives += 1
+        self._last = (i, frames)
+        self._cur, self._fill = 1 - i, 0
+
+    def flush(self):
+        """Issue the collective for the frames added since the last one (call on every rank the same number of times)."""
+        self._issue()
+
+    def latest(self):
+        """Records of the most recent collective: [world, frames, capacity + 1, 40] (waits for that collective only)."""
+        if self._last is None:
+            return None
+        i, frames = self._last
+        if self._done[i] is not None:
+            self._done[i].synchronize()
+        return self._out[i][:, :frames]

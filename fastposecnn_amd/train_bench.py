@@ -53,6 +53,12 @@ def _ground_truth(model, cat, symmetric_classes=(1, 2, 4)):
 
 
 def main(args):
+    run(args)
+
+
+def run(args, quiet=False):
+    """The config-4 step.  quiet: return rank 0's line (bench.py's `train` object) instead of printing it; the process
+    group, if any, is left to the caller."""
     import fastposecnn_amd.lib as L
     from fastposecnn_amd import config, synth, _native
     from fastposecnn_amd.train_parallel import ShardedLookaheadRAdam
@@ -175,6 +181,8 @@ def main(args):
             "step_check": {"total_loss": round(float(last["total"]), 6), "losses": losses, "predicted_instances": last["n_pred"],
                            "matched_instances": matched, "skipped_steps": int(opt.skipped), "replicas_in_sync": in_sync},
         }
+        if quiet:
+            return line
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if world > 1 and not quiet:
         dist.destroy_process_group()

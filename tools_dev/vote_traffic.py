@@ -4,7 +4,7 @@
         rocprofv3 --kernel-trace --pmc $c --output-format csv -d $REPO/gpurun_out/<dir>/<first counter> -o p -- \
             python3 $REPO/tools_dev/vote_time.py <B> <hn> 20
     done
-    python tools_dev/vote_traffic.py gpurun_out/<dir> profiles/r02_vote_traffic.json <B> <hn>
+    python tools_dev/vote_traffic.py gpurun_out/<dir> profiles/r03_vote_traffic_<tag>.json <B> <hn> <commit>
 
 Separate passes per the guide (MI355X_MICROARCH.md, HBM / rocprofv3: FETCH_SIZE and WRITE_SIZE do not fit one pass,
 and counters are never combined with the system traces).  FETCH_SIZE and WRITE_SIZE are in KB; on gfx950 FETCH_SIZE
@@ -20,6 +20,7 @@ import sys
 root, out = sys.argv[1], sys.argv[2]
 B = int(sys.argv[3]) if len(sys.argv) > 3 else 1
 hn = int(sys.argv[4]) if len(sys.argv) > 4 else 1000
+commit = sys.argv[5] if len(sys.argv) > 5 else None
 VOTE = ("k_vote_scan", "k_vote_plan", "k_vote_count", "k_vote_final")
 
 
@@ -61,6 +62,7 @@ res = {
     "traffic_bytes_per_launch": int((2 * fetch + write) * 1024),
     "algorithmic_bytes_per_launch": n_inst * 12 * 480 * 640,
     "valu_wave_instructions_per_launch": int(valu),
+    "commit": commit,
 }
 res["traffic_over_algorithmic"] = round(res["traffic_bytes_per_launch"] / res["algorithmic_bytes_per_launch"], 3)
 json.dump(res, open(out, "w"), indent=1)
