@@ -50,6 +50,9 @@ _SIGNATURES = {
     "fpc_preprocess_workspace_bytes": (_sz, [_i]),
     "fpc_preprocess_u8": (_i, [_vp, _i, _i, _i, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double), _i, _vp, _vp,
                                _sz, _vp]),
+    "fpc_png_info": (_i, [_vp, _sz, ctypes.POINTER(ctypes.c_int32)]),
+    "fpc_png_decode": (_i, [_vp, _sz, _vp, _sz, _i]),
+    "fpc_png_decode_batch": (_i, [ctypes.POINTER(_vp), ctypes.POINTER(_sz), _i, _vp, _i, _i, _i]),
     "fpc_net_create": (_i, [ctypes.c_char_p, _i, _i, _i, _i, ctypes.POINTER(_vp)]),
     "fpc_net_destroy": (None, [_vp]),
     "fpc_net_set_graph": (_i, [_vp, _i]),
@@ -88,7 +91,7 @@ def lib():
             fn = getattr(L, name)
             fn.restype = res
             fn.argtypes = args
-        if L.fpc_abi_version() != 5:
+        if L.fpc_abi_version() != 6:
             raise RuntimeError("fastposecnn_amd: libfpc_hip.so ABI version mismatch")
         _lib = L
     return _lib

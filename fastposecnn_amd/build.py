@@ -61,7 +61,7 @@ def build(force=False, verbose=False, extra=()):
     linked = open(stamp).read().strip() if os.path.exists(stamp) else ""
     if (force or linked != tag or not os.path.exists(LIB)
             or os.path.getmtime(LIB) < max(os.path.getmtime(o) for o in objs)):
-        subprocess.check_call([HIPCC, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", LIB, *objs])
+        subprocess.check_call([HIPCC, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", LIB, *objs, "-lz"])      # zlib: png_decode.hip
         with open(stamp, "w") as f:
             f.write(tag)
     if verbose:

@@ -4,8 +4,8 @@
 //   k_agg_accum     one pass over labels + cat_mask + the 8 averaged planes: per-instance
 //                   pixel count, smallest class id, fp64 sums (wave-level pre-reduction when a
 //                   wave sees a single label, which is the common case)
-//   k_agg_finalize  means, exp(z), quaternion re-normalisation, class / sample ids
-//   k_agg_planes    the drop-in outputs instance_masks [N,H,W] and masked xy [N,2,H,W]
+//   k_agg_planes    the drop-in outputs instance_masks [N,H,W] and masked xy [N,2,H,W]; the first workgroup of an
+//                   instance also takes its means, exp(z), quaternion re-normalisation, class / sample ids
 #include "common.hpp"
 
 namespace fpc {
@@ -47,6 +47,8 @@ __device__ __forceinline__ void agg_flush(int i, const double* v, int n, uint32_
 // wave-uniform label is unchanged and the wave reduces (shuffles) + issues ONE set of global atomics
 // only when that label changes or the strip ends.  Rows where two instances meet inside the 64 pixels
 // fall back to per-lane atomics for the minority label.   grid (ceil(W/64), ceil(H/(4*kAggRows)), B)
+// The strip's eight label rows are requested together, then the nine planes of four rows at a time under
+// their labels: three dependent memory round trips per wave instead of sixteen (one per row and stage).
 __global__ __launch_bounds__(256) void k_agg_accum(const int32_t* __restrict__ labels,
                                                    const int64_t* __restrict__ cm, const float* __restrict__ quat,
                                                    const float* __restrict__ scales, const float* __restrict__ z,
@@ -58,6 +60,17 @@ __global__ __launch_bounds__(256) void k_agg_accum(const int32_t* __restrict__ l
     const int lane = threadIdx.x & (kWave - 1), w = threadIdx.x / kWave;
     const int x = blockIdx.x * kWave + lane;
     const int y0 = (blockIdx.y * 4 + w) * kAggRows;
+    int lab[kAggRows];
+#pragma unroll
+    for (int r = 0; r < kAggRows; ++r) {
+        const int y = y0 + r;
+        int l = (x < W && y < H) ? labels[(size_t)b * HW + (size_t)y * W + x] : 0;
+        lab[r] = l > N ? 0 : l;
+    }
+    unsigned long long any = 0ull;
+#pragma unroll
+    for (int r = 0; r < kAggRows; ++r) any |= __ballot(lab[r] > 0);
+    if (any == 0ull) return;                                 // wave-uniform: a strip of background
     int cur = 0, n = 0;
     uint32_t c = 0xFFFFFFFFu;
     double v[8];
@@ -76,51 +89,61 @@ __global__ __launch_bounds__(256) void k_agg_accum(const int32_t* __restrict__ l
 #pragma unroll
         for (int a = 0; a < 8; ++a) v[a] = 0.0;
     };
-    for (int r = 0; r < kAggRows; ++r) {
-        int y = y0 + r;
-        if (y >= H) break;                                   // wave-uniform
-        int p = y * W + x;
-        int l = 0;
-        if (x < W) l = labels[(size_t)b * HW + p];
-        if (l > N) l = 0;
-        bool act = l > 0;
-        unsigned long long m = __ballot(act);
-        if (m == 0) continue;
-        int first = __builtin_amdgcn_readlane(l, __ffsll((long long)m) - 1);
-        if (first != cur) {                                  // wave-uniform decision
-            if (cur > 0) wave_flush();
-            cur = first;
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+        float q[4][8];
+        long long cls[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {                        // the loads of four rows in flight together
+            const int r = half * 4 + k;
+            cls[k] = 0;
+#pragma unroll
+            for (int a = 0; a < 8; ++a) q[k][a] = 0.0f;
+            if (lab[r] > 0) {
+                const size_t p = (size_t)(y0 + r) * W + x, o = (size_t)b * HW + p;
+                cls[k] = cm[o];
+#pragma unroll
+                for (int a = 0; a < 4; ++a) q[k][a] = quat[((size_t)b * 4 + a) * HW + p];
+#pragma unroll
+                for (int a = 0; a < 3; ++a) q[k][4 + a] = scales[((size_t)b * 3 + a) * HW + p];
+                q[k][7] = z[o];
+            }
         }
-        if (!act) continue;
-        size_t o = (size_t)b * HW + p;
-        long long cc = cm[o];
-        uint32_t pc = cc != 0 ? (uint32_t)cc : 0xFFFFFFFFu;
-        double q[8];
 #pragma unroll
-        for (int a = 0; a < 4; ++a) q[a] = (double)quat[((size_t)b * 4 + a) * HW + p];
+        for (int k = 0; k < 4; ++k) {
+            const int l = lab[half * 4 + k];
+            const bool act = l > 0;
+            const unsigned long long m = __ballot(act);
+            if (m == 0) continue;                            // wave-uniform
+            const int first = __builtin_amdgcn_readlane(l, __ffsll((long long)m) - 1);
+            if (first != cur) {                              // wave-uniform decision
+                if (cur > 0) wave_flush();
+                cur = first;
+            }
+            if (!act) continue;
+            const uint32_t pc = cls[k] != 0 ? (uint32_t)cls[k] : 0xFFFFFFFFu;
+            if (l == cur) {
 #pragma unroll
-        for (int a = 0; a < 3; ++a) q[4 + a] = (double)scales[((size_t)b * 3 + a) * HW + p];
-        q[7] = (double)z[o];
-        if (l == cur) {
+                for (int a = 0; a < 8; ++a) v[a] += (double)q[k][a];
+                ++n;
+                c = min(c, pc);
+            } else {
+                double qd[8];
 #pragma unroll
-            for (int a = 0; a < 8; ++a) v[a] += q[a];
-            ++n;
-            c = min(c, pc);
-        } else {
-            agg_flush(l - 1, q, 1, pc, b, sums, cnt, cls_min, sample);   // a second instance inside these 64 pixels
+                for (int a = 0; a < 8; ++a) qd[a] = (double)q[k][a];
+                agg_flush(l - 1, qd, 1, pc, b, sums, cnt, cls_min, sample);   // a second instance inside these 64 pixels
+            }
         }
     }
     if (cur > 0) wave_flush();
 }
 
-__global__ void k_agg_finalize(int N, const int32_t* __restrict__ n_dev, const double* __restrict__ sums, const int32_t* __restrict__ cnt,
-                               const uint32_t* __restrict__ cls_min, const int32_t* __restrict__ sample,
-                               int64_t* __restrict__ class_ids, int64_t* __restrict__ sample_ids,
-                               float* __restrict__ oq, float* __restrict__ os, float* __restrict__ oz,
-                               float* __restrict__ stats) {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (n_dev) N = min(N, *n_dev);
-    if (i >= N) return;
+// means, exp(z), quaternion re-normalisation, class / sample ids of instance i (one thread)
+__device__ __forceinline__ void agg_finalize_one(int i, const double* __restrict__ sums, const int32_t* __restrict__ cnt,
+                                                 const uint32_t* __restrict__ cls_min, const int32_t* __restrict__ sample,
+                                                 int64_t* __restrict__ class_ids, int64_t* __restrict__ sample_ids,
+                                                 float* __restrict__ oq, float* __restrict__ os, float* __restrict__ oz,
+                                                 float* __restrict__ stats) {
     double c = (double)cnt[i];
     float q[4];
 #pragma unroll
@@ -138,13 +161,30 @@ __global__ void k_agg_finalize(int N, const int32_t* __restrict__ n_dev, const d
     sample_ids[i] = cnt[i] > 0 ? (int64_t)sample[i] : -1;
 }
 
-// grid (ceil(HW/1024), N)
+// when no plane output is wanted: the per-instance results alone
+__global__ void k_agg_finalize(int N, const int32_t* __restrict__ n_dev, const double* __restrict__ sums, const int32_t* __restrict__ cnt,
+                               const uint32_t* __restrict__ cls_min, const int32_t* __restrict__ sample,
+                               int64_t* __restrict__ class_ids, int64_t* __restrict__ sample_ids,
+                               float* __restrict__ oq, float* __restrict__ os, float* __restrict__ oz,
+                               float* __restrict__ stats) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n_dev) N = min(N, *n_dev);
+    if (i >= N) return;
+    agg_finalize_one(i, sums, cnt, cls_min, sample, class_ids, sample_ids, oq, os, oz, stats);
+}
+
+// grid (ceil(HW/1024), N); the first block of every instance also finalises it (no launch of its own)
 __global__ __launch_bounds__(256) void k_agg_planes(const int32_t* __restrict__ labels, const float* __restrict__ xy,
                                                     const int32_t* __restrict__ sample, int HW,
                                                     const int32_t* __restrict__ n_dev,
-                                                    float* __restrict__ inst_masks, float* __restrict__ oxy) {
+                                                    float* __restrict__ inst_masks, float* __restrict__ oxy,
+                                                    const double* __restrict__ sums, const int32_t* __restrict__ cnt,
+                                                    const uint32_t* __restrict__ cls_min, int64_t* __restrict__ class_ids,
+                                                    int64_t* __restrict__ sample_ids, float* __restrict__ oq,
+                                                    float* __restrict__ os, float* __restrict__ oz, float* __restrict__ stats) {
     int i = blockIdx.y;
     if (n_dev && i >= *n_dev) return;     // capacity rows past the device-side instance count
+    if (blockIdx.x == 0 && threadIdx.x == 0) agg_finalize_one(i, sums, cnt, cls_min, sample, class_ids, sample_ids, oq, os, oz, stats);
     int b = sample[i];
     int p0 = blockIdx.x * 1024 + threadIdx.x * 4;
     if (p0 >= HW) return;
@@ -214,9 +254,11 @@ extern "C" int fpc_aggregate(const int32_t* labels, const int64_t* cat_mask, con
     hipLaunchKernelGGL(k_agg_accum, dim3(cdiv(W, kWave), cdiv(H, 4 * kAggRows), B), dim3(256), 0, s, labels, cat_mask, quat, scales, z,
                        H, W, N, n_dev, w.sums,
                        w.cnt, w.cls_min, w.sample);
-    hipLaunchKernelGGL(k_agg_finalize, dim3(cdiv(N, 64)), dim3(64), 0, s, N, n_dev, w.sums, w.cnt, w.cls_min, w.sample,
-                       class_ids, sample_ids, oq, os, oz, out_stats);
     if (inst_masks || oxy)
-        hipLaunchKernelGGL(k_agg_planes, dim3(gx, N), dim3(256), 0, s, labels, xy, w.sample, HW, n_dev, inst_masks, oxy);
+        hipLaunchKernelGGL(k_agg_planes, dim3(gx, N), dim3(256), 0, s, labels, xy, w.sample, HW, n_dev, inst_masks, oxy, w.sums, w.cnt,
+                           w.cls_min, class_ids, sample_ids, oq, os, oz, out_stats);
+    else
+        hipLaunchKernelGGL(k_agg_finalize, dim3(cdiv(N, 64)), dim3(64), 0, s, N, n_dev, w.sums, w.cnt, w.cls_min, w.sample,
+                           class_ids, sample_ids, oq, os, oz, out_stats);
     return check_launch();
 }

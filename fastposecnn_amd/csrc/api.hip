@@ -22,6 +22,7 @@ extern "C" const char* fpc_error_string(int code) {
         case FPC_EWORKSPACE: return "workspace too small or misaligned";
         case FPC_ELAUNCH: return "HIP launch error";
         case FPC_EDEVICE: return "no usable gfx950 device";
+        case FPC_EFORMAT: return "not a PNG this decoder reads";
         default: return "unknown error code";
     }
 }

@@ -7,10 +7,17 @@ Mirrors what F/tools/dataset.py does per sample on the host in numpy, for frames
 
 `preprocess_frames` runs the first chain on the GPU (fpc_preprocess_u8: two kernels, bit-identical to the numpy
 chain), `FrameUploader` owns the pinned staging buffers and the host->device copy stream in front of it, and
-`my_collate_fn` keeps the reference's collate semantics for callers that bring their own samples.  File decoding
-(skimage / cv2) and the dataset walk stay out of scope (not on the hot path).
+`my_collate_fn` keeps the reference's collate semantics for callers that bring their own samples.
+
+File decoding (:158-176: skimage.io.imread of `*_color.png` / `*_mask.png`, cv2.imread of `*_depth.png`) is native too
+(csrc/png_decode.hip over zlib; libpng's headers are not in the image): `imread_png` returns what imread returns,
+`read_frame_files` mirrors the first lines of `__getitem__` (image, mask with background 255 -> 0, standardised depth),
+and `FrameUploader.upload_png` decodes a batch of colour files straight into its pinned staging slot on a few host
+threads.  The dataset walk, the meta+.json instance filtering and `generate_agg_data` stay out of scope (training-set
+ground truth; SURVEY.md 8: not on the hot path).
 """
 import ctypes
+import os
 
 import numpy as np
 import torch
@@ -64,6 +71,54 @@ def preprocess_frames(images_u8, params=None, out=None):
     return out[0] if single else out
 
 
+def imread_png(src, rgb8=False):
+    """A PNG file (path) or its bytes -> numpy array as skimage.io.imread / cv2.imread(path, -1) return it: [H,W] or
+    [H,W,C] uint8, uint16 for 16-bit files, palette expanded to RGB (channel order R,G,B,A: cv2 would give B,G,R).
+    rgb8=True: always [H,W,3] uint8 (grey replicated, alpha dropped)."""
+    data = src if isinstance(src, (bytes, bytearray, memoryview)) else open(os.fspath(src), "rb").read()
+    buf = np.frombuffer(data, dtype=np.uint8)
+    L = nat.lib()
+    info = (ctypes.c_int32 * 5)()
+    nat.check(L.fpc_png_info(buf.ctypes.data, buf.size, info), "fpc_png_info")
+    W, H, depth, ctype, C = (int(v) for v in info)
+    if rgb8:
+        out = np.empty((H, W, 3), np.uint8)
+        nat.check(L.fpc_png_decode(buf.ctypes.data, buf.size, out.ctypes.data, out.nbytes, 3), "fpc_png_decode")
+        return out
+    out = np.empty((H, W, C), np.uint16 if depth == 16 else np.uint8)
+    nat.check(L.fpc_png_decode(buf.ctypes.data, buf.size, out.ctypes.data, out.nbytes, 0), "fpc_png_decode")
+    return out[:, :, 0] if C == 1 else out
+
+
+def standardize_depth(depth_rgb_or_u16):
+    """F/tools/data_manipulation.py:153-163 for an array in R,G,B order (the reference sees cv2's B,G,R: its channels
+    [1], [2] are G, R): a 3-channel file encodes depth as G * 256 + R; a 16-bit grey file is the depth."""
+    d = depth_rgb_or_u16
+    if d.ndim == 3:
+        return (d[:, :, 1].astype(np.uint16) * np.uint16(256) + d[:, :, 0].astype(np.uint16)).astype(np.uint16)
+    if d.ndim == 2 and d.dtype == np.uint16:
+        return d
+    raise ValueError("unsupported depth image")
+
+
+def read_frame_files(color_path, camera=True):
+    """The file reads of NOCSDataset.__getitem__ (F/tools/dataset.py:158-176): {'image': u8 [H,W,3|4] as stored,
+    'mask': float64 [H,W] with the background 255 set to 0 (first channel of the CAMERA set's RGBA masks),
+    'depth': uint16 [H,W]}.  Missing mask / depth files are left out."""
+    color_path = os.fspath(color_path)
+    out = {"image": imread_png(color_path)}
+    mask_fp = color_path.replace("_color.png", "_mask.png")
+    if os.path.exists(mask_fp):
+        m = imread_png(mask_fp)
+        m = (m[:, :, 0] if (camera and m.ndim == 3) else m).astype("float")
+        m[m == 255] = 0
+        out["mask"] = m
+    depth_fp = color_path.replace("_color.png", "_depth.png")
+    if os.path.exists(depth_fp):
+        out["depth"] = standardize_depth(imread_png(depth_fp))
+    return out
+
+
 class FrameUploader:
     """Host frames -> network tensors: pinned staging + asynchronous H2D copy + preprocess_frames, buffered `slots` deep
     on its own HIP stream so the copy of batch i+1 overlaps the network of batch i.  `upload(frames)` returns
@@ -100,6 +155,26 @@ class FrameUploader:
         if self._busy[k] is not None:
             self._busy[k].synchronize()      # the pinned buffer is about to be rewritten by the CPU
         np.copyto(self._host_np[k], src)
+        return self._enqueue(k, consumed)
+
+    def upload_png(self, files, consumed=None, threads=4):
+        """files: B PNG files as bytes (`*_color.png`, all of the uploader's H x W): decoded by `threads` host threads
+        straight into the pinned staging slot (fpc_png_decode_batch: RGB8, alpha dropped), then the same copy and kernels."""
+        k = self._i % len(self._host)
+        self._i += 1
+        B, H, W, _ = self._host_np[k].shape
+        if len(files) != B:
+            raise ValueError(f"expected {B} files, got {len(files)}")
+        if self._busy[k] is not None:
+            self._busy[k].synchronize()
+        bufs = [np.frombuffer(f, dtype=np.uint8) for f in files]
+        ptrs = (ctypes.c_void_p * B)(*[b.ctypes.data for b in bufs])
+        sizes = (ctypes.c_size_t * B)(*[b.size for b in bufs])
+        nat.check(nat.lib().fpc_png_decode_batch(ptrs, sizes, B, self._host_np[k].ctypes.data, H, W, int(threads)),
+                  "fpc_png_decode_batch")
+        return self._enqueue(k, consumed)
+
+    def _enqueue(self, k, consumed):
         with torch.cuda.stream(self.stream):
             if self._free[k] is not None:
                 self.stream.wait_event(self._free[k])

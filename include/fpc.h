@@ -23,6 +23,7 @@
  *   fpc_mask_iou                 lib/gpu_tensor_funcs.py:386-409 (batchwise_get_2d_iou), called by lib/matching.py:264-267
  *   fpc_net_*                    lib/pose_regressor.py:709-743 (+ segmentation_models_pytorch encoder/decoder/head)
  *   fpc_preprocess_u8            tools/dataset.py:249-262 (preprocessing_fn, transpose, / max|.|, img_as_float32)
+ *   fpc_png_info / _decode / _decode_batch   tools/dataset.py:158-176 (skimage.io.imread / cv2.imread of *_color / *_mask / *_depth.png)
  *   fpc_pose_errors              lib/gpu_tensor_funcs.py:411-476, 486-547, 563-565 (degree error, 3-D IoU, offset error)
  *   fpc_post_network_backward    torch autograd over lib/aggregation_layer.py:119-156 + RV/ransac_voting_gpu.py:583-599
  *   fpc_vote_refine_backward     torch autograd over RV/ransac_voting_gpu.py:583-599
@@ -42,13 +43,14 @@
 extern "C" {
 #endif
 
-#define FPC_ABI_VERSION 5
+#define FPC_ABI_VERSION 6
 
 #define FPC_OK 0
 #define FPC_EINVAL (-1)      /* bad argument (shape, null pointer, ...) */
 #define FPC_EWORKSPACE (-2)  /* workspace too small / misaligned */
 #define FPC_ELAUNCH (-3)     /* HIP reported a launch error (hipGetLastError) */
 #define FPC_EDEVICE (-4)     /* not running on a gfx950 device / no device */
+#define FPC_EFORMAT (-5)     /* fpc_png_*: not a PNG this decoder reads (bad signature / CRC / zlib stream, Adam7, 1-4 bit samples) */
 
 typedef void* fpc_stream_t;  /* hipStream_t */
 
@@ -169,6 +171,20 @@ int fpc_mask_iou(const void* masks1, int n1, const void* masks2, int n2, int64_t
 size_t fpc_preprocess_workspace_bytes(int B);
 int fpc_preprocess_u8(const uint8_t* img_hwc, int B, int H, int W, const double* mean3, const double* std3,
                       int input_range_01, float* out_nchw, void* ws, size_t ws_bytes, fpc_stream_t stream);
+
+/* ---- frame decoding, HOST side (tools/dataset.py:158-176: skimage.io.imread / cv2.imread of the NOCS *_color.png,
+ * *_mask.png, *_depth.png) -------------------------------------------------------------------------------------------
+ * PNG (ISO/IEC 15948) through zlib: colour types 0 / 2 / 3 / 4 / 6, 8 or 16 bits per sample, non-interlaced; anything
+ * else (and any damaged file: signature, chunk CRC, zlib stream, filter type) is FPC_EFORMAT.  Host pointers, no stream.
+ * fpc_png_info: out5 = {width, height, bit depth, colour type, channels of the mode-0 output}.
+ * fpc_png_decode mode 0: the samples as stored, [H, W, C] u8 — or u16 in host byte order for 16-bit files; a palette is
+ *   expanded to RGB8 — exactly what imread returns; mode 3: RGB8 whatever the file holds (grey replicated, alpha
+ *   dropped, 16-bit samples by their high byte).  out_bytes is checked.
+ * fpc_png_decode_batch: n files of ONE size H x W -> out u8 [n, H, W, 3] (mode 3), decoded by `threads` host threads
+ *   (the calling thread included); out is typically FrameUploader's pinned staging slot. */
+int fpc_png_info(const uint8_t* data, size_t nbytes, int32_t* out5);
+int fpc_png_decode(const uint8_t* data, size_t nbytes, void* out, size_t out_bytes, int mode);
+int fpc_png_decode_batch(const uint8_t* const* datas, const size_t* sizes, int n, uint8_t* out, int H, int W, int threads);
 
 /* ---- evaluation maths on matched pairs (lib/gpu_tensor_funcs.py:411-476, 486-547, 563-565) ----------------------
  * One launch for n (ground truth, prediction) pairs; every output is optional (NULL skips it and its inputs).
