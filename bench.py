@@ -384,6 +384,41 @@ def run_inference(args, encoder, Bq, hn, steps, warmup, world, rank, dev, want_b
         torch.cuda.synchronize()
         res["host_frames_img_per_s"] = round(Bq * nh / (time.perf_counter() - t2), 2)
 
+        # ... and from ENCODED frames: `*_color.png` files (in memory, as a loader's read-ahead would hold them) -> native PNG
+        # decode on a few host threads straight into the pinned staging slot -> the same path (F/tools/dataset.py:158 on
+        # our side of the boundary).  Synthetic 640x480 RGB frames with smooth + noisy content (~600 KB each as PNG).
+        from oracle import png_oracle                      # fixture set-up only: the encoder that writes the test frames
+        yy, xx = np.mgrid[0:480, 0:640]
+        pngs = []
+        for i in range(4):
+            img = np.stack([(128 + 100 * np.sin(xx / (23.0 + i)) * np.cos(yy / 31.0)), (xx * 255 / 639 + 20 * i) % 256, (yy * 255 / 479)], -1)
+            img = (img + np.random.default_rng(i).integers(0, 24, (480, 640, 3))).clip(0, 255).astype(np.uint8)
+            pngs.append(png_oracle.encode(img, filters=[4] * 480))
+        from fastposecnn_amd.tools.dataset import PngFramePrefetcher
+        workers = max(1, min(14, (os.cpu_count() or 2) - 2))        # the job's CPU share is 16 on a GPU box
+        npng = max(6, nh // 2) if Bq > 1 else max(40, nh)
+        pre = PngFramePrefetcher(lambda k: [pngs[(k + j) % len(pngs)] for j in range(Bq)], npng + depth + 2, Bq, 480, 640, workers=workers)
+
+        def step_png(frames):
+            t, ready = up.upload(frames)
+            pending.append(streamer.submit(t, categorical_override=cat, ready=ready))
+            if len(pending) > depth:
+                finish(pending.pop(0))
+
+        it = iter(pre)
+        for _ in range(depth + 2):
+            step_png(next(it))
+        drain()
+        torch.cuda.synchronize()
+        t3 = time.perf_counter()
+        for frames in it:
+            step_png(frames)
+        drain()
+        torch.cuda.synchronize()
+        res["png_files_img_per_s"] = round(Bq * npng / (time.perf_counter() - t3), 2)
+        res["png_decode_workers"] = workers
+        res["png_bytes_per_frame"] = int(sum(len(p) for p in pngs) / len(pngs))
+
     # backbone alone: HIP events around the engine call on its stream
     if want_backbone and not args.vote_only:
         net_ms = []
@@ -502,6 +537,11 @@ def main():
                        "pose_gather": res["pose_gather"],
                        "post_network_input": "synthetic vote-bench fixture (SURVEY.md 8d), not the random-weight network's output",
                        "img_per_s_from_host_u8_frames": res.get("host_frames_img_per_s"),
+                       "img_per_s_from_png_files": res.get("png_files_img_per_s"),
+                       "img_per_s_from_png_files_note": "encoded *_color.png frames held in host memory -> native zlib-based decode on "
+                                                        f"{res.get('png_decode_workers')} host threads running ahead (PngFramePrefetcher; ~10 ms of inflate + "
+                                                        "un-filtering per frame and core) -> pinned staging -> H2D -> the same pipeline; "
+                                                        f"{res.get('png_bytes_per_frame')} bytes per frame",
                        "img_per_s_from_host_u8_frames_note": "PCIe-inclusive: pinned u8 frames -> H2D -> preprocessing kernels "
                                                              "(tools/dataset.py:249-262 on the device) -> the same pipeline; "
                                                              "`value` starts from tensors resident in HBM"},

@@ -95,3 +95,15 @@ def test_frame_files_follow_the_reference_item(ds, tmp_path):
     assert np.array_equal(b["depth"], e[:, :, 1].astype(np.uint16) * 256 + e[:, :, 0]) and set(np.unique(b["mask"])) == {0.0, 7.0}
     c = ds.read_frame_files(tmp_path / "0003_color.png")
     assert set(c) == {"image"}
+
+
+def test_prefetcher_yields_every_batch_in_order(ds):
+    from oracle import png_oracle
+    rng = np.random.default_rng(4)
+    frames = [rng.integers(0, 256, (16, 24, 3)).astype(np.uint8) for _ in range(7)]
+    files = [png_oracle.encode(f) for f in frames]
+    pre = ds.PngFramePrefetcher(lambda k: [files[(2 * k) % 7], files[(2 * k + 1) % 7]], 9, 2, 16, 24, workers=3, ahead=4)
+    got = list(pre)
+    assert len(got) == 9
+    for k, b in enumerate(got):
+        assert b.shape == (2, 16, 24, 3) and np.array_equal(b[0], frames[(2 * k) % 7]) and np.array_equal(b[1], frames[(2 * k + 1) % 7])

@@ -103,3 +103,23 @@ def test_frame_uploader_matches_direct():
         got = t.clone()
         want = np.stack([opre.preprocess_frame(f, IMAGENET_PARAMS) for f in b])
         np.testing.assert_array_equal(got.cpu().numpy(), want)
+
+
+@pytest.mark.gpu
+def test_uploader_from_png_files_equals_preprocessing_of_the_decoded_bytes():
+    """`*_color.png` bytes -> native decode into the pinned slot -> H2D -> fpc_preprocess_u8 == the numpy chain of
+    F/tools/dataset.py:249-262 on the frames the files encode (fixtures pinned by libpng: tests/test_png_decode.py)."""
+    import os
+    from conftest import GOLDEN, load_golden
+    from fastposecnn_amd.tools.dataset import IMAGENET_PARAMS, FrameUploader
+    exp = load_golden("png_expected.npz")
+    names = ["color_rgb", "color_noise_rgb", "mask_rgba"]                 # 48 x 64; the RGBA file loses its alpha
+    files = [open(os.path.join(GOLDEN, "png", n + ".png"), "rb").read() for n in names]
+    up = FrameUploader(3, 48, 64)
+    for threads in (1, 3):
+        t, ev = up.upload_png(files, threads=threads)
+        torch.cuda.current_stream().wait_event(ev)
+        want = np.stack([opre.preprocess_frame(exp[n][:, :, :3], IMAGENET_PARAMS) for n in names])
+        np.testing.assert_array_equal(t.cpu().numpy(), want)
+    with pytest.raises(ValueError):
+        up.upload_png(files[:2])
