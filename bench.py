@@ -557,7 +557,7 @@ def main():
             hp128.HV_NUM_OF_HYPOTHESES = 128
             cat32_cpu, _ = synth.make_vote_batch(range(32))
             cat32 = {k: v.to(dev) for k, v in cat32_cpu.items()}
-            line["roofline_hn128"] = vote_roofline(ctx["model_gpu"], cat32, 6 * 32, 9, "batch 32, hn 128, 192 instances", calls=4)
+            line["roofline_hn128"] = vote_roofline(ctx["model_gpu"], cat32, 6 * 32, 9, "batch 32, hn 128, 192 instances", calls=10)
             attach_profiled_counters(line["roofline_hn128"], "r03_vote_traffic_b32_hn128.json")
             line["post_network"] = post_network_rates(ctx["model_gpu"], ctx["cat"], ctx["n_inst"], cat32, 6 * 32)
             hp128.HV_NUM_OF_HYPOTHESES = args.hn
@@ -579,7 +579,7 @@ def main():
                              "ms_per_step_one_in_flight": r3["ms_per_frame_one_in_flight"]}}
             if "backbone" in r3:
                 c3["backbone"] = r3["backbone"]
-            c3["roofline"] = vote_roofline(ctx3["model_gpu"], ctx3["cat"], ctx3["n_inst"], 5, f"batch 32, hn {args.hn}, 192 instances", calls=4)
+            c3["roofline"] = vote_roofline(ctx3["model_gpu"], ctx3["cat"], ctx3["n_inst"], 5, f"batch 32, hn {args.hn}, 192 instances", calls=10)
             line["configs"] = {"config3": c3}
     if world == 1 and not args.no_train_line and not args.vote_only:
         # BASELINE.json configs[4] at its per-GPU share (B = 8) on this GPU, so that the driver's run times it as well

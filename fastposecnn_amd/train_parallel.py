@@ -22,6 +22,13 @@ import torch
 import torch.distributed as dist
 
 
+def _slot(numel):
+    """Elements a parameter occupies in the flat buffers: every parameter starts on a 16-byte boundary (the network
+    plan's packing kernels and fpc_net_load_params read parameters with 16-byte loads and refuse unaligned pointers);
+    the padding stays zero in the parameters, gradients and moments, so the step leaves it zero."""
+    return (numel + 3) // 4 * 4
+
+
 class ShardedLookaheadRAdam:
 
     def __init__(self, model, lr=1e-5, betas=(0.9, 0.999), eps=1e-8, weight_decay=3e-4, la_k=5, la_alpha=0.5,
@@ -51,7 +58,7 @@ class ShardedLookaheadRAdam:
         cur, cur_n = [], 0
         for p in reversed(params):
             cur.append(p)
-            cur_n += p.numel()
+            cur_n += _slot(p.numel())
             if cur_n >= limit:
                 self.buckets.append({"params": cur, "raw": cur_n})
                 cur, cur_n = [], 0
@@ -84,7 +91,7 @@ class ShardedLookaheadRAdam:
                 p.data = view
                 p.grad = self.flat_g[o:o + n].view_as(p)
                 self._hooks.append(p.register_post_accumulate_grad_hook(self._make_hook(bi)))
-                o += n
+                o += _slot(n)
             b["shard"] = b["numel"] // self.world
             b["shard_offset"] = soff
             soff += b["shard"]

@@ -188,6 +188,7 @@ def test_guard_steps_with_zero_gradient_and_views_stay_attached():
     # parameters and gradients are views of the flat buffers
     for p in model.parameters():
         assert opt.flat_p.data_ptr() <= p.data_ptr() < opt.flat_p.data_ptr() + 4 * opt.total
+        assert p.data_ptr() % 16 == 0 and p.grad.data_ptr() % 16 == 0      # fpc_net_load_params refuses unaligned parameters
     model.zero_grad(set_to_none=True)
     with pytest.raises(RuntimeError):
         opt.zero_grad()
