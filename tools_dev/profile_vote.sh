@@ -15,9 +15,11 @@ for cfg in "1 1000 b1_hn1000" "32 128 b32_hn128"; do
         first=${c%% *}
         cd /tmp && timeout 300 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $D/$first -o p -- python3 $R/tools_dev/vote_time.py $B $HN 20 > $D/$first.log 2>&1
     done
-    cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $D/stats -- python3 $R/tools_dev/vote_loop.py --hn $HN --frames $B --iters 200 > $D/stats.log 2>&1
+    cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $D/stats -- python3 $R/tools_dev/vote_loop.py --hn $HN --frames $B --iters 200 --sets 8 > $D/stats.log 2>&1
     cd $R
     python tools_dev/vote_traffic.py $D $R/gpurun_out/r03_vote_traffic_$TAG.json $B $HN $COMMIT | tail -4
     python tools_dev/kstats.py $(ls $D/stats/*/*kernel_stats.csv | tail -1) --top 6 --out $R/gpurun_out/r03_vote_${TAG}_kernel_stats.csv | grep "k_vote"
     grep per-call $D/stats.log
+    python tools_dev/vote_loop.py --hn $HN --frames $B --iters 300 --sets 8 | grep per-call
+    python tools_dev/vote_loop.py --hn $HN --frames $B --iters 300 --sets 1 | grep per-call
 done
