@@ -36,7 +36,12 @@ struct PackedConv {
 
 struct Act { size_t off = 0; int H = 0, W = 0, C = 0; };
 
-struct ConvPlan { int bm = 64, bn = 64, nsplit = 1, mtiles = 1, ntiles = 1, wino = 0, bf3 = 0; };
+struct ConvPlan { int bm = 64, bn = 64, nsplit = 1, mtiles = 1, ntiles = 1, wino = 0, bf3 = 0, fused = 0; };
+
+// fused split-K (ConvArgs::fused) needs one arrival counter per output tile
+static bool can_fuse(const ConvPlan& p, int groups, int B) {
+    return p.nsplit > 1 && (long long)groups * B * p.mtiles * p.ntiles <= kConvTickets;
+}
 
 static ConvPlan plan_conv(int HoWo, int B, int Cout, int ksteps, int groups, int force_bm = 0, int force_bn = 0,
                           int force_split = 0) {
@@ -61,6 +66,7 @@ static ConvPlan plan_conv(int HoWo, int B, int Cout, int ksteps, int groups, int
                 if (t < best_t) { best_t = t; best = ConvPlan{bm, bn, ns, mt, nt, 0}; }
             }
         }
+    best.fused = can_fuse(best, groups, B) ? 1 : 0;
     return best;
 }
 
@@ -78,6 +84,7 @@ static std::vector<ConvPlan> conv_candidates(int HoWo, int B, int Cout, int kste
                 if (ns > 1 && (per < 2 || (ns - 1) * per >= ksteps || Cout % 4 != 0)) continue;
                 if (ns > 1 && base * ns > 4096) continue;          // already plenty of workgroups
                 out.push_back(ConvPlan{bm, bn, ns, mt, nt, 0});
+                if (can_fuse(out.back(), groups, B)) { ConvPlan f = out.back(); f.fused = 1; out.push_back(f); }
             }
         }
     return out;
@@ -133,6 +140,7 @@ struct fpc_net {
     int split_precision = 0;      // autotuning may pick the bf16 x 3 form of a direct convolution (fpc_net_set_split_precision)
     hipGraphExec_t graph_exec = nullptr;
     size_t zeros_off = 0;         // 64 zero floats (DMA source for out-of-image positions)
+    size_t tickets_off = 0;       // kConvTickets zero ints: arrival counters of the fused split-K convolutions
 
     // per-conv launch plans (index = conv id of decoder 0 for grouped ones)
     std::vector<ConvPlan> cplan;
@@ -231,6 +239,7 @@ extern "C" int fpc_net_create(const char* encoder, int classes, int B, int H, in
         dc.p_head_b = n->add_param(std::string(kHeadNames[d]) + ".0.bias", head_ch[d]);
     }
     n->zeros_off = n->alloc(64);
+    n->tickets_off = n->alloc(kConvTickets);
     n->packed_floats = n->bump;
 
     // ---- activations
@@ -349,6 +358,7 @@ extern "C" int fpc_net_load_params(fpc_net_t* n, const float* const* params, int
     n->ws = (float*)ws;
     n->pptr.assign(params, params + count);
     if (hipMemsetAsync(n->ws + n->zeros_off, 0, 64 * sizeof(float), s) != hipSuccess) return FPC_ELAUNCH;
+    if (hipMemsetAsync(n->ws + n->tickets_off, 0, kConvTickets * sizeof(int), s) != hipSuccess) return FPC_ELAUNCH;
     for (const PackedConv& c : n->convs) {
         int rc = launch_pack_weight(n->pptr[c.p_w], n->ws + c.w_off, c.Cout, c.Cin, c.Cinp, c.Kh, c.Kw, c.Kwp, c.Npad, c.Kpad, s);
         if (rc) return rc;
@@ -385,6 +395,8 @@ void fill_conv_args(const fpc_net* n, ConvArgs& a, const PackedConv& c, const Co
     a.bm = p.bm; a.bn = p.bn; a.generic = mode;
     a.splitk_ws = n->ws + n->splitk_off;
     a.zeros = n->ws + n->zeros_off;
+    a.tickets = (int*)(n->ws + n->tickets_off);
+    a.fused = p.fused;
 }
 
 int launch_conv_plan(ConvArgs& a, const ConvPlan& p, int groups, hipStream_t s) {
@@ -407,9 +419,10 @@ int launch_conv_plan(ConvArgs& a, const ConvPlan& p, int groups, hipStream_t s) 
     }
     a.bm = p.bm; a.bn = p.bn; a.nsplit = p.nsplit; a.mtiles = p.mtiles; a.ntiles = p.ntiles; a.groups = groups;
     a.bf3 = (p.bf3 && a.generic == 0) ? 1 : 0;
+    a.fused = (p.fused && p.nsplit > 1) ? 1 : 0;
     int rc = launch_conv(a, groups, s);
     if (rc) return rc;
-    if (a.nsplit > 1) rc = launch_conv_splitk_epilogue(a, groups, s);
+    if (a.nsplit > 1 && !a.fused) rc = launch_conv_splitk_epilogue(a, groups, s);
     return rc;
 }
 
@@ -469,7 +482,7 @@ int run_conv(fpc_net* n, ConvArgs& a, int groups, int ci, hipStream_t s) {
         (void)hipEventDestroy(e1);
         n->cplan[ci] = best;
     }
-    ConvPlan p = n ? n->cplan[ci] : ConvPlan{a.bm, a.bn, a.nsplit, a.mtiles, a.ntiles, 0, a.bf3};
+    ConvPlan p = n ? n->cplan[ci] : ConvPlan{a.bm, a.bn, a.nsplit, a.mtiles, a.ntiles, 0, a.bf3, a.fused};
     return launch_conv_plan(a, p, groups, s);
 }
 
@@ -739,14 +752,15 @@ extern "C" size_t fpc_conv2d_workspace_bytes(int B, int Ho, int Wo, int Cin, int
     size_t packed = ((size_t)Npad * Kpad + 63) / 64 * 64;
     size_t splitk = (size_t)32 * B * (cdiv(Ho * Wo, 128) * 128) * Npad;
     size_t wino = (size_t)16 * Cout * Cin + 64;      // + a zero page for the all-DMA Winograd form
-    return (packed + splitk + wino) * sizeof(float);
+    return (packed + splitk + wino + kConvTickets) * sizeof(float);
 }
 
 extern "C" int fpc_conv2d_plan(int B, int Ho, int Wo, int Cin, int Cout, int Kh, int Kw, int bm, int bn, int nsplit,
                                int* out4) {
     if (!out4) return FPC_EINVAL;
     int Kpad = cdiv(Cin * Kh * Kw, kConvBK) * kConvBK;
-    if (nsplit >= 1000) nsplit -= 1000;      // fpc_conv2d's split-precision hook does not change the tiling
+    if (nsplit >= 1000) nsplit -= 1000;      // fpc_conv2d's split-precision / two-launch hooks do not change the tiling
+    if (nsplit >= 100) nsplit -= 100;
     ConvPlan p = plan_conv(Ho * Wo, B, Cout, Kpad / kConvBK, 1, bm, bn, nsplit);
     if (nsplit <= -1 && nsplit >= -4) { p.wino = -nsplit; p.nsplit = nsplit; }
     out4[0] = p.bm; out4[1] = p.bn; out4[2] = p.nsplit; out4[3] = plan_gn_rows(p, Ho, Wo);
@@ -769,9 +783,12 @@ extern "C" int fpc_conv2d(const float* in, int64_t sb, int64_t sh, int64_t sw, i
     FPC_TRY(launch_pack_weight(w_oihw, packed, Cout, Cin, Cin, Kh, Kw, Kw, c.Npad, c.Kpad, s));
     int bf3 = 0;
     if (nsplit >= 1000) { bf3 = 1; nsplit -= 1000; }      // test hook: 1000 + split = split-precision matrix products
+    bool two_launch = false;
+    if (nsplit >= 100) { two_launch = true; nsplit -= 100; }      // test hook: 100 + split = split-K summed by k_conv_splitk_epilogue
     bool wino = nsplit <= -1 && nsplit >= -4;      // -1: 4 waves, -2: 8 waves, -3: 4 waves wave-private, -4: 8 waves all-DMA 3-stage
     ConvPlan p = plan_conv(Ho * Wo, B, Cout, c.Kpad / kConvBK, 1, wino ? 0 : bm, bn, wino ? 1 : nsplit);
     p.bf3 = bf3;
+    if (two_launch) p.fused = 0;
     int mode = (sc == 1 && Cin % kConvBK == 0 && Kh * Kw <= 32 && ((int64_t)Hi + 2 * pad) * sh * 4 < ((int64_t)1 << 31)) ? 0
                : (sc == 1 && Cin % 4 == 0 && sw % 4 == 0 && sh % 4 == 0 && sb % 4 == 0 && ((uintptr_t)in & 15) == 0) ? 2 : 1;
     fpc_net tmp;
@@ -782,6 +799,11 @@ extern "C" int fpc_conv2d(const float* in, int64_t sb, int64_t sh, int64_t sw, i
     fill_conv_args(&tmp, a, c, p, Hi, Wi, Ho, Wo, sb, sh, sw, sc, relu != 0, mode);
     a.p[0] = ConvPtrs{in, packed, out, scale, shift, res, up, gn_part};
     a.zeros = nullptr;
+    {   // arrival counters of the fused split-K form: behind the Winograd region, zeroed per call
+        float* tk = packed + tmp.splitk_off + (size_t)32 * B * (cdiv(Ho * Wo, 128) * 128) * c.Npad + (size_t)16 * Cout * Cin + 64;
+        a.tickets = (int*)tk;
+        if (p.fused && hipMemsetAsync(tk, 0, kConvTickets * sizeof(int), s) != hipSuccess) return FPC_ELAUNCH;
+    }
     if (wino && relu == 77) { a.dbg = gn_part; a.p[0].gn_part = nullptr; a.relu = 0; }
 #ifdef FPC_STAMP_IGEMM
     if (!wino && relu == 77) { a.dbg = gn_part; a.p[0].gn_part = nullptr; a.relu = 0; }

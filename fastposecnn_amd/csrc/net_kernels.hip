@@ -60,6 +60,24 @@ __device__ __forceinline__ f32x4 buf_load4(__amdgpu_buffer_rsrc_t r, unsigned vo
     return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, soff, 0));
 }
 
+// 16 bytes that another workgroup of the same launch reads (fused split-K): write-through stores / cache-bypassing loads
+// at agent scope (sc1), so that neither side needs a whole-L2 write-back or invalidate; ordered by the drain + ticket
+// of k_conv_igemm's epilogue.
+typedef __attribute__((address_space(1))) unsigned long long gmem_u64;
+__device__ __forceinline__ void store_wt128(float* p, f32x4 v) {
+    const float a0 = v[0], a1 = v[1], a2 = v[2], a3 = v[3];      // (bit_cast of a vector ELEMENT expression misbehaves: scalars first)
+    const unsigned long long lo = (unsigned long long)__builtin_bit_cast(unsigned, a0) | ((unsigned long long)__builtin_bit_cast(unsigned, a1) << 32);
+    const unsigned long long hi = (unsigned long long)__builtin_bit_cast(unsigned, a2) | ((unsigned long long)__builtin_bit_cast(unsigned, a3) << 32);
+    __hip_atomic_store((gmem_u64*)p, lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store((gmem_u64*)p + 1, hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ f32x4 load_wt128(const float* p) {
+    const unsigned long long lo = __hip_atomic_load((gmem_u64*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned long long hi = __hip_atomic_load((gmem_u64*)p + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return f32x4{__builtin_bit_cast(float, (unsigned)lo), __builtin_bit_cast(float, (unsigned)(lo >> 32)),
+                 __builtin_bit_cast(float, (unsigned)hi), __builtin_bit_cast(float, (unsigned)(hi >> 32))};
+}
+
 // a - b as two v_pk_add_f32 with negated second operand (the compiler splits a vector subtraction into four
 // v_sub_f32).  Same IEEE result as the scalar subtraction.
 __device__ __forceinline__ f32x4 sub_pk(f32x4 a, f32x4 b) {
@@ -170,6 +188,81 @@ constexpr int kLdsRow = kConvBK;
         }                                                                                                     \
     } while (0)
 
+// Epilogue of one lane's 4 rows (p0 + 8k) x 4 channels (n .. n+3) of a 32-row tile: folded BatchNorm / bias, residual,
+// FPN nearest-x2 add, ReLU, store, and the GroupNorm partial sums of the tile's 32 rows per channel.
+struct EpiGeom { int b, HoWo, Wo, Cout, Hu, Wu, P32, relu, lane; };
+__device__ __forceinline__ void conv_epilogue(const ConvPtrs& P, const EpiGeom& g, f32x4 v0, f32x4 v1, f32x4 v2, f32x4 v3, int p0, int n) {
+    const int b = g.b, HoWo = g.HoWo, Wo = g.Wo, Cout = g.Cout, Hu = g.Hu, Wu = g.Wu;
+    const f32x4 v[4] = {v0, v1, v2, v3};
+    f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};
+    if ((Cout & 3) == 0) {
+        const bool nv = n < Cout;
+        f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
+        if (nv && P.scale) sc = *reinterpret_cast<const f32x4*>(P.scale + n);
+        if (nv && P.shift) sh = *reinterpret_cast<const f32x4*>(P.shift + n);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            int p = p0 + 8 * k;
+            if (!(nv && p < HoWo)) continue;
+            f32x4 x = v[k];
+            if (P.scale) x = x * sc;
+            x = x + sh;
+            size_t o = ((size_t)b * HoWo + p) * Cout + n;
+            if (P.res) x += *reinterpret_cast<const f32x4*>(P.res + o);
+            if (P.up) {
+                int ho = p / Wo, wo = p - ho * Wo;
+                x += *reinterpret_cast<const f32x4*>(P.up + (((size_t)b * Hu + (ho >> 1)) * Wu + (wo >> 1)) * Cout + n);
+            }
+            if (g.relu) { x[0] = fmaxf(x[0], 0.f); x[1] = fmaxf(x[1], 0.f); x[2] = fmaxf(x[2], 0.f); x[3] = fmaxf(x[3], 0.f); }
+            *reinterpret_cast<f32x4*>(P.out + o) = x;
+            s1 += x;
+            s2 += x * x;
+        }
+    } else {                                           // any Cout: scalar accesses
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            int p = p0 + 8 * k;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                int ne = n + e;
+                if (!(ne < Cout && p < HoWo)) continue;
+                float x = v[k][e];
+                if (P.scale) x = x * P.scale[ne];
+                if (P.shift) x = x + P.shift[ne];
+                size_t o = ((size_t)b * HoWo + p) * Cout + ne;
+                if (P.res) x += P.res[o];
+                if (P.up) {
+                    int ho = p / Wo, wo = p - ho * Wo;
+                    x += P.up[(((size_t)b * Hu + (ho >> 1)) * Wu + (wo >> 1)) * Cout + ne];
+                }
+                if (g.relu) x = fmaxf(x, 0.f);
+                P.out[o] = x;
+                s1[e] += x;
+                s2[e] += x * x;
+            }
+        }
+    }
+    if (P.gn_part) {
+        // column sums over the tile's 32 rows: lanes with equal (lane & 7) hold the same channels
+#pragma unroll
+        for (int o = 8; o < 64; o <<= 1) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                s1[e] += __shfl_xor(s1[e], o, 64);
+                s2[e] += __shfl_xor(s2[e], o, 64);
+            }
+        }
+        if (g.lane < 8) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (n + e < Cout) {
+                    float* gp = P.gn_part + (((size_t)b * g.P32 + p0 / 32) * Cout + n + e) * 2;
+                    gp[0] = s1[e]; gp[1] = s2[e];
+                }
+        }
+    }
+}
+
 // (the 128x128 tiling keeps 64 accumulator + 64 staging registers per lane: one workgroup per CU, no spills)
 template <int BM, int BN, int MODE, bool BF3 = false>
 __global__ __launch_bounds__(256, (BM * BN >= 128 * 128) ? 1 : 2) void k_conv_igemm(const ConvArgs a) {
@@ -177,6 +270,7 @@ __global__ __launch_bounds__(256, (BM * BN >= 128 * 128) ? 1 : 2) void k_conv_ig
     constexpr int AR = BM / 32, BR = BN / 32;     // float4 rows staged per thread
     // f32 operands: 2 stages x (BM + BN) rows x 128 B;  split precision: 2 stages x 3 planes x (BM + BN) rows x 64 B
     __shared__ __attribute__((aligned(16))) float lds[BF3 ? 2 * (BM + BN) * 48 : 2 * (BM + BN) * kLdsRow];
+    __shared__ int s_last;
     static_assert(!BF3 || MODE == 0, "split precision rides on the fast loader");
 #ifdef FPC_STAMP_IGEMM      // diagnostic build (tools_dev/igemm_stamps.py): phase stamps per wave into a.dbg
     const long long st0 = clock64();
@@ -384,10 +478,13 @@ __global__ __launch_bounds__(256, (BM * BN >= 128 * 128) ? 1 : 2) void k_conv_ig
     constexpr int kTS = 36;                                   // floats per transposed row
     float* tp = lds + wave * 32 * kTS;
     const int trow = lane >> 3, tc4 = (lane & 7) * 4;         // rows trow + 8k (k < 4), channels tc4 .. tc4+3
-    const bool vec = (Cout & 3) == 0;
     const int Wu = Wo >> 1, Hu = a.Ho >> 1;
-    float* ws = nsplit > 1 ? a.splitk_ws + ((((size_t)grp * nsplit + sp) * nB + b) * ((size_t)mtiles * BM)) * Npad
-                           : nullptr;
+    // split-K: partials of split s at ws0 + s * ws_split; padded rows / columns exist
+    const size_t ws_split = (size_t)nB * mtiles * BM * Npad;
+    float* ws0 = nsplit > 1 ? a.splitk_ws + (((size_t)grp * nsplit * nB + b) * ((size_t)mtiles * BM)) * Npad : nullptr;
+    float* ws = ws0 ? ws0 + sp * ws_split : nullptr;
+    const bool fused = a.fused != 0;
+    const EpiGeom eg{b, HoWo, Wo, Cout, Hu, Wu, mtiles * (BM / 32), a.relu, lane};
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -401,81 +498,54 @@ __global__ __launch_bounds__(256, (BM * BN >= 128 * 128) ? 1 : 2) void k_conv_ig
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // reads done before the next tile overwrites the patch
             const int prow = m0 + wm * (BM / 2) + i * 32;
             const int n = n0 + wn * (BN / 2) + j * 32 + tc4;
-            if (ws) {                                          // split-K: raw partial sums, padded rows / columns exist
+            if (ws) {                                          // split-K: raw partial sums
+                if (fused) {                                   // read by another workgroup of this launch: write-through
 #pragma unroll
-                for (int k = 0; k < 4; ++k)
-                    *reinterpret_cast<f32x4*>(ws + (size_t)(prow + trow + 8 * k) * Npad + n) = v[k];
+                    for (int k = 0; k < 4; ++k) store_wt128(ws + (size_t)(prow + trow + 8 * k) * Npad + n, v[k]);
+                } else {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+                        *reinterpret_cast<f32x4*>(ws + (size_t)(prow + trow + 8 * k) * Npad + n) = v[k];
+                }
                 continue;
             }
-            f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};
-            if (vec) {
-                const bool nv = n < Cout;
-                f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
-                if (nv && P.scale) sc = *reinterpret_cast<const f32x4*>(P.scale + n);
-                if (nv && P.shift) sh = *reinterpret_cast<const f32x4*>(P.shift + n);
+            conv_epilogue(P, eg, v[0], v[1], v[2], v[3], prow + trow, n);
+        }
+    // Fused split-K: every workgroup has written its raw partial tile through to memory; it drains, and takes a ticket
+    // of its output tile.  The one that draws the last ticket sums ALL partials in split order (its own included: the
+    // sum does not depend on who arrives last; the same order as k_conv_splitk_epilogue) and applies the epilogue.
+    if (ws && fused) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (t == 0) {
+            int* tk = a.tickets + (((size_t)grp * nB + b) * mtiles + mt) * ntiles + nt;
+            const int got = __hip_atomic_fetch_add(tk, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (got == nsplit - 1) __hip_atomic_store(tk, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // for the next launch
+            s_last = got == nsplit - 1;
+        }
+        __syncthreads();
+        if (s_last) {
+#pragma unroll 1
+            for (int ij = 0; ij < TM * TN; ++ij) {
+                const int i = ij / TN, j = ij - i * TN;
+                const int prow = m0 + wm * (BM / 2) + i * 32;
+                const int n = n0 + wn * (BN / 2) + j * 32 + tc4;
+                const float* src = ws0 + (size_t)(prow + trow) * Npad + n;
+                f32x4 v[4];
 #pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    int p = prow + trow + 8 * k;
-                    if (!(nv && p < HoWo)) continue;
-                    f32x4 x = v[k];
-                    if (P.scale) x = x * sc;
-                    x = x + sh;
-                    size_t o = ((size_t)b * HoWo + p) * Cout + n;
-                    if (P.res) x += *reinterpret_cast<const f32x4*>(P.res + o);
-                    if (P.up) {
-                        int ho = p / Wo, wo = p - ho * Wo;
-                        x += *reinterpret_cast<const f32x4*>(P.up + (((size_t)b * Hu + (ho >> 1)) * Wu + (wo >> 1)) * Cout + n);
-                    }
-                    if (a.relu) { x[0] = fmaxf(x[0], 0.f); x[1] = fmaxf(x[1], 0.f); x[2] = fmaxf(x[2], 0.f); x[3] = fmaxf(x[3], 0.f); }
-                    *reinterpret_cast<f32x4*>(P.out + o) = x;
-                    s1 += x;
-                    s2 += x * x;
+                for (int k = 0; k < 4; ++k) v[k] = load_wt128(src + (size_t)(8 * k) * Npad);
+#pragma unroll 2
+                for (int q = 1; q < nsplit; ++q) {
+                    f32x4 u[4];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) u[k] = load_wt128(src + q * ws_split + (size_t)(8 * k) * Npad);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) v[k] += u[k];
                 }
-            } else {                                           // any Cout: scalar accesses
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    int p = prow + trow + 8 * k;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        int ne = n + e;
-                        if (!(ne < Cout && p < HoWo)) continue;
-                        float x = v[k][e];
-                        if (P.scale) x = x * P.scale[ne];
-                        if (P.shift) x = x + P.shift[ne];
-                        size_t o = ((size_t)b * HoWo + p) * Cout + ne;
-                        if (P.res) x += P.res[o];
-                        if (P.up) {
-                            int ho = p / Wo, wo = p - ho * Wo;
-                            x += P.up[(((size_t)b * Hu + (ho >> 1)) * Wu + (wo >> 1)) * Cout + ne];
-                        }
-                        if (a.relu) x = fmaxf(x, 0.f);
-                        P.out[o] = x;
-                        s1[e] += x;
-                        s2[e] += x * x;
-                    }
-                }
-            }
-            if (P.gn_part) {
-                // column sums over the tile's 32 rows: lanes with equal (lane & 7) hold the same channels
-#pragma unroll
-                for (int o = 8; o < 64; o <<= 1) {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        s1[e] += __shfl_xor(s1[e], o, 64);
-                        s2[e] += __shfl_xor(s2[e], o, 64);
-                    }
-                }
-                if (lane < 8) {
-                    int P32 = mtiles * (BM / 32);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e)
-                        if (n + e < Cout) {
-                            float* g = P.gn_part + (((size_t)b * P32 + prow / 32) * Cout + n + e) * 2;
-                            g[0] = s1[e]; g[1] = s2[e];
-                        }
-                }
+                conv_epilogue(P, eg, v[0], v[1], v[2], v[3], prow + trow, n);
             }
         }
+    }
 #ifdef FPC_STAMP_IGEMM
     if (a.dbg && lane == 0) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1052,6 +1122,8 @@ int launch_conv(const ConvArgs& a, int groups, hipStream_t s) {
                            ((long long)a.Hi + 2 * a.pad) * a.in_sh * 4 >= (1LL << 31)))
         return FPC_EINVAL;      // tap mask is 32 bits, lane offsets are 31 bits
     if ((long long)a.Npad * a.Kpad * 4 >= (1LL << 31)) return FPC_EINVAL;
+    if (a.nsplit > 1 && a.fused && (!a.tickets || (long long)groups * a.B * a.mtiles * a.ntiles > kConvTickets || a.Cout % 4 != 0))
+        return FPC_EINVAL;
     if (a.generic == 2 && (a.Cin % 4 != 0 || a.in_sc != 1 || a.in_sw % 4 != 0 || a.in_sh % 4 != 0 || a.in_sb % 4 != 0))
         return FPC_EINVAL;
     if (a.bm == 128 && a.bn == 128) launch_conv_t<128, 128>(a, groups, s);

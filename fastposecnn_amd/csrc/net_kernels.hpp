@@ -8,6 +8,7 @@ namespace fpc {
 constexpr int kMaxGroup = 4;      // the four FPN decoders run as one grouped launch
 constexpr int kConvBK = 32;       // K-step of the implicit GEMM (floats)
 constexpr int kConvNAlign = 128;  // packed weight rows are padded to a multiple of this
+constexpr int kConvTickets = 16384;   // arrival counters a plan's workspace holds (fused split-K needs one per output tile)
 
 struct ConvPtrs {
     const float* in;      // input activation
@@ -23,6 +24,9 @@ struct ConvPtrs {
 struct ConvArgs {
     ConvPtrs p[kMaxGroup];
     float* splitk_ws;     // [G][nsplit][B][mtiles*BM][Npad] raw partial sums (nsplit > 1)
+    int* tickets;         // fused split-K: one arrival counter per (group, image, m tile, n tile), zero between launches
+    int fused;            // nsplit > 1: 1 = the last workgroup to arrive at a tile sums the partials and applies the epilogue
+                          // inside k_conv_igemm; 0 = k_conv_splitk_epilogue does (a second launch)
     int B, Hi, Wi, Cin, Ho, Wo, Cout, Npad, Kh, Kw, stride, pad, K, Kpad;
     long long in_sb, in_sh, in_sw, in_sc;   // element strides of the input
     int relu, nsplit, mtiles, ntiles, ksteps, bm, bn, generic, groups;

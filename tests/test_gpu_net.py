@@ -86,6 +86,11 @@ CONV_CASES = [
     (1, 128, 16, 24, 128, 3, 1, 1, (64, 128, 1), "gn"),
     (2, 256, 15, 20, 128, 3, 1, 1, (64, 64, 4), "gn"),          # split-K + GroupNorm partials, ragged M (300)
     (1, 512, 15, 20, 512, 3, 1, 1, (0, 0, 0), "bn_relu_res"),   # planner picks split-K
+    # split-K summed by the second launch (nsplit = 100 + split; the default is the fused last-arriver form)
+    (2, 256, 15, 20, 128, 3, 1, 1, (64, 64, 104), "gn"),
+    (1, 512, 15, 20, 512, 3, 1, 1, (128, 64, 108), "bn_relu_res"),
+    (2, 256, 30, 40, 128, 3, 1, 1, (128, 128, 6), "gn"),         # fused, 128 x 128 tiles
+    (2, 64, 24, 32, 256, 1, 1, 0, (64, 128, 2), "bias_up"),      # fused, FPN lateral epilogue
     (2, 64, 24, 32, 256, 1, 1, 0, (0, 0, 0), "bias_up"),        # FPN lateral: 1x1 + bias + nearest-x2 add
     (1, 64, 24, 32, 128, 1, 2, 0, (0, 0, 0), "bn"),             # downsample 1x1 stride 2
     (2, 3, 64, 96, 64, 7, 2, 3, (0, 0, 0), "stem"),             # 7x7/2 on the NCHW image (generic loader)
@@ -152,6 +157,22 @@ def test_conv2d_vs_float64(lib, dev, case):
         s = gpart.double().sum(1)                                   # [B, Cout, 2] over the row tiles
         np.testing.assert_allclose(s[..., 0].numpy(), ref.sum((2, 3)).numpy(), rtol=1e-4, atol=1e-3)
         np.testing.assert_allclose(s[..., 1].numpy(), (ref * ref).sum((2, 3)).numpy(), rtol=1e-4, atol=1e-3)
+
+
+def test_fused_split_k_equals_two_launch_form_bitwise(lib, dev):
+    """The last-arriver fix-up sums the partials in split order, like k_conv_splitk_epilogue: the outputs of the two forms
+    agree bit for bit, run after run (the arrival counters are left at zero by every launch).  The GroupNorm partial sums
+    are reduced over a tile's rows in another order by the two kernels: equal to rounding."""
+    g = torch.Generator().manual_seed(77)
+    x = torch.randn((2, 256, 15, 20), generator=g)
+    w = torch.randn((128, 256, 3, 3), generator=g) / 48.0
+    res = torch.randn((2, 128, 15, 20), generator=g)
+    for bm, bn, ns in ((64, 64, 12), (128, 64, 3), (64, 128, 24)):
+        two, gp2, _ = _conv2d(dev, x, w, 1, 1, res=res, relu=True, gn=True, bm=bm, bn=bn, nsplit=100 + ns)
+        for _ in range(3):
+            one, gp1, plan = _conv2d(dev, x, w, 1, 1, res=res, relu=True, gn=True, bm=bm, bn=bn, nsplit=ns)
+            assert plan[2] == ns and torch.equal(one, two), plan
+            torch.testing.assert_close(gp1, gp2, rtol=1e-5, atol=1e-4)
 
 
 def _model(lib, dev, encoder, seed=0):
