@@ -73,6 +73,8 @@ _SIGNATURES = {
     "fpc_conv2d_plan": (_i, [_i, _i, _i, _i, _i, _i, _i, _i, _i, _i, ctypes.POINTER(_i)]),
     "fpc_conv2d": (_i, [_vp, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i,
                         _i, _i, _i, _i, _i, _vp, _sz, _vp]),
+    "fpc_conv2d_wgrad_workspace_bytes": (_sz, [_i, _i, _i, _i, _i, _i, _i]),
+    "fpc_conv2d_wgrad": (_i, [_vp, _i64, _i64, _i64, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
 }
 
 EXPORTED = tuple(_SIGNATURES)
@@ -91,7 +93,7 @@ def lib():
             fn = getattr(L, name)
             fn.restype = res
             fn.argtypes = args
-        if L.fpc_abi_version() != 6:
+        if L.fpc_abi_version() != 7:
             raise RuntimeError("fastposecnn_amd: libfpc_hip.so ABI version mismatch")
         _lib = L
     return _lib

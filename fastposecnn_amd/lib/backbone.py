@@ -24,15 +24,29 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 
+class Conv2d(nn.Conv2d):
+    """nn.Conv2d whose TRAINING-mode forward on a GPU runs on the native kernels, forward and backward
+    (lib/train_conv.py); evaluation goes through the engine's plan (or torch, on CPU) as before.  Same parameters and
+    state_dict names as nn.Conv2d."""
+
+    def forward(self, x):
+        if self.training and x.is_cuda and self.groups == 1 and self.dilation == (1, 1) and self.padding_mode == "zeros" \
+                and self.stride[0] == self.stride[1] and self.padding[0] == self.padding[1] and not isinstance(self.padding, str):
+            from fastposecnn_amd.lib import train_conv
+            if train_conv.ENABLED:
+                return train_conv.conv2d(x, self.weight, self.bias, self.stride[0], self.padding[0])
+        return super().forward(x)
+
+
 class BasicBlock(nn.Module):
     expansion = 1
 
     def __init__(self, inplanes, planes, stride=1, downsample=None):
         super().__init__()
-        self.conv1 = nn.Conv2d(inplanes, planes, 3, stride, 1, bias=False)
+        self.conv1 = Conv2d(inplanes, planes, 3, stride, 1, bias=False)
         self.bn1 = nn.BatchNorm2d(planes)
         self.relu = nn.ReLU(inplace=True)
-        self.conv2 = nn.Conv2d(planes, planes, 3, 1, 1, bias=False)
+        self.conv2 = Conv2d(planes, planes, 3, 1, 1, bias=False)
         self.bn2 = nn.BatchNorm2d(planes)
         self.downsample = downsample
         self.stride = stride
@@ -61,7 +75,7 @@ class ResNetEncoder(nn.Module):
         self._depth = depth
         self.out_channels = (in_channels, 64, 64, 128, 256, 512)
         self.inplanes = 64
-        self.conv1 = nn.Conv2d(in_channels, 64, 7, 2, 3, bias=False)
+        self.conv1 = Conv2d(in_channels, 64, 7, 2, 3, bias=False)
         self.bn1 = nn.BatchNorm2d(64)
         self.relu = nn.ReLU(inplace=True)
         self.maxpool = nn.MaxPool2d(3, 2, 1)
@@ -79,7 +93,7 @@ class ResNetEncoder(nn.Module):
     def _make_layer(self, planes, blocks, stride=1):
         downsample = None
         if stride != 1 or self.inplanes != planes:
-            downsample = nn.Sequential(nn.Conv2d(self.inplanes, planes, 1, stride, bias=False),
+            downsample = nn.Sequential(Conv2d(self.inplanes, planes, 1, stride, bias=False),
                                        nn.BatchNorm2d(planes))
         layers = [BasicBlock(self.inplanes, planes, stride, downsample)]
         self.inplanes = planes
@@ -143,7 +157,7 @@ class Conv3x3GNReLU(nn.Module):
         super().__init__()
         self.upsample = upsample
         self.block = nn.Sequential(
-            nn.Conv2d(in_channels, out_channels, (3, 3), stride=1, padding=1, bias=False),
+            Conv2d(in_channels, out_channels, (3, 3), stride=1, padding=1, bias=False),
             nn.GroupNorm(32, out_channels),
             nn.ReLU(inplace=True),
         )
@@ -158,7 +172,7 @@ class Conv3x3GNReLU(nn.Module):
 class FPNBlock(nn.Module):
     def __init__(self, pyramid_channels, skip_channels):
         super().__init__()
-        self.skip_conv = nn.Conv2d(skip_channels, pyramid_channels, kernel_size=1)
+        self.skip_conv = Conv2d(skip_channels, pyramid_channels, kernel_size=1)
 
     def forward(self, x, skip=None):
         x = F.interpolate(x, scale_factor=2, mode="nearest")
@@ -201,7 +215,7 @@ class FPNDecoder(nn.Module):
             raise ValueError(f"Encoder depth for FPN decoder cannot be less than 3, got {encoder_depth}.")
         encoder_channels = encoder_channels[::-1]
         encoder_channels = encoder_channels[:encoder_depth + 1]
-        self.p5 = nn.Conv2d(encoder_channels[0], pyramid_channels, kernel_size=1)
+        self.p5 = Conv2d(encoder_channels[0], pyramid_channels, kernel_size=1)
         self.p4 = FPNBlock(pyramid_channels, encoder_channels[1])
         self.p3 = FPNBlock(pyramid_channels, encoder_channels[2])
         self.p2 = FPNBlock(pyramid_channels, encoder_channels[3])
@@ -225,7 +239,7 @@ class FPNDecoder(nn.Module):
 
 class SegmentationHead(nn.Sequential):
     def __init__(self, in_channels, out_channels, kernel_size=3, activation=None, upsampling=1):
-        conv2d = nn.Conv2d(in_channels, out_channels, kernel_size=kernel_size, padding=kernel_size // 2)
+        conv2d = Conv2d(in_channels, out_channels, kernel_size=kernel_size, padding=kernel_size // 2)
         up = nn.UpsamplingBilinear2d(scale_factor=upsampling) if upsampling > 1 else nn.Identity()
         if activation is not None:
             raise ValueError("only activation=None is used by FastPoseCNN (pose_regressor.py:596)")

@@ -1,0 +1,128 @@
+"""Convolutions of the TRAINING step on the native kernels (BASELINE.json configs[4]).
+
+The reference trains through torch.nn.Conv2d, i.e. cuDNN forward and backward under autograd
+(F/lib/pose_regressor.py:709-743 inside Lightning's training_step).  Here a convolution in training mode is one
+autograd.Function over three native pieces, all on channel-last (NHWC) activations:
+
+  forward        fpc_conv2d: the inference engine's implicit-GEMM / Winograd kernels (csrc/net_kernels.hip), bias fused
+  data gradient  stride 1: the SAME kernels on the flipped, transposed weights (a convolution of dy);
+                 stride 2 (three encoder convolutions, their 1x1 shortcuts) and the 7x7 stem: aten's backward
+  weight gradient  fpc_conv2d_wgrad (csrc/conv_wgrad.hip): pixels-as-K GEMM on the f32 matrix cores, fixed-order
+                 split over the pixels; Cin % 64 != 0 (stem) or Cout % 4 != 0 (odd-width heads): aten's backward
+
+The tiling / Winograd form of a shape is chosen once, by timing the candidates on the first call with that shape (this
+synchronises: it happens in the warm-up steps).  Results are f32 products accumulated in f32, like the inference path.
+`ENABLED = False` (or FPC_TRAIN_NATIVE_CONV=0) returns every convolution to torch's own kernels.
+"""
+import os
+
+import torch
+
+from fastposecnn_amd import _native as nat
+
+ENABLED = bool(int(os.environ.get("FPC_TRAIN_NATIVE_CONV", "1")))
+_plan_cache = {}            # (device index, B, Cin, H, W, Cout, k, stride, pad) -> nsplit code of fpc_conv2d
+counters = {"fwd_native": 0, "dgrad_native": 0, "wgrad_native": 0, "dgrad_aten": 0, "wgrad_aten": 0}
+
+
+def _channels_last(t):
+    return t if t.stride(1) == 1 and t.is_contiguous(memory_format=torch.channels_last) else t.contiguous(memory_format=torch.channels_last)
+
+
+def _run(x, w, bias, stride, pad, code, out):
+    B, Cin, H, W = x.shape
+    Cout, _, Kh, Kw = w.shape
+    Ho, Wo = out.shape[2], out.shape[3]
+    L = nat.lib()
+    sb, sc, sh, sw = x.stride()
+    ws = nat.workspace("train_conv", x.device, L.fpc_conv2d_workspace_bytes(B, Ho, Wo, Cin, Cout, Kh, Kw))
+    nat.check(L.fpc_conv2d(x.data_ptr(), sb, sh, sw, sc, w.data_ptr(), None, nat.ptr(bias), None, None, out.data_ptr(), None,
+                           B, H, W, Cin, Cout, Kh, Kw, stride, pad, 0, 0, 0, code, ws.data_ptr(), ws.numel(), nat.stream()),
+              "fpc_conv2d (training)")
+
+
+def conv_nhwc(x, w, bias, stride, pad):
+    """x [B,Cin,H,W] channel-last, w OIHW contiguous -> [B,Cout,Ho,Wo] channel-last, on the engine's kernels."""
+    B, Cin, H, W = x.shape
+    Cout, _, Kh, Kw = w.shape
+    Ho, Wo = (H + 2 * pad - Kh) // stride + 1, (W + 2 * pad - Kw) // stride + 1
+    out = torch.empty((B, Cout, Ho, Wo), dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
+    key = (x.device.index, B, Cin, H, W, Cout, Kh, stride, pad)
+    code = _plan_cache.get(key)
+    if code is None:
+        cands = [0]
+        if Kh == 3 and Kw == 3 and stride == 1 and pad == 1 and Cin % 8 == 0 and Cout % 64 == 0:
+            cands += [-1, -2, -4]       # Winograd F(2x2,3x3): 4 waves, 8 waves, 8 waves all-DMA
+        best = (float("inf"), 0)
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+        for c in cands:
+            _run(x, w, bias, stride, pad, c, out)
+            ev[0].record()
+            for _ in range(3):
+                _run(x, w, bias, stride, pad, c, out)
+            ev[1].record()
+            ev[1].synchronize()
+            best = min(best, (ev[0].elapsed_time(ev[1]), c))
+        code = _plan_cache[key] = best[1]
+    _run(x, w, bias, stride, pad, code, out)
+    return out
+
+
+def _native_forward_ok(x, w):
+    return w.shape[1] % 32 == 0 and w.shape[2] == w.shape[3]
+
+
+class _Conv2dFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w, bias, stride, pad):
+        x = _channels_last(x)
+        w = w.contiguous()
+        ctx.stride, ctx.pad, ctx.has_bias = stride, pad, bias is not None
+        ctx.save_for_backward(x, w)
+        counters["fwd_native"] += 1
+        return conv_nhwc(x, w, bias, stride, pad)
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, w = ctx.saved_tensors
+        stride, pad = ctx.stride, ctx.pad
+        Cout, Cin, Kh, Kw = w.shape
+        gy = _channels_last(gy)
+        need_x, need_w = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+        gx = gw = gb = None
+        aten_x = need_x and not (stride == 1 and Cout % 32 == 0 and pad <= Kh - 1)
+        aten_w = need_w and not (Cin % 64 == 0 and Cout % 4 == 0)
+        if need_x and not aten_x:
+            # dx = conv(dy, W'), W'[ci][co][kh][kw] = W[co][ci][K-1-kh][K-1-kw], padding K-1-pad
+            w2 = w.flip(2, 3).transpose(0, 1).contiguous() if Kh > 1 else w.transpose(0, 1).contiguous()
+            gx = conv_nhwc(gy, w2, None, 1, Kh - 1 - pad)
+            counters["dgrad_native"] += 1
+        if need_w and not aten_w:
+            L = nat.lib()
+            B, _, H, W = x.shape
+            Ho, Wo = gy.shape[2], gy.shape[3]
+            gw = torch.empty_like(w)
+            sb, sc, sh, sw = x.stride()
+            ws = nat.workspace("train_wgrad", x.device, L.fpc_conv2d_wgrad_workspace_bytes(B, Ho, Wo, Cin, Cout, Kh, Kw))
+            nat.check(L.fpc_conv2d_wgrad(x.data_ptr(), sb, sh, sw, gy.data_ptr(), gw.data_ptr(), B, H, W, Cin, Cout, Kh, Kw, stride,
+                                         pad, ws.data_ptr(), ws.numel(), nat.stream()), "fpc_conv2d_wgrad")
+            counters["wgrad_native"] += 1
+        if aten_x or aten_w:
+            ax, aw, _ = torch.ops.aten.convolution_backward(gy, x, w, None, [stride, stride], [pad, pad], [1, 1], False, [0, 0], 1,
+                                                            [aten_x, aten_w, False])
+            if aten_x:
+                gx = ax; counters["dgrad_aten"] += 1
+            if aten_w:
+                gw = aw; counters["wgrad_aten"] += 1
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            gb = gy.sum((0, 2, 3))
+        return gx, gw, gb, None, None
+
+
+def conv2d(x, w, bias, stride, pad):
+    """Training-mode convolution: native when the shapes allow it, torch otherwise (same signature either way)."""
+    if ENABLED and x.is_cuda and x.dtype == torch.float32 and _native_forward_ok(x, w):
+        return _Conv2dFn.apply(x, w, bias, int(stride), int(pad))
+    if ENABLED and x.is_cuda and x.dim() == 4:
+        x = _channels_last(x)        # the stem: keeps the rest of the network channel-last
+    return torch.nn.functional.conv2d(x, w, bias, stride, pad)

@@ -43,7 +43,7 @@
 extern "C" {
 #endif
 
-#define FPC_ABI_VERSION 6
+#define FPC_ABI_VERSION 7
 
 #define FPC_OK 0
 #define FPC_EINVAL (-1)      /* bad argument (shape, null pointer, ...) */
@@ -306,6 +306,18 @@ int fpc_conv2d(const float* in, int64_t sb, int64_t sh, int64_t sw, int64_t sc, 
                const float* scale, const float* shift, const float* res, const float* up, float* out,
                float* gn_part, int B, int Hi, int Wi, int Cin, int Cout, int Kh, int Kw, int stride, int pad,
                int relu, int bm, int bn, int nsplit, void* ws, size_t ws_bytes, fpc_stream_t stream);
+
+/* Weight gradient of a convolution for the training step (BASELINE.json configs[4]; the reference leaves the
+ * convolutions' backward to cuDNN through autograd, F/lib/pose_regressor.py:709-743 under Lightning's backward).
+ * x: input [B,Hi,Wi,Cin] channel-last (channel stride 1; element strides sb, sh, sw multiples of 4; 16-byte aligned),
+ * dy: output gradient NHWC contiguous [B,Ho,Wo,Cout]; dw: OIHW contiguous [Cout,Cin,Kh,Kw], overwritten.
+ * Cin % 64 == 0 and Cout % 4 == 0 are required (FPC_EINVAL otherwise); any stride / padding.  Split over the pixels,
+ * summed in a fixed order: deterministic.  The data gradient of a stride-1 convolution is fpc_conv2d on the flipped,
+ * transposed weights (fastposecnn_amd/lib/train_conv.py). */
+size_t fpc_conv2d_wgrad_workspace_bytes(int B, int Ho, int Wo, int Cin, int Cout, int Kh, int Kw);
+int fpc_conv2d_wgrad(const float* x, int64_t sb, int64_t sh, int64_t sw, const float* dy, float* dw, int B, int Hi,
+                     int Wi, int Cin, int Cout, int Kh, int Kw, int stride, int pad, void* ws, size_t ws_bytes,
+                     fpc_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -307,3 +307,145 @@ def test_fused_mask_losses_match_torch_forms(monkeypatch):
     for a, b in zip(want, got):
         assert abs(float(a) - float(b)) <= 2e-6 * max(1.0, abs(float(a)))
     assert (xa.grad - xb.grad).abs().max().item() <= 2e-5 * xa.grad.abs().max().item()
+
+
+# ---- convolutions of the training step (lib/train_conv.py, csrc/conv_wgrad.hip) ------------------------------------------
+
+TRAIN_CONV_CASES = [
+    # B, Cin, H, W, Cout, k, stride, pad, bias
+    (2, 64, 30, 40, 64, 3, 1, 1, False),        # encoder block: Winograd candidates forward and for the data gradient
+    (2, 64, 30, 40, 128, 3, 2, 1, False),       # stride 2: data gradient through aten, weight gradient native
+    (2, 64, 30, 40, 128, 1, 2, 0, False),       # 1x1 shortcut, stride 2
+    (3, 128, 15, 20, 256, 1, 1, 0, True),       # FPN lateral: 1x1 + bias
+    (2, 256, 15, 20, 128, 3, 1, 1, False),      # decoder block
+    (1, 128, 17, 23, 7, 1, 1, 0, True),         # odd-width head: both gradients through aten
+    (1, 128, 17, 23, 24, 1, 1, 0, True),        # head with Cout % 4 == 0 but not % 32: weight gradient native, data gradient aten
+    (2, 64, 9, 11, 68, 3, 1, 1, True),          # Cout not a multiple of the 64-row tile, pixel count not a multiple of 32
+    (2, 256, 6, 8, 256, 3, 1, 1, False),        # the small maps of a 96 x 128 input: fewer pixels than one tile
+    (2, 512, 3, 4, 512, 3, 1, 1, False),
+    (2, 128, 12, 16, 128, 3, 1, 1, False),
+]
+
+
+@pytest.mark.parametrize("case", TRAIN_CONV_CASES, ids=lambda c: "x".join(str(v) for v in c))
+def test_training_conv_forward_and_gradients_vs_float64_autograd(case):
+    from fastposecnn_amd.lib import train_conv
+    B, Cin, H, W, Cout, k, stride, pad, has_bias = case
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(sum(case))
+    x = torch.randn((B, Cin, H, W), generator=g)
+    w = torch.randn((Cout, Cin, k, k), generator=g) / (Cin * k * k) ** 0.5
+    b = torch.randn(Cout, generator=g) if has_bias else None
+    xr, wr = x.double().requires_grad_(), w.double().requires_grad_()
+    br = b.double().requires_grad_() if has_bias else None
+    yr = torch.nn.functional.conv2d(xr, wr, br, stride, pad)
+    gy = torch.randn(yr.shape, generator=g)
+    yr.backward(gy.double())
+
+    xd, wd = x.to(dev).requires_grad_(), w.to(dev).requires_grad_()
+    bd = b.to(dev).requires_grad_() if has_bias else None
+    before = dict(train_conv.counters)
+    y = train_conv.conv2d(xd, wd, bd, stride, pad)
+    y.backward(gy.to(dev))
+    torch.cuda.synchronize()
+    assert train_conv.counters["fwd_native"] == before["fwd_native"] + 1           # not the torch fallback
+
+    def close(got, ref, what, rel):
+        err = (got.detach().cpu().double() - ref).abs().max().item()
+        assert err <= rel * max(1.0, ref.abs().max().item()), (what, err)
+
+    close(y, yr.detach(), "y", 2e-5)
+    close(xd.grad, xr.grad, "dx", 2e-5)
+    close(wd.grad, wr.grad, "dw", 1e-4)          # sums over B*Ho*Wo pixels in f32
+    if has_bias:
+        close(bd.grad, br.grad, "db", 1e-4)
+    native_w = Cin % 64 == 0 and Cout % 4 == 0
+    native_x = stride == 1 and Cout % 32 == 0
+    assert train_conv.counters["wgrad_native"] - before["wgrad_native"] == int(native_w)
+    assert train_conv.counters["dgrad_native"] - before["dgrad_native"] == int(native_x)
+
+
+def test_wgrad_is_deterministic_and_refuses_unsupported_shapes():
+    import ctypes
+    from fastposecnn_amd import _native as nat
+    L = nat.lib()
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(3)
+    B, Cin, H, W, Cout, k = 4, 64, 60, 80, 64, 3          # 9 tiles, 19200 pixels: a deep split
+    x = torch.randn((B, H, W, Cin), generator=g).to(dev)
+    dy = torch.randn((B, H, W, Cout), generator=g).to(dev)
+    ws = torch.empty(L.fpc_conv2d_wgrad_workspace_bytes(B, H, W, Cin, Cout, k, k), dtype=torch.uint8, device=dev)
+    outs = []
+    for _ in range(2):
+        dw = torch.full((Cout, Cin, k, k), float("nan"), device=dev)
+        nat.check(L.fpc_conv2d_wgrad(x.data_ptr(), H * W * Cin, W * Cin, Cin, dy.data_ptr(), dw.data_ptr(), B, H, W, Cin, Cout, k, k, 1, 1,
+                                     ws.data_ptr(), ws.numel(), nat.stream()), "wgrad")
+        outs.append(dw.clone())
+    torch.cuda.synchronize()
+    assert torch.equal(outs[0], outs[1]) and not torch.isnan(outs[0]).any()
+    rc = L.fpc_conv2d_wgrad(x.data_ptr(), H * W * Cin, W * Cin, Cin, dy.data_ptr(), outs[0].data_ptr(), B, H, W, 48, Cout, k, k, 1, 1,
+                            ws.data_ptr(), ws.numel(), nat.stream())
+    assert rc == -1                                        # FPC_EINVAL: Cin % 64 != 0
+    rc = L.fpc_conv2d_wgrad(x.data_ptr(), H * W * Cin, W * Cin, Cin, dy.data_ptr(), outs[0].data_ptr(), B, H, W, Cin, Cout, k, k, 1, 1,
+                            ws.data_ptr(), 16, nat.stream())
+    assert rc == -2                                        # FPC_EWORKSPACE
+
+
+def test_training_mode_model_uses_native_convolutions_and_matches_torch_path():
+    """One forward + backward of the whole network in training mode (BatchNorm on batch statistics): native convolutions
+    and the same model on torch's f32 kernels, each against the model in float64.  Two f32 implementations differ from
+    each other by rounding amplified through ~40 layers; the claim checked is that the native path is as close to the
+    float64 gradients as torch's own f32 path is."""
+    import fastposecnn_amd.lib as L
+    from fastposecnn_amd import config, synth
+    from fastposecnn_amd.lib import train_conv
+    dev = torch.device("cuda:0")
+    hp = config.HEAD_TRAINING()
+    hp.RUNTIME_TIMING = False
+    torch.manual_seed(0)
+    model = L.pose_regressor.MODELS[hp.MODEL].load_from_ckpt(None, hp).to(dev).train()
+    for m in model.modules():
+        if isinstance(m, torch.nn.Dropout2d):
+            m.p = 0.0                                      # the passes must see the same network
+        # ReLU's derivative jumps at 0: a pre-activation within rounding of 0 gets another mask in another f32
+        # implementation and the gradients downstream differ by O(1) for that unit (seen at encoder.layer3.0, while every
+        # convolution agreed with aten to 1e-6 on identical inputs: tools_dev/train_conv_check.py).  A smooth activation
+        # keeps the comparison about the arithmetic of the convolutions.
+        for name, child in list(m.named_children()):
+            if isinstance(child, torch.nn.ReLU):
+                setattr(m, name, torch.nn.Softplus())
+    x = torch.stack([synth.make_image(i, 96, 128) for i in range(2)]).to(dev)
+    res = {}
+    for tag in ("native", "torch32", "torch64"):
+        train_conv.ENABLED = tag == "native"
+        try:
+            if tag == "torch64":
+                model = model.double()
+                x = x.double()
+            model.zero_grad(set_to_none=True)
+            before = dict(train_conv.counters)
+            out = model.pure_model_forward(x)
+            loss = sum(v.square().mean() for v in out.values())
+            loss.backward()
+            torch.cuda.synchronize()
+            used = {k: train_conv.counters[k] - before[k] for k in before}
+            res[tag] = (loss.item(), {k: v.detach().double() for k, v in out.items()},
+                        {n: p.grad.detach().double() for n, p in model.named_parameters() if p.grad is not None}, used)
+        finally:
+            train_conv.ENABLED = True
+    ln, on, gn, used = res["native"]
+    lt, ot, gt, unused = res["torch32"]
+    lr, orf, gr, _ = res["torch64"]
+    assert used["fwd_native"] >= 50 and used["wgrad_native"] >= 45 and used["dgrad_native"] >= 40, used
+    assert unused["fwd_native"] == 0
+    assert abs(ln - lr) <= 1e-5 * max(1.0, abs(lr))
+    for k in orf:
+        tol = 1e-4 * max(1.0, orf[k].abs().max().item())
+        assert (on[k] - orf[k]).abs().max().item() <= tol, k
+    assert set(gn) == set(gr)
+    err_n = err_t = 0.0
+    for n in gr:
+        scale = max(gr[n].abs().max().item(), 1e-12)
+        err_n = max(err_n, (gn[n] - gr[n]).abs().max().item() / scale)
+        err_t = max(err_t, (gt[n] - gr[n]).abs().max().item() / scale)
+    assert err_n <= max(2.0 * err_t, 1e-4), (err_n, err_t)
