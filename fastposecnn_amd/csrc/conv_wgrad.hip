@@ -8,9 +8,9 @@
 // As a GEMM: M = Cout, N = Cin (per kernel tap), K = B*Ho*Wo pixels.  Both operands are NHWC, i.e. K-major: a pixel's
 // channels are one contiguous row, so a K-step of 32 pixels is staged as [32][64] rows in LDS exactly as it lies in
 // memory, and the 32x32x2 MFMA operands (lane l: row l % 32 of the tile, k = l / 32) are read as 128-byte row segments.
-// One workgroup = one (tap, 64 output channels, 64 input channels) tile over a slice of the pixels (split-K: the early
-// layers have 9 tiles and 150 000 pixels); k_wgrad_reduce sums the slices in slice order and writes OIHW.
-// 256 threads = 2 x 2 waves, a 32 x 32 block of the tile each.  Double-buffered LDS, the next K-step's global loads in
+// One workgroup = one (tap, 64 or 128 output channels, 64 or 128 input channels) tile over a slice of the pixels (split-K:
+// the early layers have 9 tiles and 150 000 pixels); k_wgrad_reduce sums the slices in slice order and writes OIHW.
+// 256 threads = 2 x 2 waves, one or two 32 x 32 blocks of the tile per wave and side.  Double-buffered LDS, the next K-step's global loads in
 // flight under the current step's MFMAs, one barrier per step.
 #include <algorithm>
 
@@ -22,7 +22,6 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int kWgBK = 32;         // pixels per K-step
-constexpr int kWgRow = 68;        // floats per LDS row (64 + 4: consecutive pixels start 4 banks apart)
 
 struct WgradArgs {
     const float* x;       // input activation, channel-last (element strides sb, sh, sw; channel stride 1)
@@ -30,11 +29,18 @@ struct WgradArgs {
     float* part;          // [nsplit][taps][Cout][Cin] partial sums
     long long sb, sh, sw;
     int B, Hi, Wi, Cin, Ho, Wo, Cout, Kh, Kw, stride, pad;
+    int bm, bn;                                   // tile: output channels x input channels (64 or 128 each)
     int mtiles, ntiles, nsplit, ksteps, per;      // per = K-steps per slice
 };
 
+// TM x TN blocks of 32 x 32 per wave: the workgroup tile is (64 TM) x (64 TN).  The 128-wide forms halve the LDS reads
+// and the global bytes per MFMA; layers with 64 channels on a side keep the 64-wide form for that side.
+template <int TM, int TN>
 __global__ __launch_bounds__(256, 2) void k_conv_wgrad(const WgradArgs a) {
-    __shared__ __attribute__((aligned(16))) float lds[2][2][kWgBK * kWgRow];      // [buffer][A | B][pixel][channel]
+    constexpr int BM = 64 * TM, BN = 64 * TN;
+    constexpr int RA = BM + 4, RB = BN + 4;       // floats per LDS row: consecutive pixels start 4 banks apart
+    constexpr int NA = BM / 32, NB = BN / 32;     // float4 loads per thread and K-step (32 pixels x BM / 4 float4 over 256 threads)
+    __shared__ __attribute__((aligned(16))) float lds[2 * kWgBK * (RA + RB)];      // [buffer][A rows | B rows]
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int wm = wave >> 1, wn = wave & 1, li = lane & 31, lh = lane >> 5;
     int bid = blockIdx.x;
@@ -43,42 +49,64 @@ __global__ __launch_bounds__(256, 2) void k_conv_wgrad(const WgradArgs a) {
     const int tap = bid % (a.Kh * a.Kw);
     const int sp = bid / (a.Kh * a.Kw);
     const int kh = tap / a.Kw, kw = tap - kh * a.Kw;
-    const int m0 = mt * 64, n0 = nt * 64;
+    const int m0 = mt * BM, n0 = nt * BN;
     const int HoWo = a.Ho * a.Wo;
     const long long P = (long long)a.B * HoWo;
     const int ks0 = sp * a.per, ks1 = min(a.ksteps, ks0 + a.per);
 
-    // staging: thread (r, q) owns pixels r and r + 16 of the K-step and the float4 at channel 4q of both operands
-    const int r = t >> 4, q = t & 15;
-    const bool a_col = m0 + 4 * q < a.Cout;        // Cout % 4 == 0: a float4 is inside or outside as a whole
-    f32x4 ra[2], rb[2];
+    // staging: A rows are BM / 4 float4 wide: thread t owns float4 column qa = t % (BM / 4) of pixels ra0 + i * (1024 / BM)
+    constexpr int QA = BM / 4, QB = BN / 4, SA = 256 / QA, SB = 256 / QB;
+    const int qa = t % QA, ra0 = t / QA, qb = t % QB, rb0 = t / QB;
+    const bool a_col = m0 + 4 * qa < a.Cout;        // Cout % 4 == 0: a float4 is inside or outside as a whole
+    const bool b_col = n0 + 4 * qb < a.Cin;
+    f32x4 ra[NA], rb[NB];
     const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    // pixel walk of the B rows: (image, row, column) of pixel ks0 * 32 + rb0 + SB * i, advanced by 32 pixels per K-step
+    // with adds and compares (a division per row and step costs as many vector cycles as the step's MFMAs)
+    int pb[NB], py[NB], px[NB];
+    const int step_y = kWgBK / a.Wo, step_x = kWgBK - step_y * a.Wo;
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+        const long long p = (long long)ks0 * kWgBK + rb0 + SB * i;
+        pb[i] = (int)(p / HoWo);
+        const int rem = (int)(p - (long long)pb[i] * HoWo);
+        py[i] = rem / a.Wo; px[i] = rem - py[i] * a.Wo;
+    }
+    const float* a_ptr = a.dy + ((long long)ks0 * kWgBK + ra0) * a.Cout + m0 + 4 * qa;      // + SA * i rows; + 32 rows per step
+    long long a_left = P - ((long long)ks0 * kWgBK + ra0);                                     // rows left from this thread's first
+    // MUST be issued for consecutive K-steps ks0, ks0 + 1, ... (it advances the walk)
 #define FPC_WG_LOAD(KS)                                                                                       \
     do {                                                                                                      \
-        _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                       \
-            const long long p = (long long)(KS) * kWgBK + r + 16 * i;                                         \
-            ra[i] = zero; rb[i] = zero;                                                                       \
-            if (p < P) {                                                                                      \
-                if (a_col) ra[i] = *reinterpret_cast<const f32x4*>(a.dy + p * a.Cout + m0 + 4 * q);           \
-                const int b = (int)(p / HoWo), rem = (int)(p - (long long)b * HoWo);                          \
-                const int ho = rem / a.Wo, wo = rem - ho * a.Wo;                                              \
-                const int hi = ho * a.stride + kh - a.pad, wi = wo * a.stride + kw - a.pad;                   \
-                if (hi >= 0 && hi < a.Hi && wi >= 0 && wi < a.Wi)                                             \
-                    rb[i] = *reinterpret_cast<const f32x4*>(a.x + b * a.sb + hi * a.sh + wi * a.sw + n0 + 4 * q); \
-            }                                                                                                 \
+        _Pragma("unroll") for (int i = 0; i < NA; ++i)                                                        \
+            ra[i] = (SA * i < a_left && a_col) ? *reinterpret_cast<const f32x4*>(a_ptr + (long long)(SA * i) * a.Cout) : zero; \
+        a_ptr += (long long)kWgBK * a.Cout; a_left -= kWgBK;                                                  \
+        _Pragma("unroll") for (int i = 0; i < NB; ++i) {                                                      \
+            rb[i] = zero;                                                                                     \
+            const int hi = py[i] * a.stride + kh - a.pad, wi = px[i] * a.stride + kw - a.pad;                 \
+            if (pb[i] < a.B && b_col && hi >= 0 && hi < a.Hi && wi >= 0 && wi < a.Wi)                         \
+                rb[i] = *reinterpret_cast<const f32x4*>(a.x + pb[i] * a.sb + hi * a.sh + wi * a.sw + n0 + 4 * qb); \
+            px[i] += step_x; py[i] += step_y;                                                                 \
+            if (px[i] >= a.Wo) { px[i] -= a.Wo; ++py[i]; }                                                    \
+            while (py[i] >= a.Ho) { py[i] -= a.Ho; ++pb[i]; }                                                 \
         }                                                                                                     \
     } while (0)
 #define FPC_WG_STORE(BUF)                                                                                     \
     do {                                                                                                      \
-        _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                       \
-            *reinterpret_cast<f32x4*>(&lds[BUF][0][(r + 16 * i) * kWgRow + 4 * q]) = ra[i];                   \
-            *reinterpret_cast<f32x4*>(&lds[BUF][1][(r + 16 * i) * kWgRow + 4 * q]) = rb[i];                   \
-        }                                                                                                     \
+        float* As_ = lds + (BUF) * kWgBK * (RA + RB);                                                         \
+        float* Bs_ = As_ + kWgBK * RA;                                                                        \
+        _Pragma("unroll") for (int i = 0; i < NA; ++i)                                                        \
+            *reinterpret_cast<f32x4*>(As_ + (ra0 + SA * i) * RA + 4 * qa) = ra[i];                            \
+        _Pragma("unroll") for (int i = 0; i < NB; ++i)                                                        \
+            *reinterpret_cast<f32x4*>(Bs_ + (rb0 + SB * i) * RB + 4 * qb) = rb[i];                            \
     } while (0)
 
-    f32x16 acc;
+    f32x16 acc[TM][TN];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     if (ks0 < ks1) {
         FPC_WG_LOAD(ks0);
@@ -88,13 +116,27 @@ __global__ __launch_bounds__(256, 2) void k_conv_wgrad(const WgradArgs a) {
     for (int ks = ks0; ks < ks1; ++ks) {
         const int buf = (ks - ks0) & 1;
         if (ks + 1 < ks1) FPC_WG_LOAD(ks + 1);
-        const float* As = &lds[buf][0][lh * kWgRow + wm * 32 + li];
-        const float* Bs = &lds[buf][1][lh * kWgRow + wn * 32 + li];
-        float fa[16], fb[16];
+        const float* As = lds + buf * kWgBK * (RA + RB) + lh * RA + wm * (BM / 2) + li;
+        const float* Bs = lds + buf * kWgBK * (RA + RB) + kWgBK * RA + lh * RB + wn * (BN / 2) + li;
+        // 4 pixel pairs at a time: their fragments are read before the MFMAs that use them are issued
 #pragma unroll
-        for (int kk = 0; kk < 16; ++kk) { fa[kk] = As[2 * kk * kWgRow]; fb[kk] = Bs[2 * kk * kWgRow]; }
+        for (int k4 = 0; k4 < 16; k4 += 4) {
+            float fa[4][TM], fb[4][TN];
 #pragma unroll
-        for (int kk = 0; kk < 16; ++kk) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[kk], fb[kk], acc, 0, 0, 0);
+            for (int kk = 0; kk < 4; ++kk) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i) fa[kk][i] = As[2 * (k4 + kk) * RA + 32 * i];
+#pragma unroll
+                for (int j = 0; j < TN; ++j) fb[kk][j] = Bs[2 * (k4 + kk) * RB + 32 * j];
+            }
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[kk][i], fb[kk][j], acc[i][j], 0, 0, 0);
+        }
         if (ks + 1 < ks1) FPC_WG_STORE(buf ^ 1);
         __syncthreads();
     }
@@ -103,31 +145,47 @@ __global__ __launch_bounds__(256, 2) void k_conv_wgrad(const WgradArgs a) {
 
     // C/D layout: column (input channel) = lane & 31, row (output channel) = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
     float* out = a.part + ((size_t)sp * a.Kh * a.Kw + tap) * ((size_t)a.Cout * a.Cin);
-    const int ci = n0 + wn * 32 + li;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-        const int co = m0 + wm * 32 + (i & 3) + 8 * (i >> 2) + 4 * lh;
-        if (co < a.Cout) out[(size_t)co * a.Cin + ci] = acc[i];
-    }
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int ci = n0 + wn * (BN / 2) + 32 * j + li;
+            if (ci >= a.Cin) continue;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = m0 + wm * (BM / 2) + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                if (co < a.Cout) out[(size_t)co * a.Cin + ci] = acc[i][j][r];
+            }
+        }
 }
 
-// dw[co][ci][tap] = sum over slices (in slice order) of part[slice][tap][co][ci]; one thread per (co, ci), all taps
+// dw[co][ci][tap] = sum over slices (in slice order) of part[slice][tap][co][ci]; one thread per (tap, co, ci), four
+// independent partial sums per thread would change the order: the loop is kept sequential (deterministic, and the slices
+// are few once the tiles are large)
 __global__ __launch_bounds__(256) void k_wgrad_reduce(const float* __restrict__ part, float* __restrict__ dw, int nsplit,
                                                       int taps, int Cout, int Cin) {
     const size_t cc = (size_t)Cout * Cin;
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const int tap = blockIdx.y;
     if (i >= cc) return;
-    for (int tap = 0; tap < taps; ++tap) {
-        const float* src = part + (size_t)tap * cc + i;
-        float s = 0.f;
-        for (int sp = 0; sp < nsplit; ++sp) s += src[(size_t)sp * taps * cc];
-        dw[i * taps + tap] = s;
+    const float* src = part + (size_t)tap * cc + i;
+    const size_t step = (size_t)taps * cc;
+    float s = 0.f;
+    int sp = 0;
+    for (; sp + 4 <= nsplit; sp += 4) {          // four loads in flight, summed in slice order
+        const float v0 = src[(size_t)sp * step], v1 = src[(size_t)(sp + 1) * step], v2 = src[(size_t)(sp + 2) * step],
+                    v3 = src[(size_t)(sp + 3) * step];
+        s += v0; s += v1; s += v2; s += v3;
     }
+    for (; sp < nsplit; ++sp) s += src[(size_t)sp * step];
+    dw[i * taps + tap] = s;
 }
 
 static void wgrad_plan(int B, int Ho, int Wo, int Cin, int Cout, int taps, WgradArgs& a) {
-    a.mtiles = cdiv(Cout, 64);
-    a.ntiles = Cin / 64;
+    a.bm = Cout > 64 ? 128 : 64;
+    a.bn = Cin > 64 ? 128 : 64;
+    a.mtiles = cdiv(Cout, a.bm);
+    a.ntiles = cdiv(Cin, a.bn);
     const long long P = (long long)B * Ho * Wo;
     a.ksteps = (int)((P + kWgBK - 1) / kWgBK);
     const long long tiles = (long long)taps * a.mtiles * a.ntiles;
@@ -171,11 +229,14 @@ extern "C" int fpc_conv2d_wgrad(const float* x, int64_t sb, int64_t sh, int64_t 
     hipStream_t s = (hipStream_t)stream;
     const long long grid = (long long)a.nsplit * Kh * Kw * a.mtiles * a.ntiles;
     if (grid > 0x7FFFFFFFLL) return FPC_EINVAL;
-    hipLaunchKernelGGL(k_conv_wgrad, dim3((unsigned)grid), dim3(256), 0, s, a);
+    if (a.bm == 128 && a.bn == 128) hipLaunchKernelGGL((k_conv_wgrad<2, 2>), dim3((unsigned)grid), dim3(256), 0, s, a);
+    else if (a.bm == 128) hipLaunchKernelGGL((k_conv_wgrad<2, 1>), dim3((unsigned)grid), dim3(256), 0, s, a);
+    else if (a.bn == 128) hipLaunchKernelGGL((k_conv_wgrad<1, 2>), dim3((unsigned)grid), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((k_conv_wgrad<1, 1>), dim3((unsigned)grid), dim3(256), 0, s, a);
     int rc = check_launch();
     if (rc) return rc;
     const size_t cc = (size_t)Cout * Cin;
-    hipLaunchKernelGGL(k_wgrad_reduce, dim3((unsigned)((cc + 255) / 256)), dim3(256), 0, s, (const float*)ws, dw, a.nsplit, Kh * Kw,
-                       Cout, Cin);
+    hipLaunchKernelGGL(k_wgrad_reduce, dim3((unsigned)((cc + 255) / 256), (unsigned)(Kh * Kw)), dim3(256), 0, s, (const float*)ws, dw,
+                       a.nsplit, Kh * Kw, Cout, Cin);
     return check_launch();
 }

@@ -38,6 +38,24 @@ class Conv2d(nn.Conv2d):
         return super().forward(x)
 
 
+def _upsample_bilinear(x, scale, out_nchw=False):
+    """Bilinear, align_corners=True.  Under autograd on a GPU (the training step) the native forward / backward kernels of
+    lib/train_conv.py; plain torch otherwise (inference goes through the engine's plan and never gets here)."""
+    if x.is_cuda and torch.is_grad_enabled() and x.requires_grad:
+        from fastposecnn_amd.lib import train_conv
+        return train_conv.upsample_bilinear(x, scale, out_nchw)
+    return F.interpolate(x, scale_factor=scale, mode="bilinear", align_corners=True)
+
+
+class UpsamplingBilinear2d(nn.UpsamplingBilinear2d):
+    """nn.UpsamplingBilinear2d of the heads; the training step's forward / backward run natively (NCHW result)."""
+
+    def forward(self, x):
+        if float(self.scale_factor) in (2.0, 4.0):
+            return _upsample_bilinear(x, int(self.scale_factor), out_nchw=True)
+        return super().forward(x)
+
+
 class BasicBlock(nn.Module):
     expansion = 1
 
@@ -165,7 +183,7 @@ class Conv3x3GNReLU(nn.Module):
     def forward(self, x):
         x = self.block(x)
         if self.upsample:
-            x = F.interpolate(x, scale_factor=2, mode="bilinear", align_corners=True)
+            x = _upsample_bilinear(x, 2)
         return x
 
 
@@ -240,7 +258,7 @@ class FPNDecoder(nn.Module):
 class SegmentationHead(nn.Sequential):
     def __init__(self, in_channels, out_channels, kernel_size=3, activation=None, upsampling=1):
         conv2d = Conv2d(in_channels, out_channels, kernel_size=kernel_size, padding=kernel_size // 2)
-        up = nn.UpsamplingBilinear2d(scale_factor=upsampling) if upsampling > 1 else nn.Identity()
+        up = UpsamplingBilinear2d(scale_factor=upsampling) if upsampling > 1 else nn.Identity()
         if activation is not None:
             raise ValueError("only activation=None is used by FastPoseCNN (pose_regressor.py:596)")
         super().__init__(conv2d, up, nn.Identity())

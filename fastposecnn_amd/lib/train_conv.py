@@ -126,3 +126,43 @@ def conv2d(x, w, bias, stride, pad):
     if ENABLED and x.is_cuda and x.dim() == 4:
         x = _channels_last(x)        # the stem: keeps the rest of the network channel-last
     return torch.nn.functional.conv2d(x, w, bias, stride, pad)
+
+
+# ---- bilinear upsampling (align_corners = True): the x2 of the segmentation blocks, the x4 of the heads ----------------
+
+class _UpBilinearFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, scale, out_nhwc):
+        B, C, h, w = x.shape
+        fmt = torch.channels_last if out_nhwc else torch.contiguous_format
+        out = torch.empty((B, C, h * scale, w * scale), dtype=torch.float32, device=x.device, memory_format=fmt)
+        sb, sc, sh, sw = x.stride()
+        L = nat.lib()
+        nat.check(L.fpc_upsample_bilinear_fwd(x.data_ptr(), sb, sc, sh, sw, out.data_ptr(), B, C, h, w, scale, int(out_nhwc), nat.stream()),
+                  "fpc_upsample_bilinear_fwd")
+        ctx.scale, ctx.shape = scale, (B, C, h, w)
+        ctx.in_nhwc = C > 1 and x.stride(1) == 1 and x.is_contiguous(memory_format=torch.channels_last)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        B, C, h, w = ctx.shape
+        fmt = torch.channels_last if ctx.in_nhwc else torch.contiguous_format
+        gx = torch.empty((B, C, h, w), dtype=torch.float32, device=g.device, memory_format=fmt)
+        sb, sc, sh, sw = g.stride()
+        L = nat.lib()
+        nat.check(L.fpc_upsample_bilinear_bwd(g.data_ptr(), sb, sc, sh, sw, gx.data_ptr(), B, C, h, w, ctx.scale, int(ctx.in_nhwc), nat.stream()),
+                  "fpc_upsample_bilinear_bwd")
+        return gx, None, None
+
+
+def upsample_bilinear(x, scale, out_nchw=False):
+    """F.interpolate(x, scale_factor=scale, mode='bilinear', align_corners=True) on the native kernels (forward and backward)
+    for f32 GPU tensors with scale 2 or 4; torch otherwise.  The result keeps x's memory format unless out_nchw (the heads:
+    full-resolution logits in the layout the losses and the post-network kernels read)."""
+    if ENABLED and x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and scale in (2, 4) and x.shape[0] * x.shape[1] <= 65535:
+        nhwc = (not out_nchw) and x.shape[1] > 1 and x.stride(1) == 1 and x.is_contiguous(memory_format=torch.channels_last)
+        if any(s < 0 for s in x.stride()) or x.stride(1) == 0:
+            x = x.contiguous()
+        return _UpBilinearFn.apply(x, int(scale), bool(nhwc))
+    return torch.nn.functional.interpolate(x, scale_factor=scale, mode="bilinear", align_corners=True)

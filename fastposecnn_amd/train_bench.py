@@ -2,8 +2,11 @@
 batch 8 per GPU (64 on 8 GPUs), forward + HEAD_TRAINING losses + backward + gradient reduction + optimiser step.
 
 What runs where (stated in the JSON line as well):
-  * encoder / decoder / head convolutions, forward and backward: torch modules, i.e. MIOpen / rocBLAS through autograd —
-    the native engine (csrc/net*.hip) is inference-only until a native backward exists;
+  * encoder / decoder / head convolutions: lib/train_conv.py — forward on the engine's implicit-GEMM / Winograd kernels,
+    data gradient of the stride-1 convolutions on the same kernels (flipped weights), weight gradient on
+    csrc/conv_wgrad.hip; aten (MIOpen) keeps the 7x7 stem, the data gradient of the stride-2 convolutions and the
+    odd-width heads; bilinear upsampling forward / backward on csrc/upsample.hip; BatchNorm / GroupNorm / ReLU / adds: torch
+    (FPC_TRAIN_NATIVE_CONV=0 returns every convolution and upsampling to torch: the A/B this file's numbers come with);
   * everything after the logits, forward: the inference kernels (class compression, connected components, aggregation,
     RANSAC vote, RT); backward: csrc/train.hip through lib/train_functions.py;
   * matching (fpc_mask_iou) and the loss arithmetic of F/lib/pose_regressor.py:188-307 with lib/loss.py;
@@ -50,6 +53,16 @@ def _ground_truth(model, cat, symmetric_classes=(1, 2, 4)):
         sym |= (gt["class_ids"] == c).long()
     gt["symmetric_ids"] = sym
     return gt
+
+
+def _conv_note():
+    from fastposecnn_amd.lib import train_conv
+    if not train_conv.ENABLED:
+        return "torch modules (MIOpen / rocBLAS) forward and backward (FPC_TRAIN_NATIVE_CONV=0)"
+    c = train_conv.counters
+    return ("native: forward fpc_conv2d (implicit GEMM / Winograd), data gradient of stride-1 convolutions on the same kernels, weight "
+            "gradient fpc_conv2d_wgrad, bilinear upsampling fpc_upsample_bilinear_fwd/bwd; aten for the 7x7 stem, stride-2 data "
+            f"gradients and odd-width heads (calls so far: {dict(c)})")
 
 
 def main(args):
@@ -175,7 +188,7 @@ def run(args, quiet=False):
                        "trainable_parameters": n_param, "gradient_bytes": 4 * opt.total, "buckets": len(opt.buckets),
                        "optimizer": "Lookahead(RAdam) k=5 alpha=0.5, lr 1e-5, weight decay 3e-4, clip 0.15; native shard kernel",
                        "optimizer_state_bytes_per_rank": opt.state_bytes(),
-                       "convolutions": "torch modules (MIOpen / rocBLAS) forward and backward: the native engine has no backward yet",
+                       "convolutions": _conv_note(),
                        "post_network": "HIP kernels forward (inference path) and backward (csrc/train.hip)"},
             "stages_ms": stages,
             "step_check": {"total_loss": round(float(last["total"]), 6), "losses": losses, "predicted_instances": last["n_pred"],

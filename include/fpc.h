@@ -319,6 +319,15 @@ int fpc_conv2d_wgrad(const float* x, int64_t sb, int64_t sh, int64_t sw, const f
                      int Wi, int Cin, int Cout, int Kh, int Kw, int stride, int pad, void* ws, size_t ws_bytes,
                      fpc_stream_t stream);
 
+/* Bilinear upsampling with align_corners = True (the x2 steps of the FPN segmentation blocks and the x4 of the heads:
+ * torch.nn.functional.interpolate / nn.UpsamplingBilinear2d in the reference's network, F/lib/pose_regressor.py:608-666),
+ * forward and its exact adjoint, ATen's source-index arithmetic.  scale: 2 or 4.  The tensor that is READ is given by its
+ * element strides (any layout); the one WRITTEN is contiguous [B,C,.,.], channel-last when *_nhwc != 0.  Deterministic. */
+int fpc_upsample_bilinear_fwd(const float* in, int64_t sb, int64_t sc, int64_t sh, int64_t sw, float* out, int B, int C, int h,
+                              int w, int scale, int out_nhwc, fpc_stream_t stream);
+int fpc_upsample_bilinear_bwd(const float* dout, int64_t sb, int64_t sc, int64_t sh, int64_t sw, float* din, int B, int C, int h,
+                              int w, int scale, int din_nhwc, fpc_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

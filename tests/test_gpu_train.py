@@ -449,3 +449,35 @@ def test_training_mode_model_uses_native_convolutions_and_matches_torch_path():
         err_n = max(err_n, (gn[n] - gr[n]).abs().max().item() / scale)
         err_t = max(err_t, (gt[n] - gr[n]).abs().max().item() / scale)
     assert err_n <= max(2.0 * err_t, 1e-4), (err_n, err_t)
+
+
+@pytest.mark.parametrize("case", [(2, 128, 15, 20, 2, "nhwc"), (2, 7, 30, 40, 4, "nhwc->nchw"), (1, 24, 12, 16, 4, "nchw"),
+                                  (3, 5, 3, 4, 2, "nchw"), (1, 6, 1, 9, 4, "nhwc->nchw"), (2, 128, 2, 3, 2, "nhwc")],
+                         ids=lambda c: "x".join(str(v) for v in c))
+def test_native_bilinear_upsample_forward_and_adjoint_vs_torch(case):
+    from fastposecnn_amd.lib import train_conv
+    B, C, h, w, scale, layout = case
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(B * 100 + C)
+    x = torch.randn((B, C, h, w), generator=g)
+    gy = torch.randn((B, C, h * scale, w * scale), generator=g)
+    xr = x.double().requires_grad_()
+    yr = torch.nn.functional.interpolate(xr, scale_factor=scale, mode="bilinear", align_corners=True)
+    yr.backward(gy.double())
+    xd = x.to(dev)
+    if layout.startswith("nhwc"):
+        xd = xd.contiguous(memory_format=torch.channels_last)
+    xd.requires_grad_()
+    y = train_conv.upsample_bilinear(xd, scale, out_nchw=layout.endswith("nchw"))
+    assert y.is_contiguous(memory_format=torch.channels_last if layout == "nhwc" else torch.contiguous_format)
+    gd = gy.to(dev)
+    if layout == "nhwc":
+        gd = gd.contiguous(memory_format=torch.channels_last)
+    y.backward(gd)
+    torch.cuda.synchronize()
+    # the source coordinate r * o is an f32 product (ATen's arithmetic, kept): ~1e-5 of a pixel at o ~ 500
+    assert (y.detach().cpu().double() - yr.detach()).abs().max().item() <= 2e-5 * max(1.0, yr.abs().max().item())
+    assert (xd.grad.cpu().double() - xr.grad).abs().max().item() <= 2e-5 * max(1.0, xr.grad.abs().max().item())
+    # same numbers as torch's own f32 kernel (the network's evaluation path) to rounding
+    yt = torch.nn.functional.interpolate(x.to(dev), scale_factor=scale, mode="bilinear", align_corners=True)
+    assert (y.detach() - yt).abs().max().item() <= 1e-6 * max(1.0, yt.abs().max().item())
