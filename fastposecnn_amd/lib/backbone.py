@@ -181,7 +181,12 @@ class Conv3x3GNReLU(nn.Module):
         )
 
     def forward(self, x):
-        x = self.block(x)
+        if self.training and x.is_cuda and torch.is_grad_enabled() and isinstance(self.block[2], nn.ReLU):
+            # the training step: GroupNorm + ReLU as one native channel-last op behind the native convolution
+            from fastposecnn_amd.lib import train_conv
+            x = train_conv.groupnorm_relu(self.block[0](x), self.block[1])
+        else:
+            x = self.block(x)
         if self.upsample:
             x = _upsample_bilinear(x, 2)
         return x

@@ -166,3 +166,45 @@ def upsample_bilinear(x, scale, out_nchw=False):
             x = x.contiguous()
         return _UpBilinearFn.apply(x, int(scale), bool(nhwc))
     return torch.nn.functional.interpolate(x, scale_factor=scale, mode="bilinear", align_corners=True)
+
+
+# ---- GroupNorm(32 groups of 4 channels) + ReLU on channel-last activations (the decoder's Conv3x3GNReLU blocks) -----------
+
+class _GroupNormReLUFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, gamma, beta, groups, eps):
+        B, C, H, W = x.shape
+        L = nat.lib()
+        y = torch.empty_like(x, memory_format=torch.channels_last)
+        stats = torch.empty((B, groups, 2), dtype=torch.float32, device=x.device)
+        part = torch.empty(L.fpc_groupnorm4_relu_scratch_floats(B, H * W, C), dtype=torch.float32, device=x.device)
+        gamma, beta = gamma.contiguous(), beta.contiguous()
+        nat.check(L.fpc_groupnorm4_relu_fwd(x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), y.data_ptr(), stats.data_ptr(), part.data_ptr(),
+                                            B, H * W, C, groups, float(eps), nat.stream()), "fpc_groupnorm4_relu_fwd")
+        ctx.save_for_backward(x, gamma, beta, stats)
+        ctx.groups = groups
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, gamma, beta, stats = ctx.saved_tensors
+        B, C, H, W = x.shape
+        L = nat.lib()
+        gy = _channels_last(gy)
+        dx = torch.empty_like(x, memory_format=torch.channels_last)
+        chunks = L.fpc_groupnorm4_relu_scratch_floats(B, H * W, C) // (B * C * 2)
+        part = torch.empty((B, chunks, C, 2), dtype=torch.float32, device=x.device)
+        nat.check(L.fpc_groupnorm4_relu_bwd(x.data_ptr(), gy.data_ptr(), gamma.data_ptr(), beta.data_ptr(), stats.data_ptr(), dx.data_ptr(),
+                                            part.data_ptr(), B, H * W, C, ctx.groups, nat.stream()), "fpc_groupnorm4_relu_bwd")
+        sums = part.sum((0, 1))                      # [C, 2]: dbeta, dgamma
+        return dx, sums[:, 1].contiguous(), sums[:, 0].contiguous(), None, None
+
+
+def groupnorm_relu(x, gn):
+    """relu(gn(x)) for a torch.nn.GroupNorm `gn`: native on channel-last f32 GPU tensors whose groups are 4 channels wide
+    (the decoder: GroupNorm(32, 128)), torch otherwise."""
+    C, G = gn.num_channels, gn.num_groups
+    if (ENABLED and x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and gn.affine and C == 4 * G and 256 % G == 0 and G <= 64
+            and x.shape[0] <= 65535 and x.stride(1) == 1 and x.is_contiguous(memory_format=torch.channels_last)):
+        return _GroupNormReLUFn.apply(x, gn.weight, gn.bias, G, gn.eps)
+    return torch.relu(gn(x))

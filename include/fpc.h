@@ -328,6 +328,18 @@ int fpc_upsample_bilinear_fwd(const float* in, int64_t sb, int64_t sc, int64_t s
 int fpc_upsample_bilinear_bwd(const float* dout, int64_t sb, int64_t sc, int64_t sh, int64_t sw, float* din, int B, int C, int h,
                               int w, int scale, int din_nhwc, fpc_stream_t stream);
 
+/* GroupNorm + ReLU on channel-last activations for the training step (the decoder blocks' GroupNorm(32, 128) -> ReLU,
+ * segmentation_models_pytorch Conv3x3GNReLU, call sites F/lib/pose_regressor.py:608-666): x, y, dy, dx are [B, HW, C]
+ * with C = 4 * groups (a group is one float4 of a pixel; groups divides 256 and is <= 64; FPC_EINVAL otherwise).
+ * stats [B][groups][2] = mean, rstd (forward -> backward).  part: fpc_groupnorm4_relu_scratch_floats floats; after the
+ * backward it holds [B][chunks][C][2] = per-chunk {sum dz, sum dz * xhat}, whose sums over the first two axes are
+ * dbeta / dgamma.  Partial sums are combined in double in a fixed order: deterministic. */
+size_t fpc_groupnorm4_relu_scratch_floats(int B, int HW, int C);
+int fpc_groupnorm4_relu_fwd(const float* x, const float* gamma, const float* beta, float* y, float* stats, float* part, int B,
+                            int HW, int C, int groups, float eps, fpc_stream_t stream);
+int fpc_groupnorm4_relu_bwd(const float* x, const float* dy, const float* gamma, const float* beta, const float* stats, float* dx,
+                            float* part, int B, int HW, int C, int groups, fpc_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

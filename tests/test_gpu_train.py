@@ -481,3 +481,49 @@ def test_native_bilinear_upsample_forward_and_adjoint_vs_torch(case):
     # same numbers as torch's own f32 kernel (the network's evaluation path) to rounding
     yt = torch.nn.functional.interpolate(x.to(dev), scale_factor=scale, mode="bilinear", align_corners=True)
     assert (y.detach() - yt).abs().max().item() <= 1e-6 * max(1.0, yt.abs().max().item())
+
+
+@pytest.mark.parametrize("case", [(2, 128, 15, 20), (3, 128, 33, 17), (1, 64, 7, 5), (2, 256, 24, 32)], ids=str)
+def test_native_groupnorm_relu_forward_and_backward_vs_float64(case):
+    from fastposecnn_amd.lib import train_conv
+    B, C, H, W = case
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(C + H)
+    x = torch.randn((B, C, H, W), generator=g) * 1.5 + 0.7          # a mean that is not small against the spread
+    gy = torch.randn((B, C, H, W), generator=g)
+    gn = torch.nn.GroupNorm(C // 4, C)
+    gn.weight.data = torch.rand(C, generator=g) + 0.5
+    gn.bias.data = torch.randn(C, generator=g) * 0.3
+    ref = torch.nn.GroupNorm(C // 4, C).double()
+    ref.weight.data, ref.bias.data = gn.weight.data.double(), gn.bias.data.double()
+    xr = x.double().requires_grad_()
+    yr = torch.relu(ref(xr))
+    yr.backward(gy.double())
+    gn = gn.to(dev)
+    xd = x.to(dev).contiguous(memory_format=torch.channels_last).requires_grad_()
+    y = train_conv.groupnorm_relu(xd, gn)
+    assert y.is_contiguous(memory_format=torch.channels_last) and y.grad_fn.__class__.__name__.startswith("_GroupNormReLUFn")
+    y.backward(gy.to(dev).contiguous(memory_format=torch.channels_last))
+    torch.cuda.synchronize()
+
+    def close(got, want, what, rel=2e-5):
+        err = (got.detach().cpu().double() - want).abs().max().item()
+        assert err <= rel * max(1.0, want.abs().max().item()), (what, err)
+
+    # elements whose pre-activation is within rounding of 0 may take the other side of the ReLU: compare away from it
+    z = ref(x.double()).detach()
+    safe = (z.abs() > 1e-4)
+    close(y.detach().cpu().double() * safe, yr.detach() * safe, "y")
+    if bool(safe.all()):
+        close(xd.grad, xr.grad, "dx", 1e-4)
+        close(gn.weight.grad, ref.weight.grad, "dgamma", 1e-4)
+        close(gn.bias.grad, ref.bias.grad, "dbeta", 1e-4)
+    else:                      # a flipped unit changes the group's sums: compare against torch with the native mask instead
+        mask = (y.detach().cpu() > 0).double()
+        xr2 = x.double().requires_grad_()
+        z2 = ref(xr2)
+        ref.zero_grad()
+        (z2 * mask).backward(gy.double())
+        close(xd.grad, xr2.grad, "dx", 1e-4)
+        close(gn.weight.grad, ref.weight.grad, "dgamma", 1e-4)
+        close(gn.bias.grad, ref.bias.grad, "dbeta", 1e-4)
