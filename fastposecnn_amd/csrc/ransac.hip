@@ -9,9 +9,9 @@
 //                     in-chunk prefix, chunk count and bounding box; the chunk's foreground pixels are compacted in raster
 //                     order into the chunk's own slots of ONE float4 list {x, y, dx, dy} (vote gathered through the caller's
 //                     strides).                                                  (HBM: n x 12 H W bytes, read once)
-//      k_vote_plan    one 1024-thread workgroup per instance: chunk prefix (rank -> slot), the integer origin / radius the
-//                     filter's coordinates are measured from, the work units of the count (blocks of <= 512 entries inside
-//                     one chunk) and of the refinement (runs of eight chunks), the hn hypotheses (:552,559; pair sampling,
+//      k_vote_plan    per instance (256 threads; up to four workgroups split the hypothesis tiles): chunk prefix (rank -> slot),
+//                     the integer origin / radius the filter's coordinates are measured from, the work units of the count
+//                     (512 consecutive foreground ranks) and of the refinement (runs of 8192 ranks), the hn hypotheses (:552,559; pair sampling,
 //                     two-line intersection exactly as .cu:28-45) — each also as a bf16 MFMA B-fragment of the filter —
 //                     and a zeroed count row.
 //      k_vote_count   one resident round of workgroups over units x hypothesis slices.  EXACT inlier counts.  The two affine

@@ -88,8 +88,15 @@ int fpc_voting_for_hypothesis(const float* direct, const float* coords, const fl
  *         fpc_cc_label without reading the instance count back to the host.
  * hn      1 .. 65536.
  * ws      device workspace of at least fpc_ransac_workspace_bytes(n,H,W,hn) bytes, 256-byte aligned.  Contents
- *         are scratch: nothing has to survive between calls (four stateless launches: mask scan + pixel lists ->
- *         per-instance plan -> exact counts -> winner + refinement; csrc/ransac.hip). */
+ *         are scratch: nothing has to survive between calls and nothing has to be cleared before one (four stateless
+ *         launches on `stream`, no memset, no second stream: mask scan + compacted pixel list -> per-instance plan
+ *         (hypotheses, work records) -> exact counts on the matrix cores -> winner + refinement; csrc/ransac.hip,
+ *         csrc/vote_count.hip).
+ * Results are those of the reference's exhaustive vote bit for bit (counts, winner, inlier set); the refinement solves
+ * the 2x2 normal equations in fp64 like b_inv (RV/ransac_voting_gpu.py:503-516: inverse, pseudo-inverse when singular),
+ * and also takes the pseudo-inverse when det <= 1e-12 trace^2 (conditioning beyond fp64's reach for f32 votes; torch
+ * raises only on an exactly singular LU).  An instance above max_num without an injected `keep` / `idxs` draws its
+ * pairs by rejection over the kept pixels (include/fpc_rng.h, FPC_SAMPLE_MAX_TRIES). */
 size_t fpc_ransac_workspace_bytes(int n, int H, int W, int hn);
 int fpc_ransac_voting_v3(const float* mask, const float* vertex,
                          int64_t vs_n, int64_t vs_h, int64_t vs_w, int64_t vs_c,
