@@ -173,7 +173,8 @@ __global__ void k_agg_finalize(int N, const int32_t* __restrict__ n_dev, const d
     agg_finalize_one(i, sums, cnt, cls_min, sample, class_ids, sample_ids, oq, os, oz, stats);
 }
 
-// grid (ceil(HW/1024), N); the first block of every instance also finalises it (no launch of its own)
+// grid (ceil(HW/4096), N): a workgroup writes one 4096-pixel chunk of one instance (four 4-pixel groups per lane, their
+// label loads issued together); the first block of every instance also finalises it (no launch of its own).
 __global__ __launch_bounds__(256) void k_agg_planes(const int32_t* __restrict__ labels, const float* __restrict__ xy,
                                                     const int32_t* __restrict__ sample, int HW,
                                                     const int32_t* __restrict__ n_dev,
@@ -181,40 +182,78 @@ __global__ __launch_bounds__(256) void k_agg_planes(const int32_t* __restrict__ 
                                                     const double* __restrict__ sums, const int32_t* __restrict__ cnt,
                                                     const uint32_t* __restrict__ cls_min, int64_t* __restrict__ class_ids,
                                                     int64_t* __restrict__ sample_ids, float* __restrict__ oq,
-                                                    float* __restrict__ os, float* __restrict__ oz, float* __restrict__ stats) {
-    int i = blockIdx.y;
+                                                    float* __restrict__ os, float* __restrict__ oz, float* __restrict__ stats,
+                                                    uint64_t* __restrict__ bits, int nwords) {
+    const int i = blockIdx.y;
     if (n_dev && i >= *n_dev) return;     // capacity rows past the device-side instance count
     if (blockIdx.x == 0 && threadIdx.x == 0) agg_finalize_one(i, sums, cnt, cls_min, sample, class_ids, sample_ids, oq, os, oz, stats);
-    int b = sample[i];
-    int p0 = blockIdx.x * 1024 + threadIdx.x * 4;
-    if (p0 >= HW) return;
+    const int b = sample[i];
     const int32_t* L = labels + (size_t)b * HW;
-    if ((HW & 3) == 0) {
-        int4 l = *reinterpret_cast<const int4*>(L + p0);
-        bool f0 = l.x == i + 1, f1 = l.y == i + 1, f2 = l.z == i + 1, f3 = l.w == i + 1;
-        if (inst_masks)
-            *reinterpret_cast<float4*>(inst_masks + (size_t)i * HW + p0) =
-                make_float4(f0 ? 1.f : 0.f, f1 ? 1.f : 0.f, f2 ? 1.f : 0.f, f3 ? 1.f : 0.f);
-        if (oxy) {
-            bool any = f0 | f1 | f2 | f3;
+    const bool vec = (HW & 3) == 0;
+    const int lane = threadIdx.x & (kWave - 1);
+    int4 lab[4];
 #pragma unroll
-            for (int c = 0; c < 2; ++c) {
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (any) {
-                    float4 s = *reinterpret_cast<const float4*>(xy + ((size_t)b * 2 + c) * HW + p0);
-                    v = make_float4(f0 ? s.x : 0.f, f1 ? s.y : 0.f, f2 ? s.z : 0.f, f3 ? s.w : 0.f);
-                }
-                *reinterpret_cast<float4*>(oxy + ((size_t)i * 2 + c) * HW + p0) = v;
+    for (int it = 0; it < 4; ++it) {
+        const int p0 = blockIdx.x * 4096 + it * 1024 + threadIdx.x * 4;
+        lab[it] = make_int4(0, 0, 0, 0);
+        if (vec) {
+            if (p0 < HW) lab[it] = *reinterpret_cast<const int4*>(L + p0);
+        } else {
+            if (p0 < HW) lab[it].x = L[p0];
+            if (p0 + 1 < HW) lab[it].y = L[p0 + 1];
+            if (p0 + 2 < HW) lab[it].z = L[p0 + 2];
+            if (p0 + 3 < HW) lab[it].w = L[p0 + 3];
+        }
+    }
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        const int p0 = blockIdx.x * 4096 + it * 1024 + threadIdx.x * 4;
+        const bool f0 = lab[it].x == i + 1, f1 = lab[it].y == i + 1, f2 = lab[it].z == i + 1, f3 = lab[it].w == i + 1;      // labels are >= 1
+        if (bits) {
+            // the instance's foreground as bit words for the vote's scan (bit j of word w = pixel 64 w + j, zero past HW):
+            // four ballots, lanes 0..3 interleave the wave's four words
+            const uint64_t b0 = __ballot(f0), b1 = __ballot(f1), b2 = __ballot(f2), b3 = __ballot(f3);
+            if (lane < 4) {
+                auto spread = [](uint64_t x) {      // bit m of the low 16 -> bit 4 m
+                    x &= 0xFFFFull;
+                    x = (x | (x << 24)) & 0x000000FF000000FFull;
+                    x = (x | (x << 12)) & 0x000F000F000F000Full;
+                    x = (x | (x << 6)) & 0x0303030303030303ull;
+                    x = (x | (x << 3)) & 0x1111111111111111ull;
+                    return x;
+                };
+                const int sh = 16 * lane;
+                const uint64_t word = spread(b0 >> sh) | (spread(b1 >> sh) << 1) | (spread(b2 >> sh) << 2) | (spread(b3 >> sh) << 3);
+                const int wi = blockIdx.x * 64 + it * 16 + (threadIdx.x / kWave) * 4 + lane;
+                if (wi < nwords) bits[(size_t)i * nwords + wi] = word;
             }
         }
-    } else {
-        for (int k = 0; k < 4 && p0 + k < HW; ++k) {
-            int p = p0 + k;
-            bool f = L[p] == i + 1;
-            if (inst_masks) inst_masks[(size_t)i * HW + p] = f ? 1.f : 0.f;
+        if (p0 >= HW) continue;
+        if (vec) {
+            if (inst_masks)
+                *reinterpret_cast<float4*>(inst_masks + (size_t)i * HW + p0) =
+                    make_float4(f0 ? 1.f : 0.f, f1 ? 1.f : 0.f, f2 ? 1.f : 0.f, f3 ? 1.f : 0.f);
             if (oxy) {
-                oxy[((size_t)i * 2 + 0) * HW + p] = f ? xy[((size_t)b * 2 + 0) * HW + p] : 0.f;
-                oxy[((size_t)i * 2 + 1) * HW + p] = f ? xy[((size_t)b * 2 + 1) * HW + p] : 0.f;
+                const bool any = f0 | f1 | f2 | f3;
+#pragma unroll
+                for (int c = 0; c < 2; ++c) {
+                    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (any) {
+                        const float4 s = *reinterpret_cast<const float4*>(xy + ((size_t)b * 2 + c) * HW + p0);
+                        v = make_float4(f0 ? s.x : 0.f, f1 ? s.y : 0.f, f2 ? s.z : 0.f, f3 ? s.w : 0.f);
+                    }
+                    *reinterpret_cast<float4*>(oxy + ((size_t)i * 2 + c) * HW + p0) = v;
+                }
+            }
+        } else {
+            const bool fl[4] = {f0, f1, f2, f3};
+            for (int k = 0; k < 4 && p0 + k < HW; ++k) {
+                const int p = p0 + k;
+                if (inst_masks) inst_masks[(size_t)i * HW + p] = fl[k] ? 1.f : 0.f;
+                if (oxy) {
+                    oxy[((size_t)i * 2 + 0) * HW + p] = fl[k] ? xy[((size_t)b * 2 + 0) * HW + p] : 0.f;
+                    oxy[((size_t)i * 2 + 1) * HW + p] = fl[k] ? xy[((size_t)b * 2 + 1) * HW + p] : 0.f;
+                }
             }
         }
     }
@@ -234,6 +273,15 @@ extern "C" int fpc_aggregate(const int32_t* labels, const int64_t* cat_mask, con
                              int64_t* class_ids,
                              int64_t* sample_ids, float* inst_masks, float* oq, float* os, float* oz, float* oxy,
                              float* out_stats, void* ws, size_t ws_bytes, fpc_stream_t stream) {
+    return fpc_aggregate_bits(labels, cat_mask, quat, scales, xy, z, B, H, W, N, n_dev, class_ids, sample_ids, inst_masks, oq, os, oz, oxy,
+                              out_stats, nullptr, ws, ws_bytes, stream);
+}
+
+extern "C" int fpc_aggregate_bits(const int32_t* labels, const int64_t* cat_mask, const float* quat, const float* scales,
+                                  const float* xy, const float* z, int B, int H, int W, int N, const int32_t* n_dev,
+                                  int64_t* class_ids, int64_t* sample_ids, float* inst_masks, float* oq, float* os, float* oz,
+                                  float* oxy, float* out_stats, uint64_t* inst_bits, void* ws, size_t ws_bytes,
+                                  fpc_stream_t stream) {
     if (B < 0 || H < 1 || W < 1 || N < 0) return FPC_EINVAL;
     if (N == 0 || B == 0) return FPC_OK;
     if (B > 65535 || N > 65535) return FPC_EINVAL;
@@ -250,13 +298,15 @@ extern "C" int fpc_aggregate(const int32_t* labels, const int64_t* cat_mask, con
     int HW = H * W;
     hipError_t e = hipMemsetAsync(ws, 0, w.zero_bytes, s);
     if (e != hipSuccess) { set_hip_error(e); return FPC_ELAUNCH; }
-    int gx = cdiv(HW, 1024);
+    const int nwords = cdiv(HW, 4096) * 64;                 // fpc_mask_bits_words(H, W): whole 4096-pixel chunks
+    int gx = cdiv(HW, 4096);
+    if (((uintptr_t)inst_bits & 7) != 0) return FPC_EINVAL;
     hipLaunchKernelGGL(k_agg_accum, dim3(cdiv(W, kWave), cdiv(H, 4 * kAggRows), B), dim3(256), 0, s, labels, cat_mask, quat, scales, z,
                        H, W, N, n_dev, w.sums,
                        w.cnt, w.cls_min, w.sample);
-    if (inst_masks || oxy)
+    if (inst_masks || oxy || inst_bits)
         hipLaunchKernelGGL(k_agg_planes, dim3(gx, N), dim3(256), 0, s, labels, xy, w.sample, HW, n_dev, inst_masks, oxy, w.sums, w.cnt,
-                           w.cls_min, class_ids, sample_ids, oq, os, oz, out_stats);
+                           w.cls_min, class_ids, sample_ids, oq, os, oz, out_stats, inst_bits, nwords);
     else
         hipLaunchKernelGGL(k_agg_finalize, dim3(cdiv(N, 64)), dim3(64), 0, s, N, n_dev, w.sums, w.cnt, w.cls_min, w.sample,
                            class_ids, sample_ids, oq, os, oz, out_stats);

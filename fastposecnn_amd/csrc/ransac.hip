@@ -118,14 +118,16 @@ __global__ void k_b1_vote(const float* __restrict__ direct, const float* __restr
 // A parameter block of its own: with the whole VoteParams the compiler held 98 VGPRs (5 waves per SIMD) for this
 // latency-bound streaming kernel, with these sixteen values 52 (8 waves).
 struct ScanParams {
-    const float* mask; const float* vertex; int64_t vs_n, vs_h, vs_w, vs_c;
+    const float* mask; const uint64_t* bits; const float* vertex; int64_t vs_n, vs_h, vs_w, vs_c;
     int n; const int32_t* n_dev; int W, HW, nch;
     size_t ls;
     int32_t* ctrl; int32_t* chunk_fg; int32_t* chunk_box; float4* list;
     unsigned long long* stamps;
 };
 
-template <bool VEC4, bool VGATHER4>
+// BITS: the caller supplies the foreground as bit words (p.bits [n][nch * 64] u64, bit j of word w = pixel 64 w + j, zero
+// past H W): the f32 mask plane — two thirds of this kernel's bytes at a 13 % foreground — is not read at all.
+template <bool VEC4, bool VGATHER4, bool BITS = false>
 __global__ __launch_bounds__(256) void k_vote_scan(const ScanParams p) {
     __shared__ __attribute__((aligned(16))) uint8_t s_nib[kChunkPx / 4];
     __shared__ uint64_t s_word[kChunkWords];
@@ -149,14 +151,21 @@ __global__ __launch_bounds__(256) void k_vote_scan(const ScanParams p) {
     };
     // (Tasks handed out by tickets instead of this static round-robin - 16 sharded words, a memset - measured 70 + 5 us
     // against 68 us at B = 32: the kernel moves 330 MB in 65 us, it is at the memory system's rate, not unbalanced.)
-    if (VEC4 && (int)blockIdx.x < total) load_mask(blockIdx.x, cur);
+    uint64_t curw = 0, nxtw = 0;
+    auto load_bits = [&](int t) -> uint64_t {
+        const int inst = t / nch, c = t - inst * nch;
+        return threadIdx.x < kChunkWords ? p.bits[((size_t)inst * nch + c) * kChunkWords + threadIdx.x] : 0ull;
+    };
+    if (BITS && (int)blockIdx.x < total) curw = load_bits(blockIdx.x);
+    if (!BITS && VEC4 && (int)blockIdx.x < total) load_mask(blockIdx.x, cur);
     for (int t = blockIdx.x; t < total; t += gridDim.x) {
         const int inst = t / nch, c = t - inst * nch;
         const float* m = p.mask + (size_t)inst * HW;
-        if (VEC4 && t + (int)gridDim.x < total) load_mask(t + gridDim.x, nxt);
+        if (BITS && t + (int)gridDim.x < total) nxtw = load_bits(t + gridDim.x);
+        if (!BITS && VEC4 && t + (int)gridDim.x < total) load_mask(t + gridDim.x, nxt);
         unsigned nb[4];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
+        for (int k = 0; k < 4 && !BITS; ++k) {
             const int fi = k * 256 + threadIdx.x;           // float4 index inside the chunk
             const int px = c * kChunkPx + fi * 4;
             nb[k] = 0;
@@ -169,11 +178,13 @@ __global__ __launch_bounds__(256) void k_vote_scan(const ScanParams p) {
                     if (px + q < HW && m[px + q] != 0.0f) nb[k] |= 1u << q;
             }
         }
+        if (!BITS) {
 #pragma unroll
-        for (int k = 0; k < 4; ++k) s_nib[k * 256 + threadIdx.x] = (uint8_t)nb[k];
-        __syncthreads();
+            for (int k = 0; k < 4; ++k) s_nib[k * 256 + threadIdx.x] = (uint8_t)nb[k];
+            __syncthreads();
+        }
         if (threadIdx.x < kChunkWords) {
-            const uint64_t word = pack_nibbles(*reinterpret_cast<const uint4*>(s_nib + 16 * threadIdx.x));
+            const uint64_t word = BITS ? curw : pack_nibbles(*reinterpret_cast<const uint4*>(s_nib + 16 * threadIdx.x));
             int tot;
             const int ex = wave_excl_scan(__popcll(word), tot);
             s_word[threadIdx.x] = word;
@@ -184,6 +195,13 @@ __global__ __launch_bounds__(256) void k_vote_scan(const ScanParams p) {
             }
         }
         __syncthreads();
+        if (BITS) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int fi = k * 256 + threadIdx.x;
+                nb[k] = (unsigned)(s_word[fi >> 4] >> ((fi & 15) * 4)) & 15u;
+            }
+        }
         int bx0 = 0x7fffffff, bx1 = -1, by0 = 0x7fffffff, by1 = -1;
         const float* v = p.vertex + (int64_t)inst * p.vs_n;
         float4* L = p.list + (size_t)inst * p.ls + (size_t)c * kChunkPx;
@@ -245,7 +263,8 @@ __global__ __launch_bounds__(256) void k_vote_scan(const ScanParams p) {
         if (threadIdx.x < 4) p.chunk_box[((size_t)inst * nch + c) * 4 + threadIdx.x] = s_box[threadIdx.x];
         __syncthreads();
         FPC_STAMP(0, 1);
-        if (VEC4) {
+        if (BITS) curw = nxtw;
+        if (!BITS && VEC4) {
 #pragma unroll
             for (int k = 0; k < 4; ++k) cur[k] = nxt[k];
         }
@@ -678,6 +697,10 @@ extern "C" size_t fpc_ransac_workspace_bytes(int n, int H, int W, int hn) {
     return carve(nullptr, n, H, W, hn).total;
 }
 
+extern "C" size_t fpc_mask_bits_words(int H, int W) {
+    return (H < 1 || W < 1) ? 0 : (size_t)cdiv(H * W, kChunkPx) * kChunkWords;
+}
+
 extern "C" int fpc_ransac_voting_v3(const float* mask, const float* vertex, int64_t vs_n, int64_t vs_h, int64_t vs_w,
                                     int64_t vs_c, int n, const int32_t* n_dev, int H, int W, int hn,
                                     const int32_t* idxs, const uint8_t* keep, uint64_t seed, float inlier_thresh,
@@ -685,10 +708,22 @@ extern "C" int fpc_ransac_voting_v3(const float* mask, const float* vertex, int6
                                     int32_t* out_win_count, int32_t* out_inl_count, float* out_hyp,
                                     int32_t* out_counts, double* out_refine, void* ws, size_t ws_bytes,
                                     fpc_stream_t stream) {
+    return fpc_ransac_voting_v3_bits(mask, nullptr, vertex, vs_n, vs_h, vs_w, vs_c, n, n_dev, H, W, hn, idxs, keep, seed, inlier_thresh,
+                                     min_num, max_num, out_xy, out_tn, out_win_idx, out_win_count, out_inl_count, out_hyp, out_counts,
+                                     out_refine, ws, ws_bytes, stream);
+}
+
+extern "C" int fpc_ransac_voting_v3_bits(const float* mask, const uint64_t* mask_bits, const float* vertex, int64_t vs_n,
+                                         int64_t vs_h, int64_t vs_w, int64_t vs_c, int n, const int32_t* n_dev, int H, int W, int hn,
+                                         const int32_t* idxs, const uint8_t* keep, uint64_t seed, float inlier_thresh,
+                                         int min_num, int max_num, float* out_xy, int32_t* out_tn, int32_t* out_win_idx,
+                                         int32_t* out_win_count, int32_t* out_inl_count, float* out_hyp,
+                                         int32_t* out_counts, double* out_refine, void* ws, size_t ws_bytes,
+                                         fpc_stream_t stream) {
     if (n < 0 || H < 1 || W < 1 || hn < 1 || hn > kMaxHn || max_num < 1) return FPC_EINVAL;
     if ((int64_t)H * W > (1 << 30) || H > 65535 || W > 65535) return FPC_EINVAL;
     if (n == 0) return FPC_OK;
-    if (!mask || !vertex || !out_xy || !ws) return FPC_EINVAL;
+    if ((!mask && !mask_bits) || !vertex || !out_xy || !ws || ((uintptr_t)mask_bits & 7)) return FPC_EINVAL;
     if (n > 65535) return FPC_EINVAL;
     if (((uintptr_t)ws & 255) != 0) return FPC_EWORKSPACE;
     Ws w = carve(ws, n, H, W, hn);
@@ -728,12 +763,15 @@ extern "C" int fpc_ransac_voting_v3(const float* mask, const float* vertex, int6
 #endif
     // 1. mask planes -> per-chunk compacted pixel lists (the only pass over the masks and the vote planes)
     const bool vec4 = (HW % 4 == 0) && (((uintptr_t)mask & 15) == 0);
-    const bool vg4 = vec4 && W % 4 == 0 && vs_w == 1 && vs_h % 4 == 0 && vs_n % 4 == 0 && vs_c % 4 == 0 &&
+    const bool vg4 = (HW % 4 == 0) && W % 4 == 0 && vs_w == 1 && vs_h % 4 == 0 && vs_n % 4 == 0 && vs_c % 4 == 0 &&
                      (((uintptr_t)vertex & 15) == 0);
     const int scan_grid = (int)std::min<long long>((long long)n * p.nch, 256 * 4);       // resident: the loop prefetches
-    const ScanParams sp{mask, vertex, vs_n, vs_h, vs_w, vs_c, n, n_dev, W, HW, p.nch, p.ls, p.ctrl, p.chunk_fg, p.chunk_box, p.list, p.stamps};
+    const ScanParams sp{mask, mask_bits, vertex, vs_n, vs_h, vs_w, vs_c, n, n_dev, W, HW, p.nch, p.ls, p.ctrl, p.chunk_fg, p.chunk_box, p.list, p.stamps};
 #define FPC_LAUNCH_SCAN(A, B) hipLaunchKernelGGL((k_vote_scan<A, B>), dim3(scan_grid), dim3(256), 0, s, sp)
-    if (vg4) FPC_LAUNCH_SCAN(true, true); else if (vec4) FPC_LAUNCH_SCAN(true, false); else FPC_LAUNCH_SCAN(false, false);
+    if (mask_bits) {      // the foreground as bit words: the f32 planes are not read
+        if (vg4) hipLaunchKernelGGL((k_vote_scan<false, true, true>), dim3(scan_grid), dim3(256), 0, s, sp);
+        else hipLaunchKernelGGL((k_vote_scan<false, false, true>), dim3(scan_grid), dim3(256), 0, s, sp);
+    } else if (vg4 && vec4) FPC_LAUNCH_SCAN(true, true); else if (vec4) FPC_LAUNCH_SCAN(true, false); else FPC_LAUNCH_SCAN(false, false);
 #undef FPC_LAUNCH_SCAN
     FPC_TRACE("scan");
 

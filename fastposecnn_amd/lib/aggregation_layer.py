@@ -14,6 +14,15 @@ from fastposecnn_amd import _native as nat
 import hough_voting as hv
 
 
+def mask_bits_of(masks):
+    """The bit-word form of `masks` written by the aggregation call that produced this very tensor, or None (any other
+    tensor, a slice / copy of it, or the tensor after an in-place write)."""
+    tag = getattr(masks, "_fpc_mask_bits", None)
+    if tag is None or tag[1] != masks._version or tag[0].shape[0] != masks.shape[0]:
+        return None
+    return tag[0]
+
+
 class AggregationLayer(nn.Module):
 
     def __init__(self, HPARAM, classes):
@@ -68,11 +77,15 @@ class AggregationLayer(nn.Module):
         L = nat.lib()
         with torch.cuda.device(dev):
             ws = nat.workspace("agg", dev, L.fpc_aggregate_workspace_bytes(N))
-            nat.check(L.fpc_aggregate(nat.ptr(labels), nat.ptr(cm), nat.ptr(q), nat.ptr(s), nat.ptr(xy), nat.ptr(z),
-                                      B, H, W, N, nat.ptr(n_dev), nat.ptr(out['class_ids']), nat.ptr(out['sample_ids']),
-                                      nat.ptr(out['instance_masks']), nat.ptr(out['quaternion']),
-                                      nat.ptr(out['scales']), nat.ptr(out['z']), nat.ptr(out['xy']), nat.ptr(stats),
-                                      nat.ptr(ws), ws.numel(), nat.stream()), "fpc_aggregate")
+            # the masks also as bit words (1/32 of the bytes) for the vote's scan, which then skips the f32 planes this call
+            # has just written; they ride on the masks tensor (see mask_bits_of), not in the dict the reference defines
+            bits = torch.empty((N, L.fpc_mask_bits_words(H, W)), dtype=torch.int64, device=dev)
+            nat.check(L.fpc_aggregate_bits(nat.ptr(labels), nat.ptr(cm), nat.ptr(q), nat.ptr(s), nat.ptr(xy), nat.ptr(z),
+                                           B, H, W, N, nat.ptr(n_dev), nat.ptr(out['class_ids']), nat.ptr(out['sample_ids']),
+                                           nat.ptr(out['instance_masks']), nat.ptr(out['quaternion']),
+                                           nat.ptr(out['scales']), nat.ptr(out['z']), nat.ptr(out['xy']), nat.ptr(stats),
+                                           nat.ptr(bits), nat.ptr(ws), ws.numel(), nat.stream()), "fpc_aggregate_bits")
+            out['instance_masks']._fpc_mask_bits = (bits, out['instance_masks']._version)
         return out
 
     def forward(self, cat_data):

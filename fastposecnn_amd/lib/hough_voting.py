@@ -18,12 +18,14 @@ class HoughVotingLayer(nn.Module):
         mask = agg_data['instance_masks']      # [n,H,W]
         # [n,H,W,1,2] strided VIEW of the two planes — read in place by the kernel
         reshaped_uv_img = torch.unsqueeze(uv_img.permute(0, 2, 3, 1), dim=3)
+        from aggregation_layer import mask_bits_of
         output = rvg.ransac_voting_layer_v3(
             mask=mask,
             vertex=reshaped_uv_img,
             round_hyp_num=self.HPARAM.HV_NUM_OF_HYPOTHESES,
             n_dev=n_dev,
             seed=seed,
+            mask_bits=mask_bits_of(mask),      # set when `mask` is the aggregation layer's own output: the scan skips the f32 planes
         )
         good_output = torch.squeeze(output, dim=1)
         agg_data.update({'hypothesis': output, 'pruned_hypothesis': output, 'xy': good_output, 'xy_mask': uv_img})

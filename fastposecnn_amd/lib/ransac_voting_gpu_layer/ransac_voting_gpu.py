@@ -15,7 +15,8 @@ built-in counter-based sampler (include/fpc_rng.h; default: drawn from torch's C
 so torch.manual_seed() makes runs repeatable), `return_debug` also returns per-instance
 diagnostics (tn, win_idx, win_count, inlier_count, hyp, counts), `n_dev` (device i32[1]) limits the work
 to the first n_dev instances of a capacity-sized batch without a host read (rows past it are left
-uninitialised).
+uninitialised), `mask_bits` (i64 [b, fpc_mask_bits_words(h,w)]: the foreground as bit words, as the aggregation layer
+writes them) lets the kernels skip the f32 mask planes — same result, a third of the scan's bytes.
 """
 import torch
 
@@ -32,7 +33,7 @@ def b_inv(b_mat):
 
 def ransac_voting_layer_v3(mask, vertex, round_hyp_num, inlier_thresh=0.999, confidence=0.99, max_iter=20,
                            min_num=5, max_num=30000, *, idxs=None, keep=None, seed=None, return_debug=False, n_dev=None,
-                           refine_out=None):
+                           refine_out=None, mask_bits=None):
     """
     :param mask:      [b,h,w]   foreground where != 0
     :param vertex:    [b,h,w,vn,2]  (any strides; the permuted view of hough_voting.py:51 is read in place)
@@ -53,6 +54,10 @@ def ransac_voting_layer_v3(mask, vertex, round_hyp_num, inlier_thresh=0.999, con
         return (out, dbg) if return_debug else out
     if mask.dtype != torch.float32 or not mask.is_contiguous():
         mask = mask.to(torch.float32).contiguous()
+    if mask_bits is not None:
+        if mask_bits.dtype != torch.int64 or not mask_bits.is_contiguous() or mask_bits.device != dev or \
+                tuple(mask_bits.shape) != (b, nat.lib().fpc_mask_bits_words(h, w)):
+            raise RuntimeError("ransac_voting_layer_v3: mask_bits must be contiguous i64 [b, fpc_mask_bits_words(h, w)] on the masks' device")
     if vertex.dtype != torch.float32:
         vertex = vertex.float()
     if keep is not None:
@@ -82,13 +87,13 @@ def ransac_voting_layer_v3(mask, vertex, round_hyp_num, inlier_thresh=0.999, con
                          inlier_count=torch.empty(b, dtype=torch.int32, device=dev),
                          hyp=torch.empty((b, hn, 2), dtype=torch.float32, device=dev),
                          counts=torch.empty((b, hn), dtype=torch.int32, device=dev))
-            nat.check(L.fpc_ransac_voting_v3(
-                nat.ptr(mask), v.data_ptr(), sn, sh, sw, sc, b, nat.ptr(n_dev), h, w, hn, nat.ptr(ii), nat.ptr(keep),
+            nat.check(L.fpc_ransac_voting_v3_bits(
+                nat.ptr(mask), nat.ptr(mask_bits), v.data_ptr(), sn, sh, sw, sc, b, nat.ptr(n_dev), h, w, hn, nat.ptr(ii), nat.ptr(keep),
                 (seed + vi) & (2 ** 64 - 1), float(inlier_thresh), int(min_num), int(max_num), nat.ptr(xy),
                 nat.ptr(d["tn"]) if d else None, nat.ptr(d["win_idx"]) if d else None,
                 nat.ptr(d["win_count"]) if d else None, nat.ptr(d["inlier_count"]) if d else None,
                 nat.ptr(d["hyp"]) if d else None, nat.ptr(d["counts"]) if d else None, nat.ptr(refine),
-                nat.ptr(ws), ws.numel(), nat.stream()), "fpc_ransac_voting_v3")
+                nat.ptr(ws), ws.numel(), nat.stream()), "fpc_ransac_voting_v3_bits")
             if vn != 1:
                 out[:, vi, :] = xy
                 if refine is not None:

@@ -107,6 +107,18 @@ int fpc_ransac_voting_v3(const float* mask, const float* vertex,
                          int32_t* out_win_count, int32_t* out_inl_count,
                          float* out_hyp, int32_t* out_counts, double* out_refine,
                          void* ws, size_t ws_bytes, fpc_stream_t stream);
+/* The same with the foreground ALSO given as bit words (fpc_aggregate_bits' inst_bits: u64 [n][fpc_mask_bits_words(H,W)],
+ * 8-byte aligned): when mask_bits is not NULL the f32 `mask` planes are not read (mask may then be NULL) — two thirds of
+ * the mask scan's bytes at a typical foreground share.  The caller guarantees bit == (mask != 0); results are identical. */
+int fpc_ransac_voting_v3_bits(const float* mask, const uint64_t* mask_bits, const float* vertex,
+                              int64_t vs_n, int64_t vs_h, int64_t vs_w, int64_t vs_c,
+                              int n, const int32_t* n_dev, int H, int W, int hn,
+                              const int32_t* idxs, const uint8_t* keep, uint64_t seed,
+                              float inlier_thresh, int min_num, int max_num,
+                              float* out_xy, int32_t* out_tn, int32_t* out_win_idx,
+                              int32_t* out_win_count, int32_t* out_inl_count,
+                              float* out_hyp, int32_t* out_counts, double* out_refine,
+                              void* ws, size_t ws_bytes, fpc_stream_t stream);
 
 /* ---- class compression ------------------------------------------------------
  * mask_logits f32 [B,C,HW]; quat [B,4(C-1),HW]; scales [B,3(C-1),HW]; xy [B,2(C-1),HW];
@@ -144,6 +156,17 @@ int fpc_aggregate(const int32_t* labels, const int64_t* cat_mask,
                   int64_t* class_ids, int64_t* sample_ids, float* inst_masks,
                   float* oq, float* os, float* oz, float* oxy, float* out_stats,
                   void* ws, size_t ws_bytes, fpc_stream_t stream);
+/* The same, and — when inst_bits is not NULL — every instance's foreground also as bit words u64
+ * [N][fpc_mask_bits_words(H, W)] (bit j of word w = pixel 64 w + j, zero past H W; whole 4096-pixel chunks): 1/32 of
+ * the f32 mask plane, which fpc_ransac_voting_v3_bits reads INSTEAD of it.  No reference counterpart: the reference's
+ * voting re-reads the f32 masks its aggregation has just written (lib/hough_voting.py:41-63). */
+size_t fpc_mask_bits_words(int H, int W);
+int fpc_aggregate_bits(const int32_t* labels, const int64_t* cat_mask,
+                       const float* quat, const float* scales, const float* xy, const float* z,
+                       int B, int H, int W, int N, const int32_t* n_dev,
+                       int64_t* class_ids, int64_t* sample_ids, float* inst_masks,
+                       float* oq, float* os, float* oz, float* oxy, float* out_stats, uint64_t* inst_bits,
+                       void* ws, size_t ws_bytes, fpc_stream_t stream);
 
 /* ---- pose assembly ----------------------------------------------------------
  * q f32 [n,4] scalar-last, xy [n,2], z [n], kinv f32 [9] row-major (device)

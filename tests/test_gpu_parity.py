@@ -686,3 +686,47 @@ def test_pack_pose_records_native_equals_host_logic(lib, dev):
         assert torch.equal(out["sample_ids"], agg["sample_ids"] + 32) and torch.equal(out["RT"], agg["RT"])
     with pytest.raises(RuntimeError):
         parallel.pack_pose_records({k: v.to(dev) for k, v in agg.items()}, 0, capacity=2)
+
+
+def _pack_bits(masks, H, W):
+    """[n,H,W] masks -> the bit words fpc_aggregate_bits defines (numpy, little-endian bit order, zero padded to chunks)."""
+    from fastposecnn_amd import _native as nat
+    nw = nat.lib().fpc_mask_bits_words(H, W)
+    n = masks.shape[0]
+    flat = np.zeros((n, nw * 64), dtype=np.uint8)
+    flat[:, :H * W] = (masks.reshape(n, -1) != 0)
+    return np.packbits(flat, axis=1, bitorder="little").view(np.uint64).astype(np.int64).reshape(n, nw)
+
+
+@pytest.mark.parametrize("shape", [(480, 640), (100, 150), (67, 93)], ids=str)
+def test_mask_bits_from_aggregation_and_vote_without_the_f32_planes(lib, oracle, dev, shape):
+    """The aggregation layer's bit words are exactly (mask != 0), and the vote that reads them instead of the f32 planes
+    returns the same integers and the same centres bit for bit (incl. H W that is not a multiple of 64 or 4096)."""
+    import aggregation_layer as al
+    import ransac_voting_gpu_layer.ransac_voting_gpu as rvg
+    from fastposecnn_amd import synth
+    H, W = shape
+    if shape == (480, 640):
+        cat_cpu, _ = synth.make_vote_frame(0)
+    else:
+        cat_cpu, _ = synth.make_vote_batch(range(2), H=H, W=W, rmin=8.0, rmax=min(H, W) / 4.0, K=4)
+    cat = {k: v.to(dev) for k, v in cat_cpu.items()}
+    agg = al.AggregationLayer(None, 7).forward(cat)
+    masks = agg["instance_masks"]
+    bits = al.mask_bits_of(masks)
+    assert bits is not None and masks.shape[0] >= 2
+    assert np.array_equal(bits.cpu().numpy(), _pack_bits(masks.cpu().numpy(), H, W))
+    vertex = agg["xy"].permute(0, 2, 3, 1).unsqueeze(3)
+    hn = 256
+    a, da = rvg.ransac_voting_layer_v3(masks, vertex, hn, seed=11, return_debug=True)
+    b, db = rvg.ransac_voting_layer_v3(masks, vertex, hn, seed=11, return_debug=True, mask_bits=bits)
+    torch.cuda.synchronize()
+    assert torch.equal(a, b)
+    for k in da[0]:
+        assert torch.equal(da[0][k], db[0][k]), k
+    # a tensor that is not the aggregation's own output carries no bits
+    assert al.mask_bits_of(masks[:1]) is None and al.mask_bits_of(masks.clone()) is None
+    masks.mul_(1.0)
+    assert al.mask_bits_of(masks) is None            # written in place since: the words may be stale
+    with pytest.raises(RuntimeError):
+        rvg.ransac_voting_layer_v3(masks, vertex, hn, mask_bits=bits[:, :-1].contiguous())

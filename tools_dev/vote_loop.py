@@ -12,6 +12,7 @@ ap.add_argument("--hn", type=int, default=1000)
 ap.add_argument("--iters", type=int, default=300)
 ap.add_argument("--frames", type=int, default=1)
 ap.add_argument("--agg", action="store_true")
+ap.add_argument("--bits", action="store_true", help="pass the aggregation layer's mask bit words (the scan skips the f32 planes)")
 ap.add_argument("--sets", type=int, default=1, help="distinct copies of the inputs, used in rotation (cold reads, as in bench.py)")
 a = ap.parse_args()
 dev = torch.device("cuda:0")
@@ -28,11 +29,13 @@ ws = torch.empty(lib.fpc_ransac_workspace_bytes(n, H, W, a.hn), dtype=torch.uint
 out = torch.empty((n, 2), device=dev)
 st = torch.cuda.current_stream().cuda_stream
 
+bits = al.mask_bits_of(mask) if a.bits else None
+bptr = bits.data_ptr() if bits is not None else None
 sets = [(mask, vertex)] + [(mask.clone(), xy.clone().permute(0, 2, 3, 1)) for _ in range(a.sets - 1)]
 
 def vote(seed):
     m, v = sets[seed % len(sets)]
-    nat.check(lib.fpc_ransac_voting_v3(m.data_ptr(), v.data_ptr(), sn, sh, sw, sc, n, None, H, W, a.hn, None, None,
+    nat.check(lib.fpc_ransac_voting_v3_bits(m.data_ptr(), bptr, v.data_ptr(), sn, sh, sw, sc, n, None, H, W, a.hn, None, None,
                                        seed, 0.999, 5, 30000, out.data_ptr(), None, None, None, None, None, None, None,
                                        ws.data_ptr(), ws.numel(), st), "vote")
 
@@ -48,4 +51,4 @@ for i in range(a.iters):
 e1.record(); torch.cuda.synchronize()
 dt = time.perf_counter() - t0
 ms = e0.elapsed_time(e1) / a.iters
-print(f"n={n} hn={a.hn} sets={a.sets} per-call {ms*1e3:.1f} us (wall {dt/a.iters*1e6:.1f} us)  alg {n*12*H*W/ms/1e6:.1f} GB/s  out0={out[0].tolist()}")
+print(f"n={n} hn={a.hn} sets={a.sets} bits={int(a.bits)} per-call {ms*1e3:.1f} us (wall {dt/a.iters*1e6:.1f} us)  alg {n*12*H*W/ms/1e6:.1f} GB/s  out0={out[0].tolist()}")
