@@ -182,7 +182,11 @@ def vote_roofline(model_gpu, cat, n_inst, reps, label, calls=10):
     alg = n_inst * 12 * H * W
     ach = alg / t / 1e9
     return {"bound": "hbm", "achieved": round(ach, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBPS, 5),
-            "traffic": None, "kernel": "fpc_ransac_voting_v3 launch sequence (k_vote_scan, k_vote_plan, k_vote_count, k_vote_final)",
+            "traffic": None, "kernel": "fpc_ransac_voting_v3_bits launch sequence (k_vote_scan, k_vote_plan, k_vote_count, k_vote_final)",
+            "mask_source": "bit words written by the aggregation layer (the model's pipeline): the scan does not read the f32 mask "
+                           "planes, so `traffic` is below the algorithmic bytes; `achieved` still prices SURVEY 8(d)'s 12 H W per "
+                           "instance, the bytes of the reference's own interface.  The stand-alone entry on f32 masks: "
+                           "profiles/r03_vote_traffic_*.json, r03_vote_*_kernel_stats.csv",
             "workload": label, "algorithmic_bytes_per_launch": alg, "launch_ms": round(t * 1e3, 4),
             "timing": f"HIP events around {calls} back-to-back calls on the launch stream / {calls}, median of {reps}"}
 
@@ -523,7 +527,7 @@ def main():
         roof = vote_roofline(ctx["model_gpu"], ctx["cat"], ctx["n_inst"], max(5, min(args.steps, 20)),
                              f"batch {args.batch}, hn {args.hn}, {ctx['n_inst']} instances")
         roof["measured_copy_GBps"] = measure_copy_ceiling(dev)
-        attach_profiled_counters(roof, "r03_vote_traffic_b1_hn1000.json" if (args.hn == 1000 and args.batch == 1) else None)
+        attach_profiled_counters(roof, "r03_vote_bits_traffic_b1_hn1000.json" if (args.hn == 1000 and args.batch == 1) else None)
         roof["note"] = ("HIP events on the launch stream around the whole call, live in this run; `traffic` and `valu` are PMC "
                         "counters of a separate profiled run of the same call (`from_profile` names the file and the commit it was "
                         "taken at): rocprofv3 cannot collect them inside this process")
@@ -561,7 +565,7 @@ def main():
             cat32_cpu, _ = synth.make_vote_batch(range(32))
             cat32 = {k: v.to(dev) for k, v in cat32_cpu.items()}
             line["roofline_hn128"] = vote_roofline(ctx["model_gpu"], cat32, 6 * 32, 9, "batch 32, hn 128, 192 instances", calls=10)
-            attach_profiled_counters(line["roofline_hn128"], "r03_vote_traffic_b32_hn128.json")
+            attach_profiled_counters(line["roofline_hn128"], "r03_vote_bits_traffic_b32_hn128.json")
             line["post_network"] = post_network_rates(ctx["model_gpu"], ctx["cat"], ctx["n_inst"], cat32, 6 * 32)
             hp128.HV_NUM_OF_HYPOTHESES = args.hn
             del cat32
