@@ -169,7 +169,7 @@ struct fpc_net {
         c.w_off = alloc((size_t)c.Npad * c.Kpad);
         if (bn_prefix) { c.scale_off = alloc(Cout); c.shift_off = alloc(Cout); }
         c.wino_ok = (k == 3 && stride == 1 && pad == 1 && c.Cinp == Cin && Cin % 8 == 0 && Cout % 64 == 0);
-        if (c.wino_ok) c.wino_off = alloc((size_t)16 * Cout * Cin);
+        if (c.wino_ok) c.wino_off = alloc((size_t)40 * Cout * Cin);      // f32 image (16 x) + split-precision image (24 x)
         convs.push_back(c);
         return (int)convs.size() - 1;
     }
@@ -365,6 +365,8 @@ extern "C" int fpc_net_load_params(fpc_net_t* n, const float* const* params, int
         if (c.wino_ok) {
             rc = launch_wino_pack(n->pptr[c.p_w], n->ws + c.wino_off, c.Cout, c.Cin, s);
             if (rc) return rc;
+            rc = launch_wino_pack_bf3(n->pptr[c.p_w], n->ws + c.wino_off + (size_t)16 * c.Cout * c.Cin, c.Cout, c.Cin, s);
+            if (rc) return rc;
         }
         if (c.p_bn >= 0) {
             rc = launch_fold_bn(n->pptr[c.p_bn], n->pptr[c.p_bn + 1], n->pptr[c.p_bn + 2], n->pptr[c.p_bn + 3], 1e-5f,
@@ -406,14 +408,14 @@ int launch_conv_plan(ConvArgs& a, const ConvPlan& p, int groups, hipStream_t s) 
         for (int g = 0; g < groups; ++g) {
             if (!a.wino_w[g] || a.p[g].up) return FPC_EINVAL;
             w.p[g] = a.p[g];
-            w.p[g].w = a.wino_w[g];
+            w.p[g].w = a.wino_w[g] + (p.wino == 5 ? (size_t)16 * a.Cout * a.Cin : 0);      // the split-precision image follows the f32 one
         }
-        w.variant = p.wino == 3 ? 1 : (p.wino == 4 ? 2 : 0);
+        w.variant = p.wino == 3 ? 1 : (p.wino == 4 ? 2 : (p.wino == 5 ? 3 : 0));
         w.zeros = a.zeros;
         w.dbg = (long long*)a.dbg;
         w.groups = groups;
         w.B = a.B; w.H = a.Ho; w.W = a.Wo; w.Cin = a.Cin; w.Cout = a.Cout; w.relu = a.relu;
-        w.waves = (p.wino == 2 || p.wino == 4) ? 8 : 4;
+        w.waves = (p.wino == 2 || p.wino == 4 || p.wino == 5) ? 8 : 4;
         w.tbx = cdiv(cdiv(a.Wo, 2), 8); w.tby = cdiv(cdiv(a.Ho, 2), w.waves);
         return launch_conv_wino(w, groups, s);
     }
@@ -428,7 +430,7 @@ int launch_conv_plan(ConvArgs& a, const ConvPlan& p, int groups, hipStream_t s) 
 
 // number of GroupNorm partial rows per image a plan writes
 int plan_gn_rows(const ConvPlan& p, int Ho, int Wo) {
-    return p.wino ? cdiv(cdiv(Wo, 2), 8) * cdiv(cdiv(Ho, 2), (p.wino == 2 || p.wino == 4) ? 8 : 4) : p.mtiles * p.bm / 32;
+    return p.wino ? cdiv(cdiv(Wo, 2), 8) * cdiv(cdiv(Ho, 2), (p.wino == 2 || p.wino == 4 || p.wino == 5) ? 8 : 4) : p.mtiles * p.bm / 32;
 }
 
 // Runs conv site `ci` with its current plan; in tuning mode first times every candidate tiling
@@ -451,6 +453,7 @@ int run_conv(fpc_net* n, ConvArgs& a, int groups, int ci, hipStream_t s) {
             wq.wino = 2; cands.push_back(wq);
             wq.wino = 3; cands.push_back(wq);
             if (a.zeros) { wq.wino = 4; cands.push_back(wq); }
+            if (n->split_precision && a.zeros) { wq.wino = 5; cands.push_back(wq); }      // split-precision products, 8 waves
         }
         for (const ConvPlan& q : cands) {
             if (splitk_floats_for(q, groups, a.B, a.Npad) > cap) continue;
@@ -468,9 +471,9 @@ int run_conv(fpc_net* n, ConvArgs& a, int groups, int ci, hipStream_t s) {
             // with several frames in flight a launch that leaves CUs free lets another stream's kernels run
             float score = ms;
             if (n->tune_mode == 1) {
-                double nblk = q.wino ? (double)cdiv(cdiv(a.Wo, 2), 8) * cdiv(cdiv(a.Ho, 2), (q.wino == 2 || q.wino == 4) ? 8 : 4) * a.B * (a.Cout / 64) * groups
+                double nblk = q.wino ? (double)cdiv(cdiv(a.Wo, 2), 8) * cdiv(cdiv(a.Ho, 2), (q.wino == 2 || q.wino == 4 || q.wino == 5) ? 8 : 4) * a.B * (a.Cout / 64) * groups
                                      : (double)q.mtiles * q.ntiles * q.nsplit * a.B * groups;
-                double slots = 256.0 * ((q.wino == 2 || q.wino == 4) ? 1.0 : 2.0);
+                double slots = 256.0 * ((q.wino == 2 || q.wino == 4 || q.wino == 5) ? 1.0 : 2.0);
                 double share = nblk / slots;
                 if (share > 1.0) share = 1.0;
                 if (share < 0.125) share = 0.125;
@@ -751,7 +754,7 @@ extern "C" size_t fpc_conv2d_workspace_bytes(int B, int Ho, int Wo, int Cin, int
     int K = Cin * Kh * Kw, Kpad = cdiv(K, kConvBK) * kConvBK, Npad = cdiv(Cout, kConvNAlign) * kConvNAlign;
     size_t packed = ((size_t)Npad * Kpad + 63) / 64 * 64;
     size_t splitk = (size_t)32 * B * (cdiv(Ho * Wo, 128) * 128) * Npad;
-    size_t wino = (size_t)16 * Cout * Cin + 64;      // + a zero page for the all-DMA Winograd form
+    size_t wino = (size_t)40 * Cout * Cin + 64;      // f32 + split-precision Winograd images + a zero page for the all-DMA form
     return (packed + splitk + wino + kConvTickets) * sizeof(float);
 }
 
@@ -762,7 +765,7 @@ extern "C" int fpc_conv2d_plan(int B, int Ho, int Wo, int Cin, int Cout, int Kh,
     if (nsplit >= 1000) nsplit -= 1000;      // fpc_conv2d's split-precision / two-launch hooks do not change the tiling
     if (nsplit >= 100) nsplit -= 100;
     ConvPlan p = plan_conv(Ho * Wo, B, Cout, Kpad / kConvBK, 1, bm, bn, nsplit);
-    if (nsplit <= -1 && nsplit >= -4) { p.wino = -nsplit; p.nsplit = nsplit; }
+    if (nsplit <= -1 && nsplit >= -5) { p.wino = -nsplit; p.nsplit = nsplit; }
     out4[0] = p.bm; out4[1] = p.bn; out4[2] = p.nsplit; out4[3] = plan_gn_rows(p, Ho, Wo);
     return FPC_OK;
 }
@@ -785,7 +788,7 @@ extern "C" int fpc_conv2d(const float* in, int64_t sb, int64_t sh, int64_t sw, i
     if (nsplit >= 1000) { bf3 = 1; nsplit -= 1000; }      // test hook: 1000 + split = split-precision matrix products
     bool two_launch = false;
     if (nsplit >= 100) { two_launch = true; nsplit -= 100; }      // test hook: 100 + split = split-K summed by k_conv_splitk_epilogue
-    bool wino = nsplit <= -1 && nsplit >= -4;      // -1: 4 waves, -2: 8 waves, -3: 4 waves wave-private, -4: 8 waves all-DMA 3-stage
+    bool wino = nsplit <= -1 && nsplit >= -5;      // -1: 4 waves, -2: 8 waves, -3: 4 waves wave-private, -4: 8 waves all-DMA 3-stage, -5: 8 waves split precision
     ConvPlan p = plan_conv(Ho * Wo, B, Cout, c.Kpad / kConvBK, 1, wino ? 0 : bm, bn, wino ? 1 : nsplit);
     p.bf3 = bf3;
     if (two_launch) p.fused = 0;
@@ -800,7 +803,7 @@ extern "C" int fpc_conv2d(const float* in, int64_t sb, int64_t sh, int64_t sw, i
     a.p[0] = ConvPtrs{in, packed, out, scale, shift, res, up, gn_part};
     a.zeros = nullptr;
     {   // arrival counters of the fused split-K form: behind the Winograd region, zeroed per call
-        float* tk = packed + tmp.splitk_off + (size_t)32 * B * (cdiv(Ho * Wo, 128) * 128) * c.Npad + (size_t)16 * Cout * Cin + 64;
+        float* tk = packed + tmp.splitk_off + (size_t)32 * B * (cdiv(Ho * Wo, 128) * 128) * c.Npad + (size_t)40 * Cout * Cin + 64;
         a.tickets = (int*)tk;
         if (p.fused && hipMemsetAsync(tk, 0, kConvTickets * sizeof(int), s) != hipSuccess) return FPC_ELAUNCH;
     }
@@ -814,8 +817,9 @@ extern "C" int fpc_conv2d(const float* in, int64_t sb, int64_t sh, int64_t sw, i
             return FPC_EINVAL;
         float* wp = packed + tmp.splitk_off + (size_t)32 * B * (cdiv(Ho * Wo, 128) * 128) * c.Npad;
         FPC_TRY(launch_wino_pack(w_oihw, wp, Cout, Cin, s));
+        if (nsplit == -5) FPC_TRY(launch_wino_pack_bf3(w_oihw, wp + (size_t)16 * Cout * Cin, Cout, Cin, s));
         a.wino_w[0] = wp;
-        float* zp = wp + (size_t)16 * Cout * Cin;
+        float* zp = wp + (size_t)40 * Cout * Cin;
         if (hipMemsetAsync(zp, 0, 64 * sizeof(float), s) != hipSuccess) return FPC_ELAUNCH;
         a.zeros = zp;
         p.wino = -nsplit;

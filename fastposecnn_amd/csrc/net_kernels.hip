@@ -1217,15 +1217,23 @@ constexpr int kWinoLdsW = 16 * kWinoBN * 8;             // 8192 floats (32 KB) p
 // LDS stages, the loads of step k+2 are issued before step k's MFMAs and the wave waits with a COUNTED
 // vmcnt (the newest batch stays in flight across the raw s_barrier) — guide "Pipelining across barriers".
 // DBG: diagnostic instantiations that stamp the K-loop phases with s_memtime (tools_dev/wino_stamps.py).
-template <int NW, bool WP, bool P3, bool DBG = false>
-__global__ __launch_bounds__(64 * NW, 2) void k_conv_wino(const WinoArgs a) {
+// BF3 (NW = 8, barrier form): split-precision products.  The transformed input tile is split EXACTLY into three bf16
+// pieces per value between the MFMAs, the weights arrive pre-split (k_wino_pack_bf3: a 32 KB {b1, b2} image in the f32
+// image's own layout + a 16 KB {b3} image per K-step), and the 8-channel K-step of a 32 x 32 tile is THREE
+// v_mfma_f32_32x32x16_bf16 (slots: a1 b1, a1 b2 | a2 b1, a2 b2 | a1 b3, a3 b1 for the lane half's four channels;
+// dropped products < 2^-23 of the term, f32 accumulation) instead of four v_mfma_f32_32x32x2_f32: 96 instead of 256
+// matrix cycles.  118 KB of LDS: one 8-wave workgroup per CU, as the f32 8-wave form.
+template <int NW, bool WP, bool P3, bool DBG = false, bool BF3 = false>
+__global__ __launch_bounds__(64 * NW, BF3 ? 1 : 2) void k_conv_wino(const WinoArgs a) {
     constexpr int TY = NW;                                  // tile rows of the patch
     constexpr int RH = 2 * TY + 2, POS = kWinoRW * RH;      // staged input region
     constexpr int NT = 8 * NW;                              // tiles per workgroup
     constexpr int WPI = 8 * kWinoRW * kWinoIS;              // WP: floats of a wave's private input patch (8 rows)
     constexpr int IP3 = 512 * kWinoIS;                      // P3: floats per input stage (16 pieces of 1 KB, 324 positions used)
     constexpr int NPI = (POS + 31) / 32, LINP = NPI * 256;   // barrier form: 1 KB input pieces per stage, floats per input buffer
-    constexpr int kLdsFloats = WP ? (kWinoLdsW + 4 * WPI) : P3 ? (3 * IP3 + 3 * kWinoLdsW) : (2 * LINP + 2 * kWinoLdsW);
+    constexpr int kWB = BF3 ? 12288 : kWinoLdsW;            // floats per weight buffer (BF3: 32 KB {b1, b2} + 16 KB {b3})
+    constexpr int kLdsFloats = WP ? (kWinoLdsW + 4 * WPI) : P3 ? (3 * IP3 + 3 * kWinoLdsW) : (2 * LINP + 2 * kWB);
+    static_assert(!BF3 || (NW == 8 && !WP && !P3), "split precision rides on the 8-wave barrier form");
     static_assert(!WP || NW == 4, "wave-private form is written for 4 waves");
     static_assert(!P3 || (NW == 8 && !WP), "three-stage DMA form is written for 8 waves");
     static_assert(kLdsFloats >= 2 * 4 * NT * 32, "output transform needs 2*4*NT*32 floats");
@@ -1499,7 +1507,8 @@ __global__ __launch_bounds__(64 * NW, 2) void k_conv_wino(const WinoArgs a) {
     // back, a global_load* with a 64-bit VGPR address waits like a vector-ALU instruction (one per MFMA; a pure
     // MFMA partner starves it: 1550 cycles against 12 for the SGPR-base form — tools_dev/dma_vs_mfma.hip).
     // The bases advance on the scalar unit, the lane offsets never change: no vector instruction per K-step.
-    const float* wsb = P.w + (size_t)nb * nkb * kWinoLdsW + swv * NPIECE * 256;     // wave-uniform: this wave's pieces of step 0
+    const float* wsb = P.w + (size_t)nb * nkb * kWB + swv * NPIECE * 256;           // wave-uniform: this wave's pieces of step 0
+    const float* wsb3 = P.w + (size_t)nb * nkb * kWB + 8192 + swv * 512;            // BF3: its two pieces of the {b3} image
     const float* isb = P.in + (size_t)b * HW * Cin;                                // image base, + 8 floats per step
     const unsigned wvo = 16u * lane;                                               // bytes
     unsigned ivo[2];
@@ -1527,8 +1536,12 @@ __global__ __launch_bounds__(64 * NW, 2) void k_conv_wino(const WinoArgs a) {
             asm volatile("s_mov_b32 m0, %0\n s_nop 0\n"                                                       \
                          "global_load_lds_dwordx4 %1, %2\n global_load_lds_dwordx4 %1, %2 offset:1024\n"      \
                          "global_load_lds_dwordx4 %1, %2 offset:2048\n global_load_lds_dwordx4 %1, %2 offset:3072\n" \
-                         :: "s"(FPC_LDS_ADDR(lds_w + (BUF) * kWinoLdsW + (swv * NPIECE + 4 * g) * 256)), "v"(wvo), \
+                         :: "s"(FPC_LDS_ADDR(lds_w + (BUF) * kWB + (swv * NPIECE + 4 * g) * 256)), "v"(wvo),       \
                             "s"(wsb + 1024 * g) : "memory", "m0");                                            \
+        if constexpr (BF3)                                                                                    \
+            asm volatile("s_mov_b32 m0, %0\n s_nop 0\n"                                                       \
+                         "global_load_lds_dwordx4 %1, %2\n global_load_lds_dwordx4 %1, %2 offset:1024\n"      \
+                         :: "s"(FPC_LDS_ADDR(lds_w + (BUF) * kWB + 8192 + swv * 512)), "v"(wvo), "s"(wsb3) : "memory", "m0"); \
     } while (0)
     // input region of one K-step -> input buffer BUF (in-image lanes only)
 #define FPC_WB_ISSUE_IN(BUF)                                                                                  \
@@ -1569,7 +1582,7 @@ __global__ __launch_bounds__(64 * NW, 2) void k_conv_wino(const WinoArgs a) {
     // last step's operands once more into buffers nobody reads.
     FPC_WB_ISSUE_W(0);
     FPC_WB_ISSUE_IN(0);
-    if (nkb > 1) { wsb += kWinoLdsW; isb += 8; }
+    if (nkb > 1) { wsb += kWB; wsb3 += kWB; isb += 8; }
     FPC_WB_ISSUE_IN(1);
     if (nkb > 2) isb += 8;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1583,6 +1596,18 @@ __global__ __launch_bounds__(64 * NW, 2) void k_conv_wino(const WinoArgs a) {
                                              *reinterpret_cast<const f32x4*>(lds + in_a + c * kWinoIS));
         v[0] = sub_pk(e[0], e[2]); v[1] = e[1] + e[2]; v[2] = sub_pk(e[2], e[1]); v[3] = sub_pk(e[1], e[3]);
     }
+    // BF3: the three bf16 pieces of the transformed fragments (four channels per piece and xi), and the {b3} fragment offsets
+    u32x2 pa[4][3];
+    int w3_frag[2];
+    if constexpr (BF3) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) split_bf3(v[j], pa[j][0], pa[j][1], pa[j][2]);
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+            int co = nt * 32 + li;
+            w3_frag[nt] = 8192 + ((4 * wi) * kWinoBN + co) * 4 + 2 * (lh ^ ((co >> 4) & 1));      // halves swapped per 16 channels (k_wino_pack_bf3)
+        }
+    }
     __syncthreads();       // I[0] is refilled by step 0's DMA
     long long stamp[6] = {0, 0, 0, 0, 0, 0};
     const bool dbg = DBG && a.dbg != nullptr;
@@ -1594,13 +1619,67 @@ __global__ __launch_bounds__(64 * NW, 2) void k_conv_wino(const WinoArgs a) {
     for (int kb = 0; kb < nkb; ++kb) {
         FPC_WB_ISSUE_W(cur ^ 1);
         FPC_WB_ISSUE_IN(cur);
-        wsb += kb + 2 < nkb ? kWinoLdsW : 0;
+        wsb += kb + 2 < nkb ? kWB : 0;
+        wsb3 += kb + 2 < nkb ? kWB : 0;
         isb += kb + 3 < nkb ? 8 : 0;
         FPC_STAMP(0);      // issue of the staging loads
         const float* In = lds + (cur ^ 1) * LINP;
-        const float* Wb = lds_w + cur * kWinoLdsW;
+        const float* Wb = lds_w + cur * kWB;
         f32x4 da[4], db[4], e[4], vn[4];
         __builtin_amdgcn_s_setprio(1);      // MFMA issue ahead of the co-resident workgroup's staging
+        if constexpr (BF3) {
+            u32x4 u0 = *reinterpret_cast<const u32x4*>(Wb + w_frag[0]), u1 = *reinterpret_cast<const u32x4*>(Wb + w_frag[1]);
+            u32x2 t0 = *reinterpret_cast<const u32x2*>(Wb + w3_frag[0]), t1 = *reinterpret_cast<const u32x2*>(Wb + w3_frag[1]);
+            u32x2 pn[4][3];
+#define FPC_BF3_MFMA(A, B0, B1)                                                                               \
+    do {                                                                                                      \
+        acc[j][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, A), __builtin_bit_cast(bf16x8, B0), acc[j][0], 0, 0, 0); \
+        acc[j][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, A), __builtin_bit_cast(bf16x8, B1), acc[j][1], 0, 0, 0); \
+    } while (0)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                u32x4 n0 = u0, n1 = u1;
+                u32x2 m0 = t0, m1 = t1;
+                if (j < 3) {
+                    n0 = *reinterpret_cast<const u32x4*>(Wb + w_frag[0] + (j + 1) * kWinoBN * 8);
+                    n1 = *reinterpret_cast<const u32x4*>(Wb + w_frag[1] + (j + 1) * kWinoBN * 8);
+                    m0 = *reinterpret_cast<const u32x2*>(Wb + w3_frag[0] + (j + 1) * kWinoBN * 4);
+                    m1 = *reinterpret_cast<const u32x2*>(Wb + w3_frag[1] + (j + 1) * kWinoBN * 4);
+                }
+                if (j < 2) {
+#pragma unroll
+                    for (int c = 2 * j; c < 2 * j + 2; ++c) {
+                        da[c] = *reinterpret_cast<const f32x4*>(In + in_a + c * kWinoIS);
+                        db[c] = *reinterpret_cast<const f32x4*>(In + in_b + c * kWinoIS);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                const u32x4 A0 = {pa[j][0][0], pa[j][0][1], pa[j][0][0], pa[j][0][1]};
+                const u32x4 A1 = {pa[j][1][0], pa[j][1][1], pa[j][1][0], pa[j][1][1]};
+                const u32x4 A2 = {pa[j][0][0], pa[j][0][1], pa[j][2][0], pa[j][2][1]};
+                const u32x4 C0 = {t0[0], t0[1], u0[0], u0[1]}, C1 = {t1[0], t1[1], u1[0], u1[1]};
+                FPC_BF3_MFMA(A0, u0, u1);      // a1 b1 + a1 b2
+                // the next step's fragments in the shadow of this wave's own MFMAs: transform at xi 0 / 1, split at xi 2 / 3
+                if (j == 0) { e[0] = __builtin_elementwise_fma(sg4, db[0], da[0]); e[1] = __builtin_elementwise_fma(sg4, db[1], da[1]); }
+                if (j == 1) { e[2] = __builtin_elementwise_fma(sg4, db[2], da[2]); e[3] = __builtin_elementwise_fma(sg4, db[3], da[3]); }
+                if (j == 2) split_bf3(vn[0], pn[0][0], pn[0][1], pn[0][2]);
+                if (j == 3) split_bf3(vn[2], pn[2][0], pn[2][1], pn[2][2]);
+                __builtin_amdgcn_sched_barrier(0);
+                FPC_BF3_MFMA(A1, u0, u1);      // a2 b1 + a2 b2
+                if (j == 1) { vn[0] = sub_pk(e[0], e[2]); vn[1] = e[1] + e[2]; }
+                if (j == 2) split_bf3(vn[1], pn[1][0], pn[1][1], pn[1][2]);
+                if (j == 3) split_bf3(vn[3], pn[3][0], pn[3][1], pn[3][2]);
+                __builtin_amdgcn_sched_barrier(0);
+                FPC_BF3_MFMA(A2, C0, C1);      // a1 b3 + a3 b1
+                if (j == 1) { vn[2] = sub_pk(e[2], e[1]); vn[3] = sub_pk(e[1], e[3]); }
+                __builtin_amdgcn_sched_barrier(0);
+                u0 = n0; u1 = n1; t0 = m0; t1 = m1;
+            }
+#undef FPC_BF3_MFMA
+            __builtin_amdgcn_s_setprio(0);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { pa[j][0] = pn[j][0]; pa[j][1] = pn[j][1]; pa[j][2] = pn[j][2]; }
+        } else {
         f32x4 u0 = *reinterpret_cast<const f32x4*>(Wb + w_frag[0]);
         f32x4 u1 = *reinterpret_cast<const f32x4*>(Wb + w_frag[1]);
 #pragma unroll
@@ -1635,6 +1714,7 @@ __global__ __launch_bounds__(64 * NW, 2) void k_conv_wino(const WinoArgs a) {
         }
         __builtin_amdgcn_s_setprio(0);
         v[0] = vn[0]; v[1] = vn[1]; v[2] = vn[2]; v[3] = vn[3];
+        }
         FPC_STAMP(2);      // MFMA issue + the next step's fragments (not completion)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's DMA pieces have landed
         FPC_STAMP(3);
@@ -1762,13 +1842,57 @@ __global__ __launch_bounds__(256) void k_wino_pack(const float* __restrict__ w, 
     }
 }
 
+// The same U, every value split exactly into three bf16 pieces (truncation split, as split_bf3), packed per K-step as
+// [Cout/64][Cin/8][ 16 xi x 64 co x {half slot: b1 x 4 ch, b2 x 4 ch} (32 KB, the f32 image's addressing) | 16 xi x 64 co x
+// {half slot: b3 x 4 ch} (16 KB) ]; half slots swapped on odd 8-channel (main) / 16-channel ({b3}) groups of co.
+__global__ __launch_bounds__(256) void k_wino_pack_bf3(const float* __restrict__ w, unsigned short* __restrict__ out, int Cout,
+                                                       int Cin) {
+    long long total = (long long)Cout * Cin;
+    for (long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (long long)gridDim.x * blockDim.x) {
+        int ci = (int)(g % Cin), co = (int)(g / Cin);
+        const float* k = w + ((size_t)co * Cin + ci) * 9;
+        float gg[4][3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            float g0 = k[c], g1 = k[3 + c], g2 = k[6 + c];
+            gg[0][c] = g0;
+            gg[1][c] = 0.5f * (g0 + g1 + g2);
+            gg[2][c] = 0.5f * (g0 - g1 + g2);
+            gg[3][c] = g2;
+        }
+        const int nb = co >> 6, col = co & 63, kb = ci >> 3, cil = ci & 7, hw = cil >> 2, e = cil & 3;
+        unsigned short* img = out + ((size_t)nb * (Cin >> 3) + kb) * (12288 * 2);
+        unsigned short* dm = img + col * 16 + 8 * (hw ^ ((col >> 3) & 1)) + e;                      // + xi * 1024;  b2 at + 4
+        unsigned short* d3 = img + 8192 * 2 + col * 8 + 4 * (hw ^ ((col >> 4) & 1)) + e;            // + xi * 512
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            float r0 = gg[i][0], r1 = gg[i][1], r2 = gg[i][2];
+            const float u[4] = {r0, 0.5f * (r0 + r1 + r2), 0.5f * (r0 - r1 + r2), r2};
+#pragma unroll
+            for (int jx = 0; jx < 4; ++jx) {
+                const int xi = 4 * i + jx;
+                const float x = u[jx];
+                const unsigned xb = __builtin_bit_cast(unsigned, x) & 0xFFFF0000u;
+                const float r = x - __builtin_bit_cast(float, xb);
+                const unsigned rb = __builtin_bit_cast(unsigned, r) & 0xFFFF0000u;
+                const float q = r - __builtin_bit_cast(float, rb);
+                dm[xi * 1024] = (unsigned short)(xb >> 16);
+                dm[xi * 1024 + 4] = (unsigned short)(rb >> 16);
+                d3[xi * 512] = (unsigned short)(__builtin_bit_cast(unsigned, q) >> 16);
+            }
+        }
+    }
+}
+
 int launch_conv_wino(const WinoArgs& a, int groups, hipStream_t s) {
     if (groups < 1 || groups > kMaxGroup || a.Cin % 8 != 0 || a.Cout % kWinoBN != 0 || (a.waves != 4 && a.waves != 8))
         return FPC_EINVAL;
     dim3 grid(a.tbx * a.tby * a.B * (a.Cout / kWinoBN) * groups);
     if (a.variant != 1 && !a.zeros) return FPC_EINVAL;
     if ((long long)a.H * a.W * a.Cin * (long long)sizeof(float) >= (1LL << 32)) return FPC_EINVAL;   // 32-bit lane offsets inside one image
-    if (a.waves == 8 && a.variant == 2) {
+    if (a.waves == 8 && a.variant == 3) {
+        hipLaunchKernelGGL((k_conv_wino<8, false, false, false, true>), grid, dim3(512), 0, s, a);
+    } else if (a.waves == 8 && a.variant == 2) {
         if (a.dbg) hipLaunchKernelGGL((k_conv_wino<8, false, true, true>), grid, dim3(512), 0, s, a);
         else hipLaunchKernelGGL((k_conv_wino<8, false, true>), grid, dim3(512), 0, s, a);
     } else if (a.waves == 8 && a.dbg) hipLaunchKernelGGL((k_conv_wino<8, false, false, true>), grid, dim3(512), 0, s, a);
@@ -1782,6 +1906,14 @@ int launch_conv_wino(const WinoArgs& a, int groups, hipStream_t s) {
 int launch_wino_pack(const float* w_oihw, float* packed, int Cout, int Cin, hipStream_t s) {
     if (Cin % 8 != 0 || Cout % kWinoBN != 0) return FPC_EINVAL;
     hipLaunchKernelGGL(k_wino_pack, dim3(stream_grid((long long)Cout * Cin)), dim3(256), 0, s, w_oihw, packed, Cout, Cin);
+    return check_launch();
+}
+
+// split-precision image: 24 * Cout * Cin floats (every byte is written)
+int launch_wino_pack_bf3(const float* w_oihw, float* packed, int Cout, int Cin, hipStream_t s) {
+    if (Cin % 8 != 0 || Cout % kWinoBN != 0) return FPC_EINVAL;
+    hipLaunchKernelGGL(k_wino_pack_bf3, dim3(stream_grid((long long)Cout * Cin)), dim3(256), 0, s, w_oihw,
+                       reinterpret_cast<unsigned short*>(packed), Cout, Cin);
     return check_launch();
 }
 

@@ -81,13 +81,15 @@ struct WinoArgs {
     ConvPtrs p[kMaxGroup];   // .w = Winograd-packed weights [Cout/64][Cin/8][16][64][8]; .up unused
     long long* dbg;          // diagnostic builds: per (workgroup, wave) cycle sums of the K-loop phases, or null
     const float* zeros;      // >= 16 bytes of zeros, 16-byte aligned (source of out-of-image DMA pieces; variant 2)
-    int variant;             // 0: barrier form, 1: wave-private barrier-free K loop (4 waves), 2: all-DMA 3-stage (8 waves)
+    int variant;             // 0: barrier form, 1: wave-private barrier-free K loop (4 waves), 2: all-DMA 3-stage (8 waves),
+                             // 3: split-precision barrier form (8 waves; .w = the k_wino_pack_bf3 image)
     int groups;
     int waves;               // 4: 8x4 tile patch per workgroup; 8: 8x8 patch (512 threads)
     int B, H, W, Cin, Cout, relu, tbx, tby;   // tbx = ceil(ceil(W/2)/8), tby = ceil(ceil(H/2)/waves) tile patches
 };
 int launch_conv_wino(const WinoArgs& a, int groups, hipStream_t s);
 int launch_wino_pack(const float* w_oihw, float* packed, int Cout, int Cin, hipStream_t s);
+int launch_wino_pack_bf3(const float* w_oihw, float* packed, int Cout, int Cin, hipStream_t s);
 int launch_conv(const ConvArgs& a, int groups, hipStream_t s);
 int launch_conv_splitk_epilogue(const ConvArgs& a, int groups, hipStream_t s);
 int launch_maxpool3x3s2(const float* in, float* out, int B, int Hi, int Wi, int C, int Ho, int Wo, hipStream_t s);

@@ -249,7 +249,7 @@ class PoseRegressor(Model, torch.nn.Module):
                             autotune=getattr(self.HPARAM, 'ENGINE_AUTOTUNE', True),
                             tune_mode=int(getattr(self.HPARAM, 'ENGINE_TUNE_MODE', 0)),
                             graph=bool(getattr(self.HPARAM, 'ENGINE_GRAPH', True)),
-                            split_precision=bool(getattr(self.HPARAM, 'ENGINE_SPLIT_PRECISION', False)))
+                            split_precision=bool(getattr(self.HPARAM, 'ENGINE_SPLIT_PRECISION', True)))
             eng.generation = self._weights_gen[0]
             self._engines[key] = eng
         elif eng.stale() or eng.generation != self._weights_gen[0]:

@@ -307,10 +307,13 @@ int fpc_net_forward(fpc_net_t* net, const float* x, float* logits_mask, float* l
  * fpc_net_conv_plan reports the tiling in use for convolution i: out5 = bm, bn, nsplit, Cout, K. */
 int fpc_net_autotune_next(fpc_net_t* net, int mode /* 0: minimise each conv's latency; 1: latency x sqrt(share of
                                                       the chip its grid occupies) — for several frames in flight */);
-/* Split-precision matrix products (default 0).  1: autotuning may replace the f32 matrix instructions of a direct
- * convolution by three bf16 planes per operand and the six products with i + j <= 4 on v_mfma_f32_32x32x16_bf16
- * (f32 accumulation): f32-level accuracy (~2^-24 relative per product), not bit-identical to the f32 chain.
- * Set before fpc_net_autotune_next. */
+/* Split-precision matrix products (library default 0; the Python front end turns it on unless
+ * HPARAM.ENGINE_SPLIT_PRECISION is False).  1: autotuning may replace the f32 matrix instructions of a direct OR a
+ * Winograd convolution by the exact three-way bf16 split of both operands (x = x1 + x2 + x3, each piece 8 significant
+ * bits) and the six partial products with i + j <= 4 on v_mfma_f32_32x32x16_bf16, accumulated in f32: every kept product
+ * is exact, the dropped ones are < 2^-23 of the term, so the result has f32-level accuracy (2.4e-7 of max|ref| against
+ * float64, like another summation order) without being bit-identical to the f32 product chain.  Set before
+ * fpc_net_autotune_next.  fpc_net_conv_plan reports -5 for a split-precision Winograd site. */
 int fpc_net_set_split_precision(fpc_net_t* net, int on);
 /* HIP graph replay (default 0).  1: after autotuning, the frame-invariant launches of fpc_net_forward (everything
  * between the image conversion and the final upsample / class compression, ~57 kernels on the plan's workspace) are

@@ -118,6 +118,12 @@ CONV_CASES = [
     (1, 128, 16, 24, 128, 3, 1, 1, (64, 128, 1001), "gn"),
     (2, 64, 24, 32, 256, 1, 1, 0, (64, 64, 1001), "bias_up"),     # FPN lateral
     (1, 64, 24, 32, 128, 1, 2, 0, (128, 64, 1001), "bn"),         # 1x1 stride 2
+    # split-precision Winograd (nsplit = -5): transformed tiles split into three bf16 pieces, three bf16 MFMAs per K-step, 8 waves
+    (1, 64, 30, 40, 64, 3, 1, 1, (0, 0, -5), "bn_relu_res"),
+    (2, 256, 15, 20, 128, 3, 1, 1, (0, 0, -5), "gn"),
+    (1, 128, 34, 50, 128, 3, 1, 1, (0, 0, -5), "gn"),
+    (1, 8, 7, 9, 64, 3, 1, 1, (0, 0, -5), "bias_relu"),       # a single K-step
+    (1, 16, 20, 24, 64, 3, 1, 1, (0, 0, -5), "bias_relu"),    # two K-steps
     # 8-wave form (8x8 tile patch per workgroup, nsplit = -2)
     (1, 64, 30, 40, 64, 3, 1, 1, (0, 0, -2), "bn_relu_res"),
     (2, 256, 15, 20, 128, 3, 1, 1, (0, 0, -2), "gn"),
@@ -515,12 +521,14 @@ def test_graph_replay_is_bit_identical(lib, dev):
     assert torch.equal(lg["mask"], plain[0]["mask"])
 
 
-def test_engine_split_precision_meets_the_f32_bar(lib, dev):
-    """HPARAM.ENGINE_SPLIT_PRECISION (opt-in): autotuning may pick the bf16 x 3 form of the direct convolutions.
-    The whole network must stay within the same 1e-4 bar against the float64 CPU reference as the f32 engine."""
+@pytest.mark.parametrize("split", [True, False], ids=["split-precision", "plain-f32-products"])
+def test_engine_split_precision_meets_the_f32_bar(lib, dev, split):
+    """HPARAM.ENGINE_SPLIT_PRECISION (default on): autotuning may pick the bf16 x 3 form of the direct AND the Winograd
+    convolutions (every f32 operand split exactly into three bf16 pieces, six partial products, f32 accumulation).  The
+    whole network must stay within the same 1e-4 bar against the float64 CPU reference as with plain f32 products."""
     from fastposecnn_amd import synth
     m, hp = _model(lib, dev, "resnet18")
-    hp.ENGINE_SPLIT_PRECISION = True
+    hp.ENGINE_SPLIT_PRECISION = split
     x = torch.stack([synth.make_image(i, 64, 96) for i in range(2)])
     import copy
     ref_m = copy.deepcopy(m).double()
@@ -531,6 +539,8 @@ def test_engine_split_precision_meets_the_f32_bar(lib, dev):
     with torch.no_grad():
         out = m(x.to(dev))
     assert m._engines
+    plans = next(iter(m._engines.values())).conv_plans()
+    assert split or not any(p[2] == -5 for p in plans)          # -5 = the split-precision Winograd form
     for k in ("mask", "quaternion", "scales", "xy", "z"):
         got = out["logits"][k].cpu().double()
         err = (got - ref[k]).abs().max().item()
