@@ -446,6 +446,9 @@ def run_inference(args, encoder, Bq, hn, steps, warmup, world, rank, dev, want_b
                            "achieved_executed": round(tf_exec, 2), "achieved_direct_equiv": round(tf_direct, 2),
                            "executed_gflop_per_step": round(executed / 1e9, 2), "direct_gflop_per_step": round(direct / 1e9, 2),
                            "winograd_share_of_direct_flop": round(wino_share, 3),
+                           "peak_note": "157.3 TFLOP/s = the f32 matrix-core peak; split-precision sites (config.matrix_products) issue six "
+                                        "bf16 products per multiply-add: 2500 / 6 = 416.7 TFLOP/s f32-equivalent is their ceiling",
+                           "frac_of_bf16x3_equiv_peak": round(tf_exec / (2500.0 / 6.0), 4),
                            "timing": "HIP events on the network's stream around 8 back-to-back forwards (+ class compression) / 8, median of 9",
                            "note": "`achieved` / `frac` price the multiply-adds the engine's current plans execute (a Winograd "
                                    "F(2x2,3x3) site does 1/2.25 of the direct convolution's); achieved_direct_equiv divides "
@@ -542,6 +545,13 @@ def main():
                        "vote_only": bool(args.vote_only), "frames_in_flight": res["frames_in_flight"],
                        "net_streams": res["net_streams"], "ms_per_frame_one_in_flight": res["ms_per_frame_one_in_flight"],
                        "pose_gather": res["pose_gather"],
+                       "matrix_products": ("f32 operands, f32 accumulation, f32 results (dtype f32).  Where the autotuner finds it "
+                                           "faster a convolution's products run as the EXACT three-way bf16 split of both operands "
+                                           "(six partial products on v_mfma_f32_32x32x16_bf16, dropped terms < 2^-23: 2.4e-7 of "
+                                           "max|ref| against float64, the same 1e-4 parity bar, tests/test_gpu_net.py); "
+                                           "FPC_SPLIT_PRECISION=0 keeps every product on v_mfma_f32_32x32x2_f32")
+                                          if os.environ.get("FPC_SPLIT_PRECISION", "1") != "0" else
+                                          "plain f32 matrix products (v_mfma_f32_32x32x2_f32) everywhere: FPC_SPLIT_PRECISION=0",
                        "post_network_input": "synthetic vote-bench fixture (SURVEY.md 8d), not the random-weight network's output",
                        "img_per_s_from_host_u8_frames": res.get("host_frames_img_per_s"),
                        "img_per_s_from_png_files": res.get("png_files_img_per_s"),
