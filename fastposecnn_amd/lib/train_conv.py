@@ -11,7 +11,8 @@ autograd.Function over three native pieces, all on channel-last (NHWC) activatio
                  split over the pixels; Cin % 64 != 0 (stem) or Cout % 4 != 0 (odd-width heads): aten's backward
 
 The tiling / Winograd form of a shape is chosen once, by timing the candidates on the first call with that shape (this
-synchronises: it happens in the warm-up steps).  Results are f32 products accumulated in f32, like the inference path.
+synchronises: it happens in the warm-up steps).  f32 operands, accumulation and results, products in plain f32 or as the
+exact bf16 x 3 split (FPC_SPLIT_PRECISION, default on), like the inference path.
 `ENABLED = False` (or FPC_TRAIN_NATIVE_CONV=0) returns every convolution to torch's own kernels.
 """
 import os
@@ -21,6 +22,7 @@ import torch
 from fastposecnn_amd import _native as nat
 
 ENABLED = bool(int(os.environ.get("FPC_TRAIN_NATIVE_CONV", "1")))
+SPLIT_PRECISION = bool(int(os.environ.get("FPC_SPLIT_PRECISION", "1")))      # the bf16 x 3 product forms may be chosen
 _plan_cache = {}            # (device index, B, Cin, H, W, Cout, k, stride, pad) -> nsplit code of fpc_conv2d
 counters = {"fwd_native": 0, "dgrad_native": 0, "wgrad_native": 0, "dgrad_aten": 0, "wgrad_aten": 0}
 
@@ -50,9 +52,11 @@ def conv_nhwc(x, w, bias, stride, pad):
     key = (x.device.index, B, Cin, H, W, Cout, Kh, stride, pad)
     code = _plan_cache.get(key)
     if code is None:
-        cands = [0]
+        cands = [0] + ([1000] if SPLIT_PRECISION else [])      # heuristic tiling; the same with split-precision products
         if Kh == 3 and Kw == 3 and stride == 1 and pad == 1 and Cin % 8 == 0 and Cout % 64 == 0:
             cands += [-1, -2, -4]       # Winograd F(2x2,3x3): 4 waves, 8 waves, 8 waves all-DMA
+            if SPLIT_PRECISION:
+                cands.append(-5)        # 8 waves, split-precision products
         best = (float("inf"), 0)
         ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
         for c in cands:
