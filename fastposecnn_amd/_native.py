@@ -73,6 +73,7 @@ _SIGNATURES = {
     "fpc_net_tensor": (_i, [_vp, ctypes.c_char_p, ctypes.POINTER(_vp), ctypes.POINTER(_i), ctypes.POINTER(_i),
                             ctypes.POINTER(_i)]),
     "fpc_conv2d_workspace_bytes": (_sz, [_i, _i, _i, _i, _i, _i, _i]),
+    "fpc_conv2d_workspace_bytes_for": (_sz, [_i, _i, _i, _i, _i, _i, _i, _i, _i, _i]),
     "fpc_conv2d_plan": (_i, [_i, _i, _i, _i, _i, _i, _i, _i, _i, _i, ctypes.POINTER(_i)]),
     "fpc_conv2d": (_i, [_vp, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i,
                         _i, _i, _i, _i, _i, _vp, _sz, _vp]),

@@ -770,6 +770,48 @@ extern "C" int fpc_conv2d_plan(int B, int Ho, int Wo, int Cin, int Cout, int Kh,
     return FPC_OK;
 }
 
+namespace {
+// the hooks folded into fpc_conv2d's `nsplit` argument
+struct Conv2dRequest { int nsplit; bool bf3, two_launch, wino; };
+Conv2dRequest conv2d_request(int nsplit) {
+    Conv2dRequest r{nsplit, false, false, false};
+    if (r.nsplit >= 1000) { r.bf3 = true; r.nsplit -= 1000; }          // 1000 + split = split-precision matrix products
+    if (r.nsplit >= 100) { r.two_launch = true; r.nsplit -= 100; }      // 100 + split = split-K summed by k_conv_splitk_epilogue
+    r.wino = r.nsplit <= -1 && r.nsplit >= -5;      // -1: 4 waves, -2: 8 waves, -3: wave-private, -4: all-DMA 3-stage, -5: 8 waves split precision
+    return r;
+}
+// workspace of ONE fpc_conv2d call (floats): [packed weights | split-K partials of this plan | Winograd images + zero page |
+// arrival counters]; regions a plan does not use are empty
+struct Conv2dLayout { size_t packed, splitk, wino, tickets, total; };
+Conv2dLayout conv2d_layout(int B, int Cin, int Cout, int Kh, int Kw, const ConvPlan& p, const Conv2dRequest& r) {
+    const int K = Cin * Kh * Kw, Kpad = cdiv(K, kConvBK) * kConvBK, Npad = cdiv(Cout, kConvNAlign) * kConvNAlign;
+    Conv2dLayout L;
+    L.packed = r.wino ? 0 : ((size_t)Npad * Kpad + 63) / 64 * 64;
+    L.splitk = r.wino ? 0 : (splitk_floats_for(p, 1, B, Npad) + 63) / 64 * 64;
+    L.wino = r.wino ? (size_t)(r.nsplit == -5 ? 40 : 16) * Cout * Cin + 64 : 0;
+    L.tickets = (!r.wino && p.fused && p.nsplit > 1) ? kConvTickets : 0;
+    L.total = L.packed + L.splitk + L.wino + L.tickets;
+    return L;
+}
+ConvPlan conv2d_plan_for(int B, int Ho, int Wo, int Cin, int Cout, int Kh, int Kw, int bm, int bn, const Conv2dRequest& r) {
+    const int Kpad = cdiv(Cin * Kh * Kw, kConvBK) * kConvBK;
+    ConvPlan p = plan_conv(Ho * Wo, B, Cout, Kpad / kConvBK, 1, r.wino ? 0 : bm, bn, r.wino ? 1 : r.nsplit);
+    p.bf3 = r.bf3 ? 1 : 0;
+    if (r.two_launch) p.fused = 0;
+    return p;
+}
+}  // namespace
+
+// Exact workspace of fpc_conv2d for ONE request (same bm / bn / nsplit): at most fpc_conv2d_workspace_bytes, usually far
+// less (that bound reserves 32 split-K slices of the whole output).  fpc_conv2d accepts either.
+extern "C" size_t fpc_conv2d_workspace_bytes_for(int B, int Ho, int Wo, int Cin, int Cout, int Kh, int Kw, int bm, int bn,
+                                                 int nsplit) {
+    if (B < 1 || Ho < 1 || Wo < 1 || Cin < 1 || Cout < 1 || Kh < 1 || Kw < 1) return 0;
+    const Conv2dRequest r = conv2d_request(nsplit);
+    const ConvPlan p = conv2d_plan_for(B, Ho, Wo, Cin, Cout, Kh, Kw, bm, bn, r);
+    return std::max<size_t>(conv2d_layout(B, Cin, Cout, Kh, Kw, p, r).total * sizeof(float), 256);
+}
+
 extern "C" int fpc_conv2d(const float* in, int64_t sb, int64_t sh, int64_t sw, int64_t sc, const float* w_oihw,
                           const float* scale, const float* shift, const float* res, const float* up, float* out,
                           float* gn_part, int B, int Hi, int Wi, int Cin, int Cout, int Kh, int Kw, int stride, int pad,
@@ -777,35 +819,33 @@ extern "C" int fpc_conv2d(const float* in, int64_t sb, int64_t sh, int64_t sw, i
     if (!in || !w_oihw || !out || !ws || B < 1 || Kh != Kw) return FPC_EINVAL;
     int Ho = conv_out(Hi, Kh, stride, pad), Wo = conv_out(Wi, Kw, stride, pad);
     if (Ho < 1 || Wo < 1) return FPC_EINVAL;
-    if (ws_bytes < fpc_conv2d_workspace_bytes(B, Ho, Wo, Cin, Cout, Kh, Kw) || ((uintptr_t)ws & 255)) return FPC_EWORKSPACE;
+    const Conv2dRequest rq = conv2d_request(nsplit);
+    nsplit = rq.nsplit;
+    const bool wino = rq.wino;
+    ConvPlan p = conv2d_plan_for(B, Ho, Wo, Cin, Cout, Kh, Kw, bm, bn, rq);
+    const Conv2dLayout lay = conv2d_layout(B, Cin, Cout, Kh, Kw, p, rq);
+    if (ws_bytes < lay.total * sizeof(float) || ((uintptr_t)ws & 255)) return FPC_EWORKSPACE;
     PackedConv c;
     c.Cin = c.Cinp = Cin; c.Cout = Cout; c.Kh = Kh; c.Kw = Kw; c.stride = stride; c.pad = pad;
     c.K = Cin * Kh * Kw; c.Kpad = cdiv(c.K, kConvBK) * kConvBK; c.Npad = cdiv(Cout, kConvNAlign) * kConvNAlign;
     hipStream_t s = (hipStream_t)stream;
     float* packed = (float*)ws;
-    FPC_TRY(launch_pack_weight(w_oihw, packed, Cout, Cin, Cin, Kh, Kw, Kw, c.Npad, c.Kpad, s));
-    int bf3 = 0;
-    if (nsplit >= 1000) { bf3 = 1; nsplit -= 1000; }      // test hook: 1000 + split = split-precision matrix products
-    bool two_launch = false;
-    if (nsplit >= 100) { two_launch = true; nsplit -= 100; }      // test hook: 100 + split = split-K summed by k_conv_splitk_epilogue
-    bool wino = nsplit <= -1 && nsplit >= -5;      // -1: 4 waves, -2: 8 waves, -3: 4 waves wave-private, -4: 8 waves all-DMA 3-stage, -5: 8 waves split precision
-    ConvPlan p = plan_conv(Ho * Wo, B, Cout, c.Kpad / kConvBK, 1, wino ? 0 : bm, bn, wino ? 1 : nsplit);
-    p.bf3 = bf3;
-    if (two_launch) p.fused = 0;
+    if (!wino) FPC_TRY(launch_pack_weight(w_oihw, packed, Cout, Cin, Cin, Kh, Kw, Kw, c.Npad, c.Kpad, s));
     int mode = (sc == 1 && Cin % kConvBK == 0 && Kh * Kw <= 32 && ((int64_t)Hi + 2 * pad) * sh * 4 < ((int64_t)1 << 31)) ? 0
                : (sc == 1 && Cin % 4 == 0 && sw % 4 == 0 && sh % 4 == 0 && sb % 4 == 0 && ((uintptr_t)in & 15) == 0) ? 2 : 1;
     fpc_net tmp;
     tmp.B = B;
     tmp.ws = packed;
-    tmp.splitk_off = ((size_t)c.Npad * c.Kpad + 63) / 64 * 64;
+    tmp.splitk_off = lay.packed;
     ConvArgs a;
     fill_conv_args(&tmp, a, c, p, Hi, Wi, Ho, Wo, sb, sh, sw, sc, relu != 0, mode);
     a.p[0] = ConvPtrs{in, packed, out, scale, shift, res, up, gn_part};
     a.zeros = nullptr;
-    {   // arrival counters of the fused split-K form: behind the Winograd region, zeroed per call
-        float* tk = packed + tmp.splitk_off + (size_t)32 * B * (cdiv(Ho * Wo, 128) * 128) * c.Npad + (size_t)40 * Cout * Cin + 64;
+    a.tickets = nullptr;
+    if (lay.tickets) {   // arrival counters of the fused split-K form, zeroed per call
+        float* tk = packed + lay.packed + lay.splitk + lay.wino;
         a.tickets = (int*)tk;
-        if (p.fused && hipMemsetAsync(tk, 0, kConvTickets * sizeof(int), s) != hipSuccess) return FPC_ELAUNCH;
+        if (hipMemsetAsync(tk, 0, kConvTickets * sizeof(int), s) != hipSuccess) return FPC_ELAUNCH;
     }
     if (wino && relu == 77) { a.dbg = gn_part; a.p[0].gn_part = nullptr; a.relu = 0; }
 #ifdef FPC_STAMP_IGEMM
@@ -815,11 +855,11 @@ extern "C" int fpc_conv2d(const float* in, int64_t sb, int64_t sh, int64_t sw, i
         if (Kh != 3 || stride != 1 || pad != 1 || Cin % 8 || Cout % 64 || sc != 1 || up || sw != Cin ||
             sh != (int64_t)Wi * Cin || sb != (int64_t)Hi * Wi * Cin)
             return FPC_EINVAL;
-        float* wp = packed + tmp.splitk_off + (size_t)32 * B * (cdiv(Ho * Wo, 128) * 128) * c.Npad;
+        float* wp = packed + lay.packed + lay.splitk;
         FPC_TRY(launch_wino_pack(w_oihw, wp, Cout, Cin, s));
         if (nsplit == -5) FPC_TRY(launch_wino_pack_bf3(w_oihw, wp + (size_t)16 * Cout * Cin, Cout, Cin, s));
         a.wino_w[0] = wp;
-        float* zp = wp + (size_t)40 * Cout * Cin;
+        float* zp = wp + lay.wino - 64;
         if (hipMemsetAsync(zp, 0, 64 * sizeof(float), s) != hipSuccess) return FPC_ELAUNCH;
         a.zeros = zp;
         p.wino = -nsplit;

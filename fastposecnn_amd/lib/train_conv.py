@@ -37,7 +37,7 @@ def _run(x, w, bias, stride, pad, code, out):
     Ho, Wo = out.shape[2], out.shape[3]
     L = nat.lib()
     sb, sc, sh, sw = x.stride()
-    ws = nat.workspace("train_conv", x.device, L.fpc_conv2d_workspace_bytes(B, Ho, Wo, Cin, Cout, Kh, Kw))
+    ws = nat.workspace("train_conv", x.device, L.fpc_conv2d_workspace_bytes_for(B, Ho, Wo, Cin, Cout, Kh, Kw, 0, 0, code))
     nat.check(L.fpc_conv2d(x.data_ptr(), sb, sh, sw, sc, w.data_ptr(), None, nat.ptr(bias), None, None, out.data_ptr(), None,
                            B, H, W, Cin, Cout, Kh, Kw, stride, pad, 0, 0, 0, code, ws.data_ptr(), ws.numel(), nat.stream()),
               "fpc_conv2d (training)")

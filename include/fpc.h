@@ -333,6 +333,9 @@ int fpc_net_tensor(const fpc_net_t* net, const char* name, const float** ptr, in
  * optional per-channel scale / shift, residual (as out), nearest-x2 `up` [B,Ho/2,Wo/2,Cout], ReLU,
  * GroupNorm partials gn_part [B][P32][Cout][2]; bm/bn/nsplit = 0 -> chosen by the planner. */
 size_t fpc_conv2d_workspace_bytes(int B, int Ho, int Wo, int Cin, int Cout, int Kh, int Kw);
+/* the exact need of one request (same bm / bn / nsplit as the fpc_conv2d call): <= the bound above, which reserves 32
+ * split-K slices of the whole output; fpc_conv2d accepts either size */
+size_t fpc_conv2d_workspace_bytes_for(int B, int Ho, int Wo, int Cin, int Cout, int Kh, int Kw, int bm, int bn, int nsplit);
 int fpc_conv2d_plan(int B, int Ho, int Wo, int Cin, int Cout, int Kh, int Kw, int bm, int bn, int nsplit,
                     int* out4 /* bm, bn, nsplit, P32 */);
 int fpc_conv2d(const float* in, int64_t sb, int64_t sh, int64_t sw, int64_t sc, const float* w_oihw,
