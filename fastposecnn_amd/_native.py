@@ -79,7 +79,8 @@ _SIGNATURES = {
                         _i, _i, _i, _i, _i, _vp, _sz, _vp]),
     "fpc_conv2d_wgrad_workspace_bytes": (_sz, [_i, _i, _i, _i, _i, _i, _i]),
     "fpc_upsample_bilinear_fwd": (_i, [_vp, _i64, _i64, _i64, _i64, _vp, _i, _i, _i, _i, _i, _i, _vp]),
-    "fpc_upsample_bilinear_bwd": (_i, [_vp, _i64, _i64, _i64, _i64, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    "fpc_upsample_bilinear_bwd_scratch_floats": (_sz, [_i, _i, _i, _i, _i]),
+    "fpc_upsample_bilinear_bwd": (_i, [_vp, _i64, _i64, _i64, _i64, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "fpc_groupnorm4_relu_scratch_floats": (_sz, [_i, _i, _i]),
     "fpc_groupnorm4_relu_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, ctypes.c_float, _vp]),
     "fpc_groupnorm4_relu_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),

@@ -155,8 +155,9 @@ class _UpBilinearFn(torch.autograd.Function):
         gx = torch.empty((B, C, h, w), dtype=torch.float32, device=g.device, memory_format=fmt)
         sb, sc, sh, sw = g.stride()
         L = nat.lib()
-        nat.check(L.fpc_upsample_bilinear_bwd(g.data_ptr(), sb, sc, sh, sw, gx.data_ptr(), B, C, h, w, ctx.scale, int(ctx.in_nhwc), nat.stream()),
-                  "fpc_upsample_bilinear_bwd")
+        ws = nat.workspace("train_up_bwd", g.device, 4 * L.fpc_upsample_bilinear_bwd_scratch_floats(B, C, h, w, ctx.scale))
+        nat.check(L.fpc_upsample_bilinear_bwd(g.data_ptr(), sb, sc, sh, sw, gx.data_ptr(), ws.data_ptr(), B, C, h, w, ctx.scale,
+                                              int(ctx.in_nhwc), nat.stream()), "fpc_upsample_bilinear_bwd")
         return gx, None, None
 
 

@@ -358,11 +358,13 @@ int fpc_conv2d_wgrad(const float* x, int64_t sb, int64_t sh, int64_t sw, const f
 /* Bilinear upsampling with align_corners = True (the x2 steps of the FPN segmentation blocks and the x4 of the heads:
  * torch.nn.functional.interpolate / nn.UpsamplingBilinear2d in the reference's network, F/lib/pose_regressor.py:608-666),
  * forward and its exact adjoint, ATen's source-index arithmetic.  scale: 2 or 4.  The tensor that is READ is given by its
- * element strides (any layout); the one WRITTEN is contiguous [B,C,.,.], channel-last when *_nhwc != 0.  Deterministic. */
+ * element strides (any layout); the one WRITTEN is contiguous [B,C,.,.], channel-last when *_nhwc != 0.  The backward runs
+ * one axis at a time through `scratch` (fpc_upsample_bilinear_bwd_scratch_floats floats).  Deterministic. */
 int fpc_upsample_bilinear_fwd(const float* in, int64_t sb, int64_t sc, int64_t sh, int64_t sw, float* out, int B, int C, int h,
                               int w, int scale, int out_nhwc, fpc_stream_t stream);
-int fpc_upsample_bilinear_bwd(const float* dout, int64_t sb, int64_t sc, int64_t sh, int64_t sw, float* din, int B, int C, int h,
-                              int w, int scale, int din_nhwc, fpc_stream_t stream);
+size_t fpc_upsample_bilinear_bwd_scratch_floats(int B, int C, int h, int w, int scale);
+int fpc_upsample_bilinear_bwd(const float* dout, int64_t sb, int64_t sc, int64_t sh, int64_t sw, float* din, float* scratch,
+                              int B, int C, int h, int w, int scale, int din_nhwc, fpc_stream_t stream);
 
 /* GroupNorm + ReLU on channel-last activations for the training step (the decoder blocks' GroupNorm(32, 128) -> ReLU,
  * segmentation_models_pytorch Conv3x3GNReLU, call sites F/lib/pose_regressor.py:608-666): x, y, dy, dx are [B, HW, C]
