@@ -10,7 +10,7 @@ a rank.  RCCL ("nccl") carries the one collective of the path: the all-gather of
 
 Workload of the headline line (BASELINE.json configs[1]): ResNet18-FPN + all four heads, batch = 1 frame of 640x480
 per GPU per step, HV_NUM_OF_HYPOTHESES = 1000 (config.INFERENCE), random-init weights (torch.manual_seed(0)),
-synthetic data, f32 throughout.  One step is one pass of the hot path over one frame:
+synthetic data, f32 operands / accumulation / results (product forms: config.matrix_products).  One step is one pass of the hot path over one frame:
 
     image -> native engine (fpc_net_forward): encoder -> 4 FPN decoders -> 4 heads -> x4 upsample
              -> class compression                                           (on the synthetic image)
@@ -26,17 +26,22 @@ four submissions later); `config.ms_per_frame_one_in_flight` is the latency with
 every rank runs its own frames; `value` = N * B * K / max-over-ranks(time).
 
 Extra objects on the JSON line:
-  roofline          the hough-vote launch sequence (fpc_ransac_voting_v3) at the headline config: algorithmic bytes
-                    n_instances * 12*H*W per call / HIP-event time of the call on its stream, against the 8 TB/s HBM peak of
-                    MI355X_MICROARCH.md; `traffic` = PMC-measured HBM bytes per launch (profiles/r02_vote_traffic.json);
-                    `valu` = the bound that actually binds at hn = 1000: vector wave-instructions per second of the
-                    sequence (PMC SQ_INSTS_VALU of the same profile / the live time) against 1024 SIMDs x 2.4 GHz / 2
+  roofline          the hough-vote launch sequence at the headline config, as the model's pipeline calls it (the aggregation
+                    layer's mask bit words: fpc_ransac_voting_v3_bits): algorithmic bytes n_instances * 12*H*W per call /
+                    HIP-event time of 10 back-to-back calls on cold inputs, against the 8 TB/s HBM peak of MI355X_MICROARCH.md;
+                    `traffic` and `valu` are PMC counters of a separately profiled run (`from_profile` names file and commit:
+                    profiles/r03_vote_bits_traffic_*.json)
   roofline_hn128    the same sequence at the training value hn = 128 (F/config.py:93) on a 32-frame batch (192 instances)
-  backbone          the network part: executed f32 multiply-add FLOP of the engine's plans (Winograd sites count 1/2.25)
-                    and the direct-convolution equivalent / HIP-event time, against the 157.3 TFLOP/s f32 matrix peak
+  post_network      connected components and aggregation at B = 1 and B = 32: time, algorithmic bytes, fraction of 8 TB/s
+  backbone          the network part: executed f32-equivalent multiply-add FLOP of the engine's plans (Winograd sites count
+                    1/2.25) / device time per network, against the 157.3 TFLOP/s f32 matrix peak (and, second figure,
+                    against the bf16 x 3 equivalent peak: config.matrix_products says which product form the plans use)
   configs.config3   BASELINE.json configs[2]: ResNet34, batch 32 per step, same pipeline (shorter timed region)
-  cpu_baseline      the same step on the host: torch-CPU backbone + the C oracle's post-network path (1 thread and all
-                    cores), three samples each
+  train             BASELINE.json configs[4] at batch 8 on this GPU (fastposecnn_amd/train_bench.py; 1-GPU runs)
+  cpu_baseline      the same step on the host: torch-CPU backbone + the C oracle's post-network path (1 thread and the
+                    job's CPU share), three samples each
+`value` is the MEDIAN of the repeated K-step timed regions (`repeats`, `ms_per_step_min_max`); `scaling_measured` is false:
+no N > 1 run has been measured by this repository.
 """
 import argparse
 import json
