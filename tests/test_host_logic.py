@@ -353,3 +353,37 @@ def test_bench_launches_its_own_ranks():
     out = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "4"], env=env1, capture_output=True,
                          text=True, timeout=300)
     assert out.returncode != 0
+
+
+def test_training_conv_helpers_fall_back_to_torch_on_cpu():
+    """lib/train_conv.py on CPU tensors: plain torch results and gradients (the native kernels are GPU-only and are never
+    substituted silently: the GPU tests assert that they ran)."""
+    import torch
+    import fastposecnn_amd.lib  # noqa: F401
+    from fastposecnn_amd.lib import train_conv, backbone
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn((2, 32, 9, 11), generator=g, requires_grad=True)
+    conv = backbone.Conv2d(32, 8, 3, 1, 1).train()
+    y = conv(x)
+    assert torch.equal(y, torch.nn.functional.conv2d(x, conv.weight, conv.bias, 1, 1))
+    before = dict(train_conv.counters)
+    y.sum().backward()
+    assert train_conv.counters == before and x.grad is not None
+    up = train_conv.upsample_bilinear(x.detach(), 2)
+    assert torch.equal(up, torch.nn.functional.interpolate(x.detach(), scale_factor=2, mode="bilinear", align_corners=True))
+    gn = torch.nn.GroupNorm(8, 32)
+    assert torch.equal(train_conv.groupnorm_relu(x.detach(), gn), torch.relu(gn(x.detach())))
+
+
+def test_mask_bits_ride_on_the_very_tensor_only():
+    import torch
+    import fastposecnn_amd.lib  # noqa: F401
+    import aggregation_layer as al
+    m = torch.zeros((3, 4, 5))
+    assert al.mask_bits_of(m) is None
+    bits = torch.zeros((3, 64), dtype=torch.int64)
+    m._fpc_mask_bits = (bits, m._version)
+    assert al.mask_bits_of(m) is bits
+    assert al.mask_bits_of(m[:2]) is None and al.mask_bits_of(m.clone()) is None
+    m.add_(1.0)
+    assert al.mask_bits_of(m) is None            # written since: the words may be stale
