@@ -1724,7 +1724,7 @@ __global__ __launch_bounds__(64 * NW, BF3 ? 1 : 2) void k_conv_wino(const WinoAr
     }
     if (dbg && lane == 0) {
         long long* o = a.dbg + ((size_t)blockIdx.x * NW + wv) * 8;
-        for (int i = 0; i < 3; ++i) o[i] = stamp[i];
+        o[0] = stamp[0]; o[1] = stamp[3] + stamp[4]; o[2] = stamp[2];      // issue of the staging loads | wait + barrier | MFMA block
         o[3] = clock64() - c_begin;            // shader-clock ticks of the whole K loop
         o[6] = c_begin - t_entry;              // kernel entry -> K loop
         o[4] = wall_clock64() - r_begin;       // 100 MHz reference ticks of the same span
@@ -1891,7 +1891,8 @@ int launch_conv_wino(const WinoArgs& a, int groups, hipStream_t s) {
     if (a.variant != 1 && !a.zeros) return FPC_EINVAL;
     if ((long long)a.H * a.W * a.Cin * (long long)sizeof(float) >= (1LL << 32)) return FPC_EINVAL;   // 32-bit lane offsets inside one image
     if (a.waves == 8 && a.variant == 3) {
-        hipLaunchKernelGGL((k_conv_wino<8, false, false, false, true>), grid, dim3(512), 0, s, a);
+        if (a.dbg) hipLaunchKernelGGL((k_conv_wino<8, false, false, true, true>), grid, dim3(512), 0, s, a);
+        else hipLaunchKernelGGL((k_conv_wino<8, false, false, false, true>), grid, dim3(512), 0, s, a);
     } else if (a.waves == 8 && a.variant == 2) {
         if (a.dbg) hipLaunchKernelGGL((k_conv_wino<8, false, true, true>), grid, dim3(512), 0, s, a);
         else hipLaunchKernelGGL((k_conv_wino<8, false, true>), grid, dim3(512), 0, s, a);

@@ -5,12 +5,12 @@ import torch
 from fastposecnn_amd import _native as nat
 dev = torch.device("cuda:0"); L = nat.lib()
 VAR = int(sys.argv[1]) if len(sys.argv) > 1 else -1      # -1: 4-wave barrier form, -4: 8-wave all-DMA form
-NWAVE = 8 if VAR in (-4, -2) else 4
+NWAVE = 8 if VAR in (-4, -2, -5) else 4
 B, Cin, Hi, Wi, Cout, k = 4, 256, 120, 160, 128, 3
 x = torch.randn((B, Hi, Wi, Cin), device=dev); w = torch.randn((Cout, Cin, k, k), device=dev) * 0.05
 out = torch.empty((B, Hi, Wi, Cout), device=dev)
 ws = torch.empty(L.fpc_conv2d_workspace_bytes(B, Hi, Wi, Cin, Cout, k, k), dtype=torch.uint8, device=dev)
-nblk = (10 * 8 if VAR in (-4, -2) else 10 * 15) * B * 2
+nblk = (10 * 8 if VAR in (-4, -2, -5) else 10 * 15) * B * 2
 dbg = torch.zeros((nblk, NWAVE, 8), dtype=torch.int64, device=dev)
 sb, sh, sw, sc = x.stride(); st = torch.cuda.current_stream().cuda_stream
 for _ in range(200):
@@ -22,7 +22,7 @@ clk = (d[:, :, 3] / d[:, :, 4] * 100.0)
 print("in-kernel clock (s_memtime / s_memrealtime * 100 MHz): mean %.0f MHz, min %.0f, max %.0f" % (clk.mean(), clk.min(), clk.max()))
 print("K loop: %.0f shader ticks = %.1f us per workgroup" % (d[:, :, 3].mean(), (d[:, :, 4].mean() / 100.0)))
 per = d[:, :, :3] / d[:, :, 5:6]
-names = ["issue loads", "frag+transform", "MFMA issue"] if VAR != -4 else ["first half (16 MFMA)", "vmcnt + barrier", "issue + second half"]
+names = ["issue loads", "wait + barrier", "MFMA block"] if VAR != -4 else ["first half (16 MFMA)", "vmcnt + barrier", "issue + second half"]
 print("cycles per K-step (s_memtime ticks), mean over waves / median / p90:")
 for i, n in enumerate(names):
     v = per[:, :, i].flatten()
