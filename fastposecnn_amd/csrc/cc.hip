@@ -4,10 +4,9 @@
 //
 // 4-connectivity inside an image, none across images (the 3x3x3 structuring element
 // of :43-59).  Lock-free union-find on global linear pixel indices:
-//   k_cc_init     row runs: every pixel points at the start of its run inside the
-//                 64-pixel wave segment (ballot + clz), run starts chain to the
-//                 previous segment
-//   k_cc_merge    vertical unions, only where a run start / run break makes one necessary
+//   k_cc_tile     64 x 16 pixel tiles: row runs (ballot + clz) and the tile's vertical unions in LDS; every pixel
+//                 points at the global index of its tile-local root
+//   k_cc_border   unions across tile borders, only where a run start / run break makes one necessary
 //   k_cc_flatten  root of every pixel; root census per 1024-pixel block
 //   k_cc_scan     exclusive scan of the block census (one block) -> N
 //   k_cc_rank     roots in raster order get labels 1..N (scipy's numbering, continuing
@@ -17,8 +16,8 @@
 // order, so ranking the roots by index reproduces scipy.ndimage.label's order exactly.
 // (Round 3 tried flatten + scan + rank as ONE launch — blocks in ticket order, decoupled look-back over 64 predecessors per
 // step: 43.4 us against 45.6 us for the six launches at B = 1, 225 us against 181 us at B = 32, where one ticket word
-// serves ~88 draws / us and batching the draws serialises the tree walks.  The walks themselves (run starts climbing a
-// union-find tree as deep as the blob is tall, one dependent load per level) are the 15-22 us that dominate; not kept.)
+// serves ~88 draws / us and batching the draws serialises the tree walks; not kept.  What was kept is the tile-local first
+// stage below: 60 -> 35 us at 640 x 480, 178 -> 119 us for 32 frames.)
 #include "common.hpp"
 
 namespace fpc {
@@ -60,53 +59,105 @@ __device__ __forceinline__ void cc_unite(int32_t* L, int a, int b) {
     }
 }
 
-__global__ __launch_bounds__(256) void k_cc_init(const int64_t* __restrict__ cm, int W, int HW, long long total,
-                                                 int32_t* __restrict__ L) {
-    long long g0 = (long long)blockIdx.x * kCcBlock;
-    int lane = threadIdx.x & (kWave - 1);
-    const unsigned p0 = (unsigned)(g0 % HW);               // uniform: the 64-bit division runs once, on the scalar unit
-#pragma unroll
-    for (int it = 0; it < 4; ++it) {
-        long long g = g0 + it * 256 + threadIdx.x;
-        bool in = g < total;
-        unsigned pp = p0 + it * 256 + threadIdx.x;
-        if (pp >= (unsigned)HW) pp %= (unsigned)HW;        // the block crosses into the next image (rare lanes)
-        int p = in ? (int)pp : 0;
-        int x = (int)((unsigned)p % (unsigned)W);
-        bool fg = in && cm[g] != 0;
-        unsigned long long m = __ballot(fg);
-        bool left_in_wave = lane > 0 && ((m >> (lane - 1)) & 1ull);
-        bool is_start = fg && (lane == 0 || x == 0 || !left_in_wave);
-        unsigned long long s = __ballot(is_start);
-        if (!in) continue;
-        int parent = -1;
-        if (fg) {
-            unsigned long long below = s & ((2ull << lane) - 1ull);
-            int start_lane = 63 - __clzll(below);
-            parent = (int)(g - lane + start_lane);
-            // a run that begins at lane 0 may continue the previous wave segment's run
-            if (start_lane == lane && lane == 0 && x > 0 && cm[g - 1] != 0) parent = (int)(g - 1);
-        }
-        L[g] = parent;
+// ---- tile-local labelling ----------------------------------------------------------------
+// One workgroup = a 64 x 16 pixel tile (a wave per row, four rows each).  Row runs by ballot + clz, the vertical unions of
+// the tile in LDS (the same lock-free union-find, trees at most 16 deep, ~100-cycle links), then every pixel's parent is
+// written as the GLOBAL linear index of its tile-local root: the first pixel of its tile component in raster order, which is
+// also the smallest global index of that component.  What is left for global memory are the unions ACROSS tile borders
+// (k_cc_border): trees as deep as a blob spans tiles, not as it is tall in rows.  (Round 3: the row-run init + all-rows
+// merge walked chains of up to 150 dependent global loads per run start: 25 + 14 us at 640 x 480.)
+constexpr int kTileW = 64, kTileH = 16;
+
+__device__ __forceinline__ int lds_find_halve(int* l, int a) {
+    while (true) {
+        int pa = l[a];
+        if (pa == a) return a;
+        int gpa = l[pa];
+        if (gpa == pa) return pa;
+        atomicMin(&l[a], gpa);
+        a = gpa;
+    }
+}
+__device__ __forceinline__ void lds_unite(int* l, int a, int b) {
+    while (true) {
+        a = lds_find_halve(l, a);
+        b = lds_find_halve(l, b);
+        if (a == b) return;
+        if (a < b) { int t = a; a = b; b = t; }
+        int old = atomicMin(&l[a], b);
+        if (old == a) return;
+        a = old;
     }
 }
 
-__global__ __launch_bounds__(256) void k_cc_merge(int W, int HW, long long total, int32_t* __restrict__ L) {
-    long long g0 = (long long)blockIdx.x * kCcBlock;
-    const unsigned p0 = (unsigned)(g0 % HW);               // uniform
+// grid (ceil(W / 64), ceil(H / 16), B)
+__global__ __launch_bounds__(256) void k_cc_tile(const int64_t* __restrict__ cm, int H, int W, int32_t* __restrict__ L) {
+    __shared__ int l[kTileH * kTileW];          // parent as a tile-local index (row * 64 + column), -1 = background
+    const int lane = threadIdx.x & (kWave - 1), w = threadIdx.x / kWave;
+    const int x0 = blockIdx.x * kTileW, y0 = blockIdx.y * kTileH;
+    const int x = x0 + lane;
+    const size_t img = (size_t)blockIdx.z * H * W;
+    bool fg[4];
 #pragma unroll
-    for (int it = 0; it < 4; ++it) {
-        long long g = g0 + it * 256 + threadIdx.x;
-        if (g >= total) continue;
-        unsigned pp = p0 + it * 256 + threadIdx.x;
-        if (pp >= (unsigned)HW) pp %= (unsigned)HW;
-        int p = (int)pp;
-        if (p < W) continue;  // first row of its image
-        if (L[g] < 0 || L[g - W] < 0) continue;
-        int x = (int)((unsigned)p % (unsigned)W);
-        // (p, p-W) is implied by (p-1, p-1-W) when both left neighbours are foreground
-        if (x > 0 && L[g - 1] >= 0 && L[g - 1 - W] >= 0) continue;
+    for (int r = 0; r < 4; ++r) {
+        const int ly = w + 4 * r, y = y0 + ly;
+        const bool in = x < W && y < H;
+        fg[r] = in && cm[img + (size_t)y * W + x] != 0;
+        const unsigned long long m = __ballot(fg[r]);
+        const bool left = lane > 0 && ((m >> (lane - 1)) & 1ull);
+        const unsigned long long s = __ballot(fg[r] && !left);
+        int parent = -1;
+        if (fg[r]) parent = ly * kTileW + 63 - __clzll(s & ((2ull << lane) - 1ull));
+        l[ly * kTileW + lane] = parent;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int ly = w + 4 * r;
+        if (ly == 0 || !fg[r] || l[(ly - 1) * kTileW + lane] < 0) continue;
+        // (p, p - row) is implied by the pair to the left when both left neighbours are foreground
+        if (lane > 0 && l[ly * kTileW + lane - 1] >= 0 && l[(ly - 1) * kTileW + lane - 1] >= 0) continue;
+        lds_unite(l, ly * kTileW + lane, (ly - 1) * kTileW + lane);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int ly = w + 4 * r, y = y0 + ly;
+        if (x >= W || y >= H) continue;
+        int parent = -1;
+        if (fg[r]) {
+            const int root = lds_find_halve(l, ly * kTileW + lane);
+            parent = (int)(img + (size_t)(y0 + (root >> 6)) * W + x0 + (root & 63));
+        }
+        L[img + (size_t)y * W + x] = parent;
+    }
+}
+
+// Unions across tile borders: one thread per pixel of a tile's first row (against the pixel above) or first column (against
+// the pixel to its left).  A pair is skipped when the neighbouring pair one step before it along the border is foreground
+// too (all four pixels are then connected through unions that somebody performs).
+__global__ __launch_bounds__(256) void k_cc_border(int B, int H, int W, int32_t* __restrict__ L) {
+    const int nyb = (H - 1) / kTileH, nxb = (W - 1) / kTileW;      // border rows / columns per image
+    const int per_img = nyb * W + nxb * H;
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (t >= (long long)B * per_img) return;
+    const int b = (int)(t / per_img), k = (int)(t - (long long)b * per_img);
+    const size_t img = (size_t)b * H * W;
+    if (k < nyb * W) {                       // horizontal border: pixel (x, y) with y a multiple of 16, against (x, y - 1)
+        const int y = (k / W + 1) * kTileH, x = k - (k / W) * W;
+        const size_t g = img + (size_t)y * W + x;
+        if (L[g] < 0 || L[g - W] < 0) return;
+        if (x > 0 && L[g - 1] >= 0 && L[g - 1 - W] >= 0) return;
         cc_unite(L, (int)g, (int)(g - W));
+    } else {                                 // vertical border: pixel (x, y) with x a multiple of 64, against (x - 1, y)
+        const int k2 = k - nyb * W;
+        const int x = (k2 / H + 1) * kTileW, y = k2 - (k2 / H) * H;
+        const size_t g = img + (size_t)y * W + x;
+        if (L[g] < 0 || L[g - 1] < 0) return;
+        // implied by the pair one row up only when both vertical links are tile-LOCAL (not on a tile's first row: there the
+        // link (x, y) ~ (x, y - 1) is a horizontal-border pair whose own skip rule may lean on this very union)
+        if (y % kTileH != 0 && L[g - W] >= 0 && L[g - 1 - W] >= 0) return;
+        cc_unite(L, (int)g, (int)(g - 1));
     }
 }
 
@@ -129,7 +180,10 @@ __global__ __launch_bounds__(256) void k_cc_flatten(long long total, int32_t* __
         long long seg0 = g - lane;
         bool inseg = fg && p >= seg0 && p < g;
         int r = -1;
-        if (fg && !inseg) r = cc_find_halve(L, (int)g);
+        // a tile root (its own parent after k_cc_tile, unless a border union re-pointed it) walks with path halving; every
+        // other pixel starts at its tile root and only reads: the few writers shorten the chains the many readers follow,
+        // and the readers' loads of a shared chain hit in cache (all pixels halving at once: 24 us instead of 9 at 640 x 480)
+        if (fg && !inseg) r = (p == (int)g || L[p] == p) ? (p == (int)g ? cc_find_halve(L, (int)g) : p) : cc_find(L, p);
         for (int k = 0; k < 8; ++k) {      // in-segment chains are one link deep unless runs of one row were united
             int pr = __shfl(r, inseg ? (int)(p - seg0) : lane, kWave);
             if (inseg && r < 0 && pr >= 0) r = pr;
@@ -257,10 +311,12 @@ extern "C" int fpc_cc_label(const int64_t* cat_mask, int B, int H, int W, int32_
     if (((uintptr_t)ws & 255) != 0) return FPC_EWORKSPACE;
     CcWs w = cc_carve(ws, B, H, W);
     if (ws_bytes < w.total) return FPC_EWORKSPACE;
-    int HW = H * W;
     int nb = (int)((total + kCcBlock - 1) / kCcBlock);
-    hipLaunchKernelGGL(k_cc_init, dim3(nb), dim3(256), 0, s, cat_mask, W, HW, total, w.L);
-    hipLaunchKernelGGL(k_cc_merge, dim3(nb), dim3(256), 0, s, W, HW, total, w.L);
+    if (B > 65535 || cdiv(H, kTileH) > 65535) return FPC_EINVAL;
+    hipLaunchKernelGGL(k_cc_tile, dim3(cdiv(W, kTileW), cdiv(H, kTileH), B), dim3(256), 0, s, cat_mask, H, W, w.L);
+    const long long nborder = (long long)B * (((H - 1) / kTileH) * (long long)W + ((W - 1) / kTileW) * (long long)H);
+    if (nborder > 0)
+        hipLaunchKernelGGL(k_cc_border, dim3((unsigned)((nborder + 255) / 256)), dim3(256), 0, s, B, H, W, w.L);
     hipLaunchKernelGGL(k_cc_flatten, dim3(nb), dim3(256), 0, s, total, w.L, w.R, w.blk_cnt);
     hipLaunchKernelGGL(k_cc_scan, dim3(1), dim3(1024), 0, s, nb, w.blk_cnt, w.blk_off, n_out);
     // rank is written only at root positions; L is dead after k_cc_flatten and is reused for it
