@@ -8,7 +8,8 @@
 //                 points at the global index of its tile-local root
 //   k_cc_border   unions across tile borders, only where a run start / run break makes one necessary
 //   k_cc_flatten  root of every pixel; root census per 1024-pixel block
-//   k_cc_scan     exclusive scan of the block census (one block) -> N
+//   k_cc_scan     exclusive scan of the block census (one block) -> N  (only beyond 1024 blocks: k_cc_rank sums a short
+//                 census itself)
 //   k_cc_rank     roots in raster order get labels 1..N (scipy's numbering, continuing
 //                 across the batch)
 //   k_cc_relabel  labels[p] = rank of root(p)
@@ -225,10 +226,14 @@ __global__ __launch_bounds__(1024) void k_cc_scan(int nb, const int32_t* __restr
 
 // Thread t of a block owns pixels g0 + it*256 + t; raster order inside the block is
 // (it, t), so the block-local exclusive scan runs over it-major order.
+// blk_off == nullptr (few blocks: one or a few frames): every block sums the census of the blocks before it itself and the
+// last block writes the component count — the scan launch (4.4 us of pure latency at 640 x 480) is not needed.
 __global__ __launch_bounds__(256) void k_cc_rank(long long total, const int32_t* __restrict__ R,
-                                                 const int32_t* __restrict__ blk_off, int32_t* __restrict__ rank,
+                                                 const int32_t* __restrict__ blk_off, const int32_t* __restrict__ blk_cnt,
+                                                 int32_t* __restrict__ n_out, int32_t* __restrict__ rank,
                                                  int32_t* __restrict__ root_pix, int cap) {
     __shared__ int s_wave[4][4];
+    __shared__ int s_red[4];
     long long g0 = (long long)blockIdx.x * kCcBlock;
     int lane = threadIdx.x & (kWave - 1), w = threadIdx.x / kWave;
     bool isr[4];
@@ -242,7 +247,19 @@ __global__ __launch_bounds__(256) void k_cc_rank(long long total, const int32_t*
         if (lane == 0) s_wave[it][w] = __popcll(m);
     }
     __syncthreads();
-    int base = blk_off[blockIdx.x];
+    int base;
+    if (blk_off) {
+        base = blk_off[blockIdx.x];
+    } else {
+        int part = 0;
+        for (int i = threadIdx.x; i < (int)blockIdx.x; i += 256) part += blk_cnt[i];
+        base = block_sum_bcast(part, s_red);
+        if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) {
+            int mine = 0;
+            for (int j = 0; j < 16; ++j) mine += s_wave[j / 4][j % 4];
+            *n_out = base + mine;
+        }
+    }
 #pragma unroll
     for (int it = 0; it < 4; ++it) {
         int off = base;
@@ -318,9 +335,11 @@ extern "C" int fpc_cc_label(const int64_t* cat_mask, int B, int H, int W, int32_
     if (nborder > 0)
         hipLaunchKernelGGL(k_cc_border, dim3((unsigned)((nborder + 255) / 256)), dim3(256), 0, s, B, H, W, w.L);
     hipLaunchKernelGGL(k_cc_flatten, dim3(nb), dim3(256), 0, s, total, w.L, w.R, w.blk_cnt);
-    hipLaunchKernelGGL(k_cc_scan, dim3(1), dim3(1024), 0, s, nb, w.blk_cnt, w.blk_off, n_out);
+    const bool fold_scan = nb <= 1024;          // each block then reads <= 4 KB of census itself
+    if (!fold_scan) hipLaunchKernelGGL(k_cc_scan, dim3(1), dim3(1024), 0, s, nb, w.blk_cnt, w.blk_off, n_out);
     // rank is written only at root positions; L is dead after k_cc_flatten and is reused for it
-    hipLaunchKernelGGL(k_cc_rank, dim3(nb), dim3(256), 0, s, total, w.R, w.blk_off, w.L, root_pix, cap);
+    hipLaunchKernelGGL(k_cc_rank, dim3(nb), dim3(256), 0, s, total, w.R, fold_scan ? nullptr : w.blk_off, w.blk_cnt, n_out, w.L,
+                       root_pix, cap);
     hipLaunchKernelGGL(k_cc_relabel, dim3(nb), dim3(256), 0, s, total, w.R, w.L, labels);
     return check_launch();
 }
