@@ -14,6 +14,7 @@ struct AggWs {
     double* sums;        // [N, 8]   zero-filled per call
     int32_t* cnt;        // [N]      zero-filled
     uint32_t* cls_min;   // [N]      zero-filled; holds 0xFFFFFFFF - (smallest class id seen)
+    int32_t* ticket;     // [1]      zero-filled; arrival counter of the fused launch
     int32_t* sample;     // [N]
     size_t zero_bytes, total;
 };
@@ -25,6 +26,7 @@ static AggWs agg_carve(void* base, int N) {
     w.sums = (double*)(p + off); off = align_up(off + sizeof(double) * 8 * (size_t)N, 256);
     w.cnt = (int32_t*)(p + off); off = align_up(off + sizeof(int32_t) * (size_t)N, 256);
     w.cls_min = (uint32_t*)(p + off); off = align_up(off + sizeof(uint32_t) * (size_t)N, 256);
+    w.ticket = (int32_t*)(p + off); off = align_up(off + sizeof(int32_t), 256);
     w.zero_bytes = off;
     w.sample = (int32_t*)(p + off); off = align_up(off + sizeof(int32_t) * (size_t)N, 256);
     w.total = off;
@@ -77,24 +79,21 @@ __device__ __forceinline__ void agg_flush_lds(AggLds& s, int i, const double* v,
 // fall back to per-lane atomics for the minority label.   grid (ceil(W/64), ceil(H/(4*kAggRows)), B)
 // The strip's eight label rows are requested together, then the nine planes of four rows at a time under
 // their labels: three dependent memory round trips per wave instead of sixteen (one per row and stage).
-__global__ __launch_bounds__(256) void k_agg_accum(const int32_t* __restrict__ labels,
-                                                   const int64_t* __restrict__ cm, const float* __restrict__ quat,
-                                                   const float* __restrict__ scales, const float* __restrict__ z,
-                                                   int H, int W, int N, const int32_t* __restrict__ n_dev,
-                                                   double* __restrict__ sums, int32_t* __restrict__ cnt,
-                                                   uint32_t* __restrict__ cls_min, int32_t* __restrict__ sample) {
-    if (n_dev) N = min(N, *n_dev);
-    __shared__ AggLds s;
+__device__ __forceinline__ void agg_accum_block(AggLds& s, int bx, int by, int bz, const int32_t* __restrict__ labels,
+                                                const int64_t* __restrict__ cm, const float* __restrict__ quat,
+                                                const float* __restrict__ scales, const float* __restrict__ z,
+                                                int H, int W, int N, double* __restrict__ sums, int32_t* __restrict__ cnt,
+                                                uint32_t* __restrict__ cls_min, int32_t* __restrict__ sample) {
     if (threadIdx.x < kAggSlots) {
         s.lab[threadIdx.x] = 0; s.cnt[threadIdx.x] = 0; s.cls[threadIdx.x] = 0xFFFFFFFFu;
 #pragma unroll
         for (int a = 0; a < 8; ++a) s.sum[threadIdx.x][a] = 0.0;
     }
     __syncthreads();
-    const int b = blockIdx.z, HW = H * W;
+    const int b = bz, HW = H * W;
     const int lane = threadIdx.x & (kWave - 1), w = threadIdx.x / kWave;
-    const int x = blockIdx.x * kWave + lane;
-    const int y0 = (blockIdx.y * 4 + w) * kAggRows;
+    const int x = bx * kWave + lane;
+    const int y0 = (by * 4 + w) * kAggRows;
     int lab[kAggRows];
 #pragma unroll
     for (int r = 0; r < kAggRows; ++r) {
@@ -177,6 +176,17 @@ __global__ __launch_bounds__(256) void k_agg_accum(const int32_t* __restrict__ l
         agg_flush(s.lab[threadIdx.x] - 1, s.sum[threadIdx.x], s.cnt[threadIdx.x], s.cls[threadIdx.x], b, sums, cnt, cls_min, sample);
 }
 
+__global__ __launch_bounds__(256) void k_agg_accum(const int32_t* __restrict__ labels,
+                                                   const int64_t* __restrict__ cm, const float* __restrict__ quat,
+                                                   const float* __restrict__ scales, const float* __restrict__ z,
+                                                   int H, int W, int N, const int32_t* __restrict__ n_dev,
+                                                   double* __restrict__ sums, int32_t* __restrict__ cnt,
+                                                   uint32_t* __restrict__ cls_min, int32_t* __restrict__ sample) {
+    if (n_dev) N = min(N, *n_dev);
+    __shared__ AggLds s;
+    agg_accum_block(s, blockIdx.x, blockIdx.y, blockIdx.z, labels, cm, quat, scales, z, H, W, N, sums, cnt, cls_min, sample);
+}
+
 // means, exp(z), quaternion re-normalisation, class / sample ids of instance i (one thread)
 __device__ __forceinline__ void agg_finalize_one(int i, const double* __restrict__ sums, const int32_t* __restrict__ cnt,
                                                  const uint32_t* __restrict__ cls_min, const int32_t* __restrict__ sample,
@@ -214,26 +224,17 @@ __global__ void k_agg_finalize(int N, const int32_t* __restrict__ n_dev, const d
 
 // grid (ceil(HW/4096), N): a workgroup writes one 4096-pixel chunk of one instance (four 4-pixel groups per lane, their
 // label loads issued together); the first block of every instance also finalises it (no launch of its own).
-__global__ __launch_bounds__(256) void k_agg_planes(const int32_t* __restrict__ labels, const float* __restrict__ xy,
-                                                    const int32_t* __restrict__ sample, int HW,
-                                                    const int32_t* __restrict__ n_dev,
-                                                    float* __restrict__ inst_masks, float* __restrict__ oxy,
-                                                    const double* __restrict__ sums, const int32_t* __restrict__ cnt,
-                                                    const uint32_t* __restrict__ cls_min, int64_t* __restrict__ class_ids,
-                                                    int64_t* __restrict__ sample_ids, float* __restrict__ oq,
-                                                    float* __restrict__ os, float* __restrict__ oz, float* __restrict__ stats,
-                                                    uint64_t* __restrict__ bits, int nwords) {
-    const int i = blockIdx.y;
-    if (n_dev && i >= *n_dev) return;     // capacity rows past the device-side instance count
-    if (blockIdx.x == 0 && threadIdx.x == 0) agg_finalize_one(i, sums, cnt, cls_min, sample, class_ids, sample_ids, oq, os, oz, stats);
-    const int b = sample[i];
+// the planes of chunk `bx` of instance i, which lives in image b
+__device__ __forceinline__ void agg_planes_block(int bx, int i, int b, const int32_t* __restrict__ labels, const float* __restrict__ xy,
+                                                 int HW, float* __restrict__ inst_masks, float* __restrict__ oxy,
+                                                 uint64_t* __restrict__ bits, int nwords) {
     const int32_t* L = labels + (size_t)b * HW;
     const bool vec = (HW & 3) == 0;
     const int lane = threadIdx.x & (kWave - 1);
     int4 lab[4];
 #pragma unroll
     for (int it = 0; it < 4; ++it) {
-        const int p0 = blockIdx.x * 4096 + it * 1024 + threadIdx.x * 4;
+        const int p0 = bx * 4096 + it * 1024 + threadIdx.x * 4;
         lab[it] = make_int4(0, 0, 0, 0);
         if (vec) {
             if (p0 < HW) lab[it] = *reinterpret_cast<const int4*>(L + p0);
@@ -246,7 +247,7 @@ __global__ __launch_bounds__(256) void k_agg_planes(const int32_t* __restrict__ 
     }
 #pragma unroll
     for (int it = 0; it < 4; ++it) {
-        const int p0 = blockIdx.x * 4096 + it * 1024 + threadIdx.x * 4;
+        const int p0 = bx * 4096 + it * 1024 + threadIdx.x * 4;
         const bool f0 = lab[it].x == i + 1, f1 = lab[it].y == i + 1, f2 = lab[it].z == i + 1, f3 = lab[it].w == i + 1;      // labels are >= 1
         if (bits) {
             // the instance's foreground as bit words for the vote's scan (bit j of word w = pixel 64 w + j, zero past HW):
@@ -263,7 +264,7 @@ __global__ __launch_bounds__(256) void k_agg_planes(const int32_t* __restrict__ 
                 };
                 const int sh = 16 * lane;
                 const uint64_t word = spread(b0 >> sh) | (spread(b1 >> sh) << 1) | (spread(b2 >> sh) << 2) | (spread(b3 >> sh) << 3);
-                const int wi = blockIdx.x * 64 + it * 16 + (threadIdx.x / kWave) * 4 + lane;
+                const int wi = bx * 64 + it * 16 + (threadIdx.x / kWave) * 4 + lane;
                 if (wi < nwords) bits[(size_t)i * nwords + wi] = word;
             }
         }
@@ -298,6 +299,75 @@ __global__ __launch_bounds__(256) void k_agg_planes(const int32_t* __restrict__ 
     }
 }
 
+// grid (ceil(HW/4096), N): a workgroup writes one 4096-pixel chunk of one instance (four 4-pixel groups per lane, their
+// label loads issued together); the first block of every instance also finalises it (no launch of its own).
+__global__ __launch_bounds__(256) void k_agg_planes(const int32_t* __restrict__ labels, const float* __restrict__ xy,
+                                                    const int32_t* __restrict__ sample, int HW,
+                                                    const int32_t* __restrict__ n_dev,
+                                                    float* __restrict__ inst_masks, float* __restrict__ oxy,
+                                                    const double* __restrict__ sums, const int32_t* __restrict__ cnt,
+                                                    const uint32_t* __restrict__ cls_min, int64_t* __restrict__ class_ids,
+                                                    int64_t* __restrict__ sample_ids, float* __restrict__ oq,
+                                                    float* __restrict__ os, float* __restrict__ oz, float* __restrict__ stats,
+                                                    uint64_t* __restrict__ bits, int nwords) {
+    const int i = blockIdx.y;
+    if (n_dev && i >= *n_dev) return;     // capacity rows past the device-side instance count
+    if (blockIdx.x == 0 && threadIdx.x == 0) agg_finalize_one(i, sums, cnt, cls_min, sample, class_ids, sample_ids, oq, os, oz, stats);
+    agg_planes_block(blockIdx.x, i, sample[i], labels, xy, HW, inst_masks, oxy, bits, nwords);
+}
+
+// ONE launch for both halves when the image of an instance is known without the accumulation (root_pix, from
+// fpc_cc_label): blocks [0, nacc) accumulate, the rest write planes; the accumulating block that arrives last (ticket)
+// finalises every instance.  The planes never wait for the sums.
+struct AggFusedArgs {
+    const int32_t* labels; const int64_t* cm; const float* quat; const float* scales; const float* xy; const float* z;
+    const int32_t* n_dev; const int32_t* root_pix;
+    int B, H, W, N, gax, gay, gpx, nwords;
+    double* sums; int32_t* cnt; uint32_t* cls_min; int32_t* sample; int32_t* ticket;
+    int64_t* class_ids; int64_t* sample_ids; float* inst_masks; float* oq; float* os; float* oz; float* oxy; float* stats;
+    uint64_t* bits;
+};
+
+__global__ __launch_bounds__(256) void k_agg_fused(const AggFusedArgs a) {
+    __shared__ AggLds s;
+    __shared__ int s_last;
+    const int N = a.n_dev ? min(a.N, *a.n_dev) : a.N;
+    const int HW = a.H * a.W;
+    const int nacc = a.gax * a.gay * a.B;
+    int bid = blockIdx.x;
+    if (bid < nacc) {
+        const int bx = bid % a.gax; bid /= a.gax;
+        const int by = bid % a.gay;
+        const int bz = bid / a.gay;
+        agg_accum_block(s, bx, by, bz, a.labels, a.cm, a.quat, a.scales, a.z, a.H, a.W, N, a.sums, a.cnt, a.cls_min, a.sample);
+        // the flushing threads drain their device-scope atomics before the ticket is taken (no cache write-back / invalidate:
+        // the sums live where atomics are performed, the last block reads them with cache-bypassing loads)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (threadIdx.x == 0) s_last = __hip_atomic_fetch_add(a.ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == nacc - 1;
+        __syncthreads();
+        if (!s_last) return;
+        for (int i = threadIdx.x; i < N; i += blockDim.x) {
+            // sums / counts were written by atomics of other workgroups: read them past this CU's caches
+            double sm[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+                sm[k] = __builtin_bit_cast(double, __hip_atomic_load((const unsigned long long*)(a.sums + (size_t)i * 8 + k), __ATOMIC_RELAXED,
+                                                                     __HIP_MEMORY_SCOPE_AGENT));
+            const int32_t c = __hip_atomic_load(a.cnt + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const uint32_t cl = __hip_atomic_load(a.cls_min + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const int32_t smp = a.root_pix[i] / HW;
+            agg_finalize_one(0, sm, &c, &cl, &smp, a.class_ids + i, a.sample_ids + i, a.oq + (size_t)i * 4, a.os + (size_t)i * 3,
+                             a.oz + i, a.stats ? a.stats + (size_t)i * 2 : nullptr);
+        }
+        return;
+    }
+    bid -= nacc;
+    const int bx = bid % a.gpx, i = bid / a.gpx;
+    if (i >= N) return;
+    agg_planes_block(bx, i, a.root_pix[i] / HW, a.labels, a.xy, HW, a.inst_masks, a.oxy, a.bits, a.nwords);
+}
+
 }  // namespace fpc
 
 using namespace fpc;
@@ -313,14 +383,14 @@ extern "C" int fpc_aggregate(const int32_t* labels, const int64_t* cat_mask, con
                              int64_t* sample_ids, float* inst_masks, float* oq, float* os, float* oz, float* oxy,
                              float* out_stats, void* ws, size_t ws_bytes, fpc_stream_t stream) {
     return fpc_aggregate_bits(labels, cat_mask, quat, scales, xy, z, B, H, W, N, n_dev, class_ids, sample_ids, inst_masks, oq, os, oz, oxy,
-                              out_stats, nullptr, ws, ws_bytes, stream);
+                              out_stats, nullptr, nullptr, ws, ws_bytes, stream);
 }
 
 extern "C" int fpc_aggregate_bits(const int32_t* labels, const int64_t* cat_mask, const float* quat, const float* scales,
                                   const float* xy, const float* z, int B, int H, int W, int N, const int32_t* n_dev,
                                   int64_t* class_ids, int64_t* sample_ids, float* inst_masks, float* oq, float* os, float* oz,
-                                  float* oxy, float* out_stats, uint64_t* inst_bits, void* ws, size_t ws_bytes,
-                                  fpc_stream_t stream) {
+                                  float* oxy, float* out_stats, uint64_t* inst_bits, const int32_t* root_pix, void* ws,
+                                  size_t ws_bytes, fpc_stream_t stream) {
     if (B < 0 || H < 1 || W < 1 || N < 0) return FPC_EINVAL;
     if (N == 0 || B == 0) return FPC_OK;
     if (B > 65535 || N > 65535) return FPC_EINVAL;
@@ -340,6 +410,21 @@ extern "C" int fpc_aggregate_bits(const int32_t* labels, const int64_t* cat_mask
     const int nwords = cdiv(HW, 4096) * 64;                 // fpc_mask_bits_words(H, W): whole 4096-pixel chunks
     int gx = cdiv(HW, 4096);
     if (((uintptr_t)inst_bits & 7) != 0) return FPC_EINVAL;
+    if (root_pix && (inst_masks || oxy || inst_bits) && (long long)B * HW <= 4LL * 640 * 480) {
+        // the image of instance i is root_pix[i] / (H W): the planes do not wait for the accumulation, one launch does both.
+        // For a few frames only (13.0 against 9.8 + 8.5 us on one): the planes part then runs at the accumulation's register
+        // count, which costs the bandwidth-bound large batches more than the launch saves (236 against 51 + 171 us on 32).
+        AggFusedArgs a{};
+        a.labels = labels; a.cm = cat_mask; a.quat = quat; a.scales = scales; a.xy = xy; a.z = z; a.n_dev = n_dev; a.root_pix = root_pix;
+        a.B = B; a.H = H; a.W = W; a.N = N; a.gax = cdiv(W, kWave); a.gay = cdiv(H, 4 * kAggRows); a.gpx = gx; a.nwords = nwords;
+        a.sums = w.sums; a.cnt = w.cnt; a.cls_min = w.cls_min; a.sample = w.sample; a.ticket = w.ticket;
+        a.class_ids = class_ids; a.sample_ids = sample_ids; a.inst_masks = inst_masks; a.oq = oq; a.os = os; a.oz = oz; a.oxy = oxy;
+        a.stats = out_stats; a.bits = inst_bits;
+        const long long grid = (long long)a.gax * a.gay * B + (long long)gx * N;
+        if (grid > 0x7FFFFFFFLL) return FPC_EINVAL;
+        hipLaunchKernelGGL(k_agg_fused, dim3((unsigned)grid), dim3(256), 0, s, a);
+        return check_launch();
+    }
     hipLaunchKernelGGL(k_agg_accum, dim3(cdiv(W, kWave), cdiv(H, 4 * kAggRows), B), dim3(256), 0, s, labels, cat_mask, quat, scales, z,
                        H, W, N, n_dev, w.sums,
                        w.cnt, w.cls_min, w.sample);

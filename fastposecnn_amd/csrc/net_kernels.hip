@@ -1631,7 +1631,7 @@ __global__ __launch_bounds__(64 * NW, BF3 ? 1 : 2) void k_conv_wino(const WinoAr
             u32x4 u0 = *reinterpret_cast<const u32x4*>(Wb + w_frag[0]), u1 = *reinterpret_cast<const u32x4*>(Wb + w_frag[1]);
             u32x2 t0 = *reinterpret_cast<const u32x2*>(Wb + w3_frag[0]), t1 = *reinterpret_cast<const u32x2*>(Wb + w3_frag[1]);
             u32x2 pn[4][3];
-#define FPC_BF3_MFMA(A, B0, B1)                                                                               \
+#define FPC_WINO_BF3_MFMA(A, B0, B1)                                                                               \
     do {                                                                                                      \
         acc[j][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, A), __builtin_bit_cast(bf16x8, B0), acc[j][0], 0, 0, 0); \
         acc[j][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, A), __builtin_bit_cast(bf16x8, B1), acc[j][1], 0, 0, 0); \
@@ -1658,24 +1658,24 @@ __global__ __launch_bounds__(64 * NW, BF3 ? 1 : 2) void k_conv_wino(const WinoAr
                 const u32x4 A1 = {pa[j][1][0], pa[j][1][1], pa[j][1][0], pa[j][1][1]};
                 const u32x4 A2 = {pa[j][0][0], pa[j][0][1], pa[j][2][0], pa[j][2][1]};
                 const u32x4 C0 = {t0[0], t0[1], u0[0], u0[1]}, C1 = {t1[0], t1[1], u1[0], u1[1]};
-                FPC_BF3_MFMA(A0, u0, u1);      // a1 b1 + a1 b2
+                FPC_WINO_BF3_MFMA(A0, u0, u1);      // a1 b1 + a1 b2
                 // the next step's fragments in the shadow of this wave's own MFMAs: transform at xi 0 / 1, split at xi 2 / 3
                 if (j == 0) { e[0] = __builtin_elementwise_fma(sg4, db[0], da[0]); e[1] = __builtin_elementwise_fma(sg4, db[1], da[1]); }
                 if (j == 1) { e[2] = __builtin_elementwise_fma(sg4, db[2], da[2]); e[3] = __builtin_elementwise_fma(sg4, db[3], da[3]); }
                 if (j == 2) split_bf3(vn[0], pn[0][0], pn[0][1], pn[0][2]);
                 if (j == 3) split_bf3(vn[2], pn[2][0], pn[2][1], pn[2][2]);
                 __builtin_amdgcn_sched_barrier(0);
-                FPC_BF3_MFMA(A1, u0, u1);      // a2 b1 + a2 b2
+                FPC_WINO_BF3_MFMA(A1, u0, u1);      // a2 b1 + a2 b2
                 if (j == 1) { vn[0] = sub_pk(e[0], e[2]); vn[1] = e[1] + e[2]; }
                 if (j == 2) split_bf3(vn[1], pn[1][0], pn[1][1], pn[1][2]);
                 if (j == 3) split_bf3(vn[3], pn[3][0], pn[3][1], pn[3][2]);
                 __builtin_amdgcn_sched_barrier(0);
-                FPC_BF3_MFMA(A2, C0, C1);      // a1 b3 + a3 b1
+                FPC_WINO_BF3_MFMA(A2, C0, C1);      // a1 b3 + a3 b1
                 if (j == 1) { vn[2] = sub_pk(e[2], e[1]); vn[3] = sub_pk(e[1], e[3]); }
                 __builtin_amdgcn_sched_barrier(0);
                 u0 = n0; u1 = n1; t0 = m0; t1 = m1;
             }
-#undef FPC_BF3_MFMA
+#undef FPC_WINO_BF3_MFMA
             __builtin_amdgcn_s_setprio(0);
 #pragma unroll
             for (int j = 0; j < 4; ++j) { pa[j][0] = pn[j][0]; pa[j][1] = pn[j][1]; pa[j][2] = pn[j][2]; }

@@ -44,11 +44,15 @@ class AggregationLayer(nn.Module):
         cm = cm.contiguous()
         labels = torch.empty((B, H, W), dtype=torch.int32, device=dev)
         n_dev = torch.empty(1, dtype=torch.int32, device=dev)      # always written by fpc_cc_label
+        # the first pixel of every component (labels 1..cap): tells the aggregation which image an instance lives in without
+        # waiting for its sums; rides on the labels tensor (see _aggregate)
+        root_pix = torch.empty(max(256, 64 * B), dtype=torch.int32, device=dev)
         L = nat.lib()
         with torch.cuda.device(dev):
             ws = nat.workspace("cc", dev, L.fpc_cc_workspace_bytes(B, H, W))
-            nat.check(L.fpc_cc_label(nat.ptr(cm), B, H, W, nat.ptr(labels), nat.ptr(n_dev), None, 0, nat.ptr(ws),
-                                     ws.numel(), nat.stream()), "fpc_cc_label")
+            nat.check(L.fpc_cc_label(nat.ptr(cm), B, H, W, nat.ptr(labels), nat.ptr(n_dev), nat.ptr(root_pix), root_pix.numel(),
+                                     nat.ptr(ws), ws.numel(), nat.stream()), "fpc_cc_label")
+        labels._fpc_root_pix = (root_pix, labels._version)
         if return_device_count:
             return labels, n_dev
         return labels, int(n_dev.item())
@@ -80,11 +84,13 @@ class AggregationLayer(nn.Module):
             # the masks also as bit words (1/32 of the bytes) for the vote's scan, which then skips the f32 planes this call
             # has just written; they ride on the masks tensor (see mask_bits_of), not in the dict the reference defines
             bits = torch.empty((N, L.fpc_mask_bits_words(H, W)), dtype=torch.int64, device=dev)
+            tag = getattr(labels, "_fpc_root_pix", None)
+            root_pix = tag[0] if (tag is not None and tag[1] == labels._version and tag[0].numel() >= N) else None
             nat.check(L.fpc_aggregate_bits(nat.ptr(labels), nat.ptr(cm), nat.ptr(q), nat.ptr(s), nat.ptr(xy), nat.ptr(z),
                                            B, H, W, N, nat.ptr(n_dev), nat.ptr(out['class_ids']), nat.ptr(out['sample_ids']),
                                            nat.ptr(out['instance_masks']), nat.ptr(out['quaternion']),
                                            nat.ptr(out['scales']), nat.ptr(out['z']), nat.ptr(out['xy']), nat.ptr(stats),
-                                           nat.ptr(bits), nat.ptr(ws), ws.numel(), nat.stream()), "fpc_aggregate_bits")
+                                           nat.ptr(bits), nat.ptr(root_pix), nat.ptr(ws), ws.numel(), nat.stream()), "fpc_aggregate_bits")
             out['instance_masks']._fpc_mask_bits = (bits, out['instance_masks']._version)
         return out
 

@@ -159,14 +159,16 @@ int fpc_aggregate(const int32_t* labels, const int64_t* cat_mask,
 /* The same, and — when inst_bits is not NULL — every instance's foreground also as bit words u64
  * [N][fpc_mask_bits_words(H, W)] (bit j of word w = pixel 64 w + j, zero past H W; whole 4096-pixel chunks): 1/32 of
  * the f32 mask plane, which fpc_ransac_voting_v3_bits reads INSTEAD of it.  No reference counterpart: the reference's
- * voting re-reads the f32 masks its aggregation has just written (lib/hough_voting.py:41-63). */
+ * voting re-reads the f32 masks its aggregation has just written (lib/hough_voting.py:41-63).
+ * root_pix (nullable): fpc_cc_label's root_pix with at least N valid entries (its cap >= N).  With it the image of an
+ * instance is known without the accumulation, and accumulation and planes run as ONE launch. */
 size_t fpc_mask_bits_words(int H, int W);
 int fpc_aggregate_bits(const int32_t* labels, const int64_t* cat_mask,
                        const float* quat, const float* scales, const float* xy, const float* z,
                        int B, int H, int W, int N, const int32_t* n_dev,
                        int64_t* class_ids, int64_t* sample_ids, float* inst_masks,
                        float* oq, float* os, float* oz, float* oxy, float* out_stats, uint64_t* inst_bits,
-                       void* ws, size_t ws_bytes, fpc_stream_t stream);
+                       const int32_t* root_pix, void* ws, size_t ws_bytes, fpc_stream_t stream);
 
 /* ---- pose assembly ----------------------------------------------------------
  * q f32 [n,4] scalar-last, xy [n,2], z [n], kinv f32 [9] row-major (device)
