@@ -414,7 +414,9 @@ extern "C" int fpc_mask_losses(const float* logits, const int64_t* target, int B
     if (B < 0 || C < 2 || C > 32 || HW < 1) return FPC_EINVAL;
     if (B == 0) return FPC_OK;
     if (B > 65535 || !logits || !target || (!sums6 && !grad) || (grad && !w3)) return FPC_EINVAL;
-    const dim3 grid(std::min(cdiv(HW, 256), 1024), B);
+    // the forward ends in six f64 atomics per workgroup on the same six addresses: few, long-running workgroups (device-scope
+    // f64 atomics serialise at ~1 us each once they contend: csrc/aggregate.hip); the backward has none and fills the chip
+    const dim3 grid(grad ? std::min(cdiv(HW, 256), 1024) : std::min(cdiv(HW, 256), 96), B);
     hipStream_t s = (hipStream_t)stream;
 #define FPC_ML(MAXC, BWD)                                                                                              \
     hipLaunchKernelGGL((k_mask_losses<MAXC, BWD>), grid, dim3(256), 0, s, logits, target, C, HW, (long long)ignore_ce,     \
