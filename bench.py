@@ -37,6 +37,7 @@ Extra objects on the JSON line:
                     1/2.25) / device time per network, against the 157.3 TFLOP/s f32 matrix peak (and, second figure,
                     against the bf16 x 3 equivalent peak: config.matrix_products says which product form the plans use)
   configs.config3   BASELINE.json configs[2]: ResNet34, batch 32 per step, same pipeline (shorter timed region)
+  plain_f32_products  the headline measurement once more with split-precision products switched off (1-GPU runs)
   train             BASELINE.json configs[4] at batch 8 on this GPU (fastposecnn_amd/train_bench.py; 1-GPU runs)
   cpu_baseline      the same step on the host: torch-CPU backbone + the C oracle's post-network path (1 thread and the
                     job's CPU share), three samples each
@@ -74,6 +75,7 @@ def parse(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-config3", action="store_true", help="skip the ResNet34 batch-32 section (configs[2])")
     ap.add_argument("--no-hn128", action="store_true", help="skip the hn=128 / 32-frame vote roofline")
+    ap.add_argument("--no-plain-f32", action="store_true", help="skip the second streamed measurement with plain f32 matrix products")
     ap.add_argument("--no-train-line", action="store_true", help="skip the `train` object (configs[4] at B=8 on this GPU, 1-GPU runs only)")
     ap.add_argument("--min-seconds", type=float, default=0.5, help="the K-step timed region is repeated until this much time is covered; `value` is the median repeat")
     ap.add_argument("--gather-every", type=int, default=0, help="frames per pose all-gather on the side stream (0 = frames in flight)")
@@ -276,7 +278,7 @@ def measure_copy_ceiling(dev):
         return None
 
 
-def run_inference(args, encoder, Bq, hn, steps, warmup, world, rank, dev, want_backbone=True):
+def run_inference(args, encoder, Bq, hn, steps, warmup, world, rank, dev, want_backbone=True, split_precision=None):
     """The timed hot path for one (encoder, batch) configuration.  Returns a dict of measurements and the objects
     later sections reuse."""
     import torch
@@ -290,7 +292,8 @@ def run_inference(args, encoder, Bq, hn, steps, warmup, world, rank, dev, want_b
     hp.HV_NUM_OF_HYPOTHESES = hn
     hp.ENCODER = encoder
     hp.ENGINE_TUNE_MODE = args.tune_mode
-    hp.ENGINE_SPLIT_PRECISION = bool(int(os.environ.get('FPC_SPLIT_PRECISION', '1')))      # 0: plain f32 MFMA products only
+    hp.ENGINE_SPLIT_PRECISION = (bool(int(os.environ.get('FPC_SPLIT_PRECISION', '1')))      # 0: plain f32 MFMA products only
+                                 if split_precision is None else bool(split_precision))
     hp.ENGINE_GRAPH = bool(int(os.environ.get('FPC_ENGINE_GRAPH', '1')))      # HIP graph replay of the frame-invariant launches
     torch.manual_seed(0)
     model = L.pose_regressor.MODELS[hp.MODEL].load_from_ckpt(None, hp).eval()
@@ -617,6 +620,16 @@ def main():
             line["cpu_baseline"] = cpu_baseline(ctx["model"].to("cpu"), ctx["image"][:1], one, args.hn,
                                                 torch.inverse(torch.from_numpy(ctx["hp"].NUMPY_INTRINSICS).float()).numpy(),
                                                 args.encoder)
+        if not args.no_plain_f32 and os.environ.get("FPC_SPLIT_PRECISION", "1") != "0" and not args.vote_only:
+            # the same streamed measurement with every product on the f32 matrix instruction, so that one line holds both
+            torch.cuda.empty_cache()
+            rp, ctxp = run_inference(args, args.encoder, args.batch, args.hn, max(50, args.steps // 2), max(5, args.warmup // 2), 1, 0,
+                                     dev, split_precision=False)
+            line["plain_f32_products"] = {"value": rp["value"], "unit": "img/s", "ms_per_step": rp["ms_per_step"], "steps": rp["steps"],
+                                          "backbone": {k: rp["backbone"][k] for k in ("ms", "achieved", "frac")} if "backbone" in rp else None,
+                                          "note": "HPARAM.ENGINE_SPLIT_PRECISION = False: the engine's plans may only use "
+                                                  "v_mfma_f32_32x32x2_f32 (a shorter timed region than `value`'s)"}
+            del rp, ctxp
         if not args.no_config3 and not (args.encoder == "resnet34" and args.batch == 32):
             del ctx
             torch.cuda.empty_cache()

@@ -20,3 +20,5 @@ if "train" in l:
 c3 = l.get("configs", {}).get("config3")
 if c3:
     print("config3", c3["value"], "img/s", "vote", c3["roofline"]["launch_ms"], "ms frac", c3["roofline"]["frac"], "backbone", c3.get("backbone", {}).get("frac"))
+
+if l.get("plain_f32_products"): print("plain f32 products", l["plain_f32_products"]["value"], "img/s", l["plain_f32_products"].get("backbone"))
