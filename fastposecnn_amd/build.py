@@ -64,6 +64,12 @@ def build(force=False, verbose=False, extra=()):
         subprocess.check_call([HIPCC, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", LIB, *objs, "-lz"])      # zlib: png_decode.hip
         with open(stamp, "w") as f:
             f.write(tag)
+        from . import isa_lint
+        try:
+            isa_lint.check(LIB)          # no `s_mov vcc` next to a v_div_fmas (csrc/common.hpp: div_ieee)
+        except Exception:
+            os.remove(stamp)             # the next build links and lints again
+            raise
     if verbose:
         print("built", LIB, "(diagnostic flags: %s)" % " ".join(extra) if extra else "")
     return LIB

@@ -196,15 +196,15 @@ __device__ __forceinline__ void agg_finalize_one(int i, const double* __restrict
     double c = (double)cnt[i];
     float q[4];
 #pragma unroll
-    for (int a = 0; a < 4; ++a) q[a] = (float)(sums[(size_t)i * 8 + a] / c);
+    for (int a = 0; a < 4; ++a) q[a] = (float)div_ieee(sums[(size_t)i * 8 + a], c);
     float nq = sqrtf(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
     if (stats) { stats[(size_t)i * 2] = (float)cnt[i]; stats[(size_t)i * 2 + 1] = nq; }     // for the backward (train.hip)
     if (nq == 0.0f) nq = 1.0f;
 #pragma unroll
-    for (int a = 0; a < 4; ++a) oq[(size_t)i * 4 + a] = q[a] / nq;
+    for (int a = 0; a < 4; ++a) oq[(size_t)i * 4 + a] = div_ieee(q[a], nq);
 #pragma unroll
-    for (int a = 0; a < 3; ++a) os[(size_t)i * 3 + a] = (float)(sums[(size_t)i * 8 + 4 + a] / c);
-    oz[i] = expf((float)(sums[(size_t)i * 8 + 7] / c));
+    for (int a = 0; a < 3; ++a) os[(size_t)i * 3 + a] = (float)div_ieee(sums[(size_t)i * 8 + 4 + a], c);
+    oz[i] = expf((float)div_ieee(sums[(size_t)i * 8 + 7], c));
     uint32_t cm = 0xFFFFFFFFu - cls_min[i];
     class_ids[i] = cm == 0xFFFFFFFFu ? 0 : (int64_t)cm;
     sample_ids[i] = cnt[i] > 0 ? (int64_t)sample[i] : -1;

@@ -32,6 +32,54 @@ inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 // (tests/test_host_logic.py::test_eps_threshold_equivalence).
 __device__ __forceinline__ bool below_eps(float x) { return x <= 1e-6f; }
 
+// IEEE division as ONE instruction group.  hipcc expands `a / b` into v_div_scale / v_rcp / fma / v_div_fmas /
+// v_div_fixup, and when it interleaves two independent divisions the second one's scale flag travels through an SGPR
+// pair and returns as `s_mov_b64 vcc, s[..]` one or two instructions before its `v_div_fmas`.  On gfx950 that
+// v_div_fmas was seen reading the PREVIOUS vcc (the first division's flag) in aligned 16-lane groups when MFMA-heavy
+// waves shared the CU: k_vote_plan's hypothesis x came out wrong in about one frame in 10^4 under the streaming
+// runtime (tools_dev/pipe_soak.py).  Inside this block each division takes vcc straight from its own
+// v_div_scale, seven VALU instructions before the v_div_fmas, and nothing can be scheduled into it.  The sequence is
+// the compiler's own (f32 denormals on, the HIP default), so quotients are the correctly rounded ones the oracle gets.
+// fastposecnn_amd/isa_lint.py fails the build when any kernel still has an SALU write of vcc close before a
+// v_div_fmas.
+__device__ __forceinline__ float div_ieee(float a, float b) {
+    float d, n, r, e, q, o;
+    asm("v_div_scale_f32 %0, vcc, %7, %7, %6\n\t"
+        "v_rcp_f32_e32 %2, %0\n\t"
+        "v_div_scale_f32 %1, vcc, %6, %7, %6\n\t"
+        "v_fma_f32 %3, -%0, %2, 1.0\n\t"
+        "v_fmac_f32_e32 %2, %3, %2\n\t"
+        "v_mul_f32_e32 %4, %1, %2\n\t"
+        "v_fma_f32 %3, -%0, %4, %1\n\t"
+        "v_fmac_f32_e32 %4, %3, %2\n\t"
+        "v_fma_f32 %3, -%0, %4, %1\n\t"
+        "v_div_fmas_f32 %3, %3, %2, %4\n\t"
+        "v_div_fixup_f32 %5, %3, %7, %6"
+        : "=&v"(d), "=&v"(n), "=&v"(r), "=&v"(e), "=&v"(q), "=&v"(o)
+        : "v"(a), "v"(b)
+        : "vcc");
+    return o;
+}
+
+__device__ __forceinline__ double div_ieee(double a, double b) {
+    double d, n, r, e, q, o;
+    asm("v_div_scale_f64 %0, vcc, %7, %7, %6\n\t"
+        "v_rcp_f64_e32 %2, %0\n\t"
+        "v_div_scale_f64 %1, vcc, %6, %7, %6\n\t"
+        "v_fma_f64 %3, -%0, %2, 1.0\n\t"
+        "v_fmac_f64_e32 %2, %2, %3\n\t"
+        "v_fma_f64 %3, -%0, %2, 1.0\n\t"
+        "v_fmac_f64_e32 %2, %2, %3\n\t"
+        "v_mul_f64 %4, %1, %2\n\t"
+        "v_fma_f64 %3, -%0, %4, %1\n\t"
+        "v_div_fmas_f64 %3, %3, %2, %4\n\t"
+        "v_div_fixup_f64 %5, %3, %7, %6"
+        : "=&v"(d), "=&v"(n), "=&v"(r), "=&v"(e), "=&v"(q), "=&v"(o)
+        : "v"(a), "v"(b)
+        : "vcc");
+    return o;
+}
+
 // One (pixel, hypothesis) vote, RV/src/ransac_voting_kernel.cu:106-125, with the
 // pixel's |n| passed in (it does not depend on the hypothesis).  Compiled with
 // -ffp-contract=off; `/` and sqrtf are correctly rounded in hipcc's default mode, so

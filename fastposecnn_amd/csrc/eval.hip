@@ -36,7 +36,7 @@ __device__ __forceinline__ bool inverse4(const float* m, double* inv) {
     inv[15] = a[0] * a[5] * a[10] - a[0] * a[6] * a[9] - a[4] * a[1] * a[10] + a[4] * a[2] * a[9] + a[8] * a[1] * a[6] - a[8] * a[2] * a[5];
     const double det = a[0] * inv[0] + a[1] * inv[4] + a[2] * inv[8] + a[3] * inv[12];
     if (det == 0.0) return false;
-    const double r = 1.0 / det;
+    const double r = div_ieee(1.0, det);
 #pragma unroll
     for (int i = 0; i < 16; ++i) inv[i] *= r;
     return true;
@@ -77,7 +77,7 @@ __global__ __launch_bounds__(64) void k_pose_errors(const float* __restrict__ q0
                 double oz = aw * rz + ax * ry - ay * rx + az * rw;
                 double nn = sqrt(ow * ow + ox * ox + oy * oy + oz * oz);
                 if (nn == 0.0) nn = 1.0;
-                ow /= nn; ox /= nn; oy /= nn; oz /= nn;
+                ow = div_ieee(ow, nn); ox = div_ieee(ox, nn); oy = div_ieee(oy, nn); oz = div_ieee(oz, nn);
                 const double m0 = (double)a0 - ow, m1 = (double)a1 - ox, m2 = (double)a2 - oy, m3 = (double)a3 - oz;
                 const double p0 = (double)a0 + ow, p1 = (double)a1 + ox, p2 = (double)a2 + oy, p3 = (double)a3 + oz;
                 const double dm = sqrt(m0 * m0 + m1 * m1 + m2 * m2 + m3 * m3), dp = sqrt(p0 * p0 + p1 * p1 + p2 * p2 + p3 * p3);
@@ -104,7 +104,7 @@ __global__ __launch_bounds__(64) void k_pose_errors(const float* __restrict__ q0
         const double wy = inv[4] * px + inv[5] * py + inv[6] * pz + inv[7];
         const double wz = inv[8] * px + inv[9] * py + inv[10] * pz + inv[11];
         const double ww = inv[12] * px + inv[13] * py + inv[14] * pz + inv[15];
-        const double cx = wx / ww, cy = wy / ww, cz = wz / ww;
+        const double cx = div_ieee(wx, ww), cy = div_ieee(wy, ww), cz = div_ieee(wz, ww);
         const double mx = ok ? fmax(cx, fmax(cy, cz)) : nan(""), mn = ok ? fmin(cx, fmin(cy, cz)) : nan("");
         // corner j of one box meets corner j of the other (lanes j and j + 8)
         const double omx = __shfl_xor(mx, 8, kWave), omn = __shfl_xor(mn, 8, kWave);
@@ -118,7 +118,7 @@ __global__ __launch_bounds__(64) void k_pose_errors(const float* __restrict__ q0
         }
         const double vol1 = __shfl(v, 0, kWave), vol2 = __shfl(v, 8, kWave);
         const double inter = (e < 0.0) ? 0.0 : ie;
-        if (lane == 0) out_iou[i] = (float)(inter / (vol1 + vol2 - inter));
+        if (lane == 0) out_iou[i] = (float)div_ieee(inter, vol1 + vol2 - inter);
     }
 }
 

@@ -137,7 +137,7 @@ __global__ __launch_bounds__(256) void k_gn4_bwd_dx(const GnArgs a) {
             s1 += da * a.gamma[4 * t + e]; s2 += db * a.gamma[4 * t + e];
         }
         const double n = 4.0 * a.HW;
-        sg[t][0] = (float)(s1 / n); sg[t][1] = (float)(s2 / n);
+        sg[t][0] = (float)div_ieee(s1, n); sg[t][1] = (float)div_ieee(s2, n);
     }
     __syncthreads();
     const size_t n4 = (size_t)a.HW * Q;

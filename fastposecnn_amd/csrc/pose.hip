@@ -11,7 +11,7 @@ __global__ void k_pose_rt(const float* __restrict__ q, const float* __restrict__
                           float* __restrict__ RT) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    float zz = z[i] / 1000.0f;
+    float zz = div_ieee(z[i], 1000.0f);
     float px = xy[2 * i] * zz, py = xy[2 * i + 1] * zz;
     float t[3];
 #pragma unroll
@@ -19,7 +19,7 @@ __global__ void k_pose_rt(const float* __restrict__ q, const float* __restrict__
     float q1 = q[4 * i], q2 = q[4 * i + 1], q3 = q[4 * i + 2], q4 = q[4 * i + 3];
     float nrm = sqrtf(q1 * q1 + q2 * q2 + q3 * q3 + q4 * q4);
     if (!(nrm > 0.0f)) nrm = 1.0f;
-    q1 /= nrm; q2 /= nrm; q3 /= nrm; q4 /= nrm;
+    q1 = div_ieee(q1, nrm); q2 = div_ieee(q2, nrm); q3 = div_ieee(q3, nrm); q4 = div_ieee(q4, nrm);
     float a = q1 * q1, b = q2 * q2, c = q3 * q3, d = q4 * q4;
     // M as written at gpu_tensor_funcs.py:316-324; the function returns its transpose
     float M[9] = {a - b - c + d, 2 * (q1 * q2 + q3 * q4), 2 * (q1 * q3 - q2 * q4),

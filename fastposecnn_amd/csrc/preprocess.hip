@@ -66,8 +66,8 @@ __global__ __launch_bounds__(256) void k_pre_apply(const uint8_t* __restrict__ i
     const bool div255 = a.scale255 && max(mx[0], max(mx[1], mx[2])) > 1u;
     auto f64 = [&](int c, unsigned x) -> double {
         double v = (double)x;
-        if (div255) v = v / 255.0;
-        return (v - a.mean[c]) / a.stdv[c];
+        if (div255) v = div_ieee(v, 255.0);
+        return div_ieee(v - a.mean[c], a.stdv[c]);
     };
     if (threadIdx.x == 0) {
         double m = 0.0;
@@ -76,7 +76,7 @@ __global__ __launch_bounds__(256) void k_pre_apply(const uint8_t* __restrict__ i
     }
     __syncthreads();
     const double m = s_m;
-    for (int i = threadIdx.x; i < 768; i += blockDim.x) s_tab[i >> 8][i & 255] = (float)(f64(i >> 8, i & 255) / m);
+    for (int i = threadIdx.x; i < 768; i += blockDim.x) s_tab[i >> 8][i & 255] = (float)div_ieee(f64(i >> 8, i & 255), m);
     __syncthreads();
     const uint8_t* p = img + (size_t)b * HW * 3;
     float* o = out + (size_t)b * 3 * HW;

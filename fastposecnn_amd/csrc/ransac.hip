@@ -63,8 +63,9 @@ __device__ __forceinline__ void intersect(float4 a, float4 b, float& x, float& y
     float det_x = ny1 * nx0 - ny0 * nx1;
     x = 0.0f; y = 0.0f;
     if (!below_eps(fabsf(det_y)) && !below_eps(fabsf(det_x))) {
-        y = (nx1 * (nx0 * cx0 + ny0 * cy0) - nx0 * (nx1 * cx1 + ny1 * cy1)) / det_y;
-        x = (ny1 * (nx0 * cx0 + ny0 * cy0) - ny0 * (nx1 * cx1 + ny1 * cy1)) / det_x;
+        // div_ieee (common.hpp): the two quotients must not be interleaved by the scheduler
+        y = div_ieee(nx1 * (nx0 * cx0 + ny0 * cy0) - nx0 * (nx1 * cx1 + ny1 * cy1), det_y);
+        x = div_ieee(ny1 * (nx0 * cx0 + ny0 * cy0) - ny0 * (nx1 * cx1 + ny1 * cy1), det_x);
     }
 }
 

@@ -387,3 +387,26 @@ def test_mask_bits_ride_on_the_very_tensor_only():
     assert al.mask_bits_of(m[:2]) is None and al.mask_bits_of(m.clone()) is None
     m.add_(1.0)
     assert al.mask_bits_of(m) is None            # written since: the words may be stale
+
+
+def test_isa_lint_flags_salu_vcc_before_div_fmas():
+    """fastposecnn_amd/isa_lint.py: the pattern behind the streaming-runtime hypothesis mismatch."""
+    from fastposecnn_amd import isa_lint
+    paired = ["v_div_scale_f32 v7, vcc, v16, v8, v16", "v_div_scale_f32 v20, s[0:1], v17, v9, v17",
+              "v_fma_f32 v4, -v4, v21, v7", "v_div_fmas_f32 v4, v4, v18, v21", "s_mov_b64 vcc, s[0:1]",
+              "v_div_fixup_f32 v18, v4, v8, v16", "v_div_fmas_f32 v4, v7, v19, v22"]
+    hits = isa_lint.scan(paired)
+    assert [(h[0], h[1]) for h in hits] == [(2, "s_mov_b64 vcc, s[0:1]")]
+    alone = ["v_div_scale_f32 v4, vcc, v8, v8, v16", "v_rcp_f32_e32 v18, v4", "v_div_scale_f32 v7, vcc, v16, v8, v16",
+             "v_fma_f32 v21, -v4, v18, 1.0", "v_div_fmas_f32 v4, v4, v18, v21"]
+    assert isa_lint.scan(alone) == []
+    far = ["s_mov_b64 vcc, s[0:1]"] + ["v_mov_b32_e32 v1, v2"] * isa_lint.WINDOW + ["v_div_fmas_f32 v4, v7, v19, v22"]
+    assert isa_lint.scan(far) == []
+
+
+def test_isa_lint_built_library_is_clean():
+    from fastposecnn_amd import isa_lint
+    if not os.path.exists(isa_lint.LIB) or not os.path.exists(isa_lint.OBJDUMP):
+        pytest.skip("libfpc_hip.so or llvm-objdump not present")
+    bad, n_div = isa_lint.findings()
+    assert n_div > 0 and bad == []
