@@ -85,6 +85,7 @@ _SIGNATURES = {
     "fpc_groupnorm4_relu_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, ctypes.c_float, _vp]),
     "fpc_groupnorm4_relu_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "fpc_conv2d_wgrad": (_i, [_vp, _i64, _i64, _i64, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
+    "fpc_conv2d_wgrad_split": (_i, [_vp, _i64, _i64, _i64, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
 }
 
 EXPORTED = tuple(_SIGNATURES)
@@ -103,7 +104,7 @@ def lib():
             fn = getattr(L, name)
             fn.restype = res
             fn.argtypes = args
-        if L.fpc_abi_version() != 7:
+        if L.fpc_abi_version() != 8:
             raise RuntimeError("fastposecnn_amd: libfpc_hip.so ABI version mismatch")
         _lib = L
     return _lib

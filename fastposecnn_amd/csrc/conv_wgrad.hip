@@ -19,7 +19,8 @@
 namespace fpc {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 constexpr int kWgBK = 32;         // pixels per K-step
 
@@ -35,7 +36,11 @@ struct WgradArgs {
 
 // TM x TN blocks of 32 x 32 per wave: the workgroup tile is (64 TM) x (64 TN).  The 128-wide forms halve the LDS reads
 // and the global bytes per MFMA; layers with 64 channels on a side keep the 64-wide form for that side.
-template <int TM, int TN>
+// BF3: split-precision products (common.hpp: split_bf3).  The LDS image stays f32 [pixel][channel]; a lane gathers its
+// eight pixels of a 16-pixel group with eight 4-byte reads of one column, splits them into three bf16 pieces and issues
+// the six piece products on v_mfma_f32_32x32x16_bf16 (the same six, smallest first, as the forward kernels): 24 matrix
+// instructions of 8 passes per 16 pixels and 2 x 2 blocks against 32 of 16 passes for the f32 form.
+template <int TM, int TN, bool BF3>
 __global__ __launch_bounds__(256, 2) void k_conv_wgrad(const WgradArgs a) {
     constexpr int BM = 64 * TM, BN = 64 * TN;
     constexpr int RA = BM + 4, RB = BN + 4;       // floats per LDS row: consecutive pixels start 4 banks apart
@@ -116,6 +121,41 @@ __global__ __launch_bounds__(256, 2) void k_conv_wgrad(const WgradArgs a) {
     for (int ks = ks0; ks < ks1; ++ks) {
         const int buf = (ks - ks0) & 1;
         if (ks + 1 < ks1) FPC_WG_LOAD(ks + 1);
+        if constexpr (BF3) {
+            const float* As = lds + buf * kWgBK * (RA + RB) + 8 * lh * RA + wm * (BM / 2) + li;
+            const float* Bs = lds + buf * kWgBK * (RA + RB) + kWgBK * RA + 8 * lh * RB + wn * (BN / 2) + li;
+#pragma unroll
+            for (int k16 = 0; k16 < kWgBK; k16 += 16) {
+                bf16x8 FA[3][TM], FB[3][TN];
+#pragma unroll
+                for (int i = 0; i < TM + TN; ++i) {
+                    const float* src = i < TM ? As + k16 * RA + 32 * i : Bs + k16 * RB + 32 * (i - TM);
+                    const int R = i < TM ? RA : RB;
+                    f32x4 lo, hi;
+#pragma unroll
+                    for (int kk = 0; kk < 4; ++kk) { lo[kk] = src[kk * R]; hi[kk] = src[(4 + kk) * R]; }
+                    u32x2 l1, l2, l3, h1, h2, h3;
+                    split_bf3(lo, l1, l2, l3);
+                    split_bf3(hi, h1, h2, h3);
+                    const bf16x8 q1 = __builtin_bit_cast(bf16x8, u32x4{l1.x, l1.y, h1.x, h1.y});
+                    const bf16x8 q2 = __builtin_bit_cast(bf16x8, u32x4{l2.x, l2.y, h2.x, h2.y});
+                    const bf16x8 q3 = __builtin_bit_cast(bf16x8, u32x4{l3.x, l3.y, h3.x, h3.y});
+                    if (i < TM) { FA[0][i < TM ? i : 0] = q1; FA[1][i < TM ? i : 0] = q2; FA[2][i < TM ? i : 0] = q3; }
+                    else { FB[0][i < TM ? 0 : i - TM] = q1; FB[1][i < TM ? 0 : i - TM] = q2; FB[2][i < TM ? 0 : i - TM] = q3; }
+                }
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(FA[2][i], FB[0][j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(FA[0][i], FB[2][j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(FA[1][i], FB[1][j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(FA[1][i], FB[0][j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(FA[0][i], FB[1][j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(FA[0][i], FB[0][j], acc[i][j], 0, 0, 0);
+                    }
+            }
+        } else {
         const float* As = lds + buf * kWgBK * (RA + RB) + lh * RA + wm * (BM / 2) + li;
         const float* Bs = lds + buf * kWgBK * (RA + RB) + kWgBK * RA + lh * RB + wn * (BN / 2) + li;
         // 4 pixel pairs at a time: their fragments are read before the MFMAs that use them are issued
@@ -136,6 +176,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_wgrad(const WgradArgs a) {
 #pragma unroll
                     for (int j = 0; j < TN; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[kk][i], fb[kk][j], acc[i][j], 0, 0, 0);
+        }
         }
         if (ks + 1 < ks1) FPC_WG_STORE(buf ^ 1);
         __syncthreads();
@@ -212,9 +253,9 @@ extern "C" size_t fpc_conv2d_wgrad_workspace_bytes(int B, int Ho, int Wo, int Ci
 // element strides sb / sh / sw, 16-byte aligned rows) and output gradient dy [B, Ho, Wo, Cout] (NHWC contiguous).
 // Requires Cin % 64 == 0 and Cout % 4 == 0 (FPC_EINVAL otherwise: the caller keeps another path for the stem and the
 // odd-width heads).  Any stride / padding.  Deterministic: fixed slice order.
-extern "C" int fpc_conv2d_wgrad(const float* x, int64_t sb, int64_t sh, int64_t sw, const float* dy, float* dw, int B, int Hi,
-                                int Wi, int Cin, int Cout, int Kh, int Kw, int stride, int pad, void* ws, size_t ws_bytes,
-                                fpc_stream_t stream) {
+static int conv2d_wgrad(bool split, const float* x, int64_t sb, int64_t sh, int64_t sw, const float* dy, float* dw, int B, int Hi,
+                        int Wi, int Cin, int Cout, int Kh, int Kw, int stride, int pad, void* ws, size_t ws_bytes,
+                        fpc_stream_t stream) {
     if (!x || !dy || !dw || !ws || B < 1 || Kh < 1 || Kw < 1 || stride < 1 || pad < 0) return FPC_EINVAL;
     if (Cin % 64 != 0 || Cout % 4 != 0 || Cout < 4) return FPC_EINVAL;
     if (((uintptr_t)x & 15) || ((uintptr_t)dy & 15) || (sb & 3) || (sh & 3) || (sw & 3)) return FPC_EINVAL;
@@ -229,14 +270,35 @@ extern "C" int fpc_conv2d_wgrad(const float* x, int64_t sb, int64_t sh, int64_t 
     hipStream_t s = (hipStream_t)stream;
     const long long grid = (long long)a.nsplit * Kh * Kw * a.mtiles * a.ntiles;
     if (grid > 0x7FFFFFFFLL) return FPC_EINVAL;
-    if (a.bm == 128 && a.bn == 128) hipLaunchKernelGGL((k_conv_wgrad<2, 2>), dim3((unsigned)grid), dim3(256), 0, s, a);
-    else if (a.bm == 128) hipLaunchKernelGGL((k_conv_wgrad<2, 1>), dim3((unsigned)grid), dim3(256), 0, s, a);
-    else if (a.bn == 128) hipLaunchKernelGGL((k_conv_wgrad<1, 2>), dim3((unsigned)grid), dim3(256), 0, s, a);
-    else hipLaunchKernelGGL((k_conv_wgrad<1, 1>), dim3((unsigned)grid), dim3(256), 0, s, a);
+#define FPC_WG_LAUNCH(TM_, TN_)                                                                               \
+    do {                                                                                                      \
+        if (split) hipLaunchKernelGGL((k_conv_wgrad<TM_, TN_, true>), dim3((unsigned)grid), dim3(256), 0, s, a);  \
+        else hipLaunchKernelGGL((k_conv_wgrad<TM_, TN_, false>), dim3((unsigned)grid), dim3(256), 0, s, a);   \
+    } while (0)
+    if (a.bm == 128 && a.bn == 128) FPC_WG_LAUNCH(2, 2);
+    else if (a.bm == 128) FPC_WG_LAUNCH(2, 1);
+    else if (a.bn == 128) FPC_WG_LAUNCH(1, 2);
+    else FPC_WG_LAUNCH(1, 1);
+#undef FPC_WG_LAUNCH
     int rc = check_launch();
     if (rc) return rc;
     const size_t cc = (size_t)Cout * Cin;
     hipLaunchKernelGGL(k_wgrad_reduce, dim3((unsigned)((cc + 255) / 256), (unsigned)(Kh * Kw)), dim3(256), 0, s, (const float*)ws, dw,
                        a.nsplit, Kh * Kw, Cout, Cin);
     return check_launch();
+}
+
+extern "C" int fpc_conv2d_wgrad(const float* x, int64_t sb, int64_t sh, int64_t sw, const float* dy, float* dw, int B, int Hi,
+                                int Wi, int Cin, int Cout, int Kh, int Kw, int stride, int pad, void* ws, size_t ws_bytes,
+                                fpc_stream_t stream) {
+    return conv2d_wgrad(false, x, sb, sh, sw, dy, dw, B, Hi, Wi, Cin, Cout, Kh, Kw, stride, pad, ws, ws_bytes, stream);
+}
+
+// The same with split-precision matrix products (three bf16 pieces per f32 operand, six piece products accumulated in
+// f32: include/fpc.h "split precision").  Same workspace, same determinism; results differ from fpc_conv2d_wgrad in the
+// last bits only (both are within f32 summation error of the exact sums).
+extern "C" int fpc_conv2d_wgrad_split(const float* x, int64_t sb, int64_t sh, int64_t sw, const float* dy, float* dw, int B,
+                                      int Hi, int Wi, int Cin, int Cout, int Kh, int Kw, int stride, int pad, void* ws,
+                                      size_t ws_bytes, fpc_stream_t stream) {
+    return conv2d_wgrad(true, x, sb, sh, sw, dy, dw, B, Hi, Wi, Cin, Cout, Kh, Kw, stride, pad, ws, ws_bytes, stream);
 }

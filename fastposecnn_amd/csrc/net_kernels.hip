@@ -28,28 +28,7 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
-// Split-precision operands (opt-in, ConvArgs::bf3): x = p1 + p2 + p3 exactly, each part 8 significant bits (bf16 by
-// truncation), four values -> three packed 8-byte groups.  The six products p_i q_j with i + j <= 4 on
-// v_mfma_f32_32x32x16_bf16 (f32 accumulation) reproduce the f32 product chain to ~2^-24 relative
-// (tools_dev/split_precision_check.py) at 2.2x the f32 matrix rate (tools_dev/bf16x3_probe.hip).
-__device__ __forceinline__ unsigned pack_hi16(float lo, float hi) {        // {bf16(lo), bf16(hi)}: the two high halves
-    return __builtin_amdgcn_perm(__builtin_bit_cast(unsigned, hi), __builtin_bit_cast(unsigned, lo), 0x07060302u);
-}
-__device__ __forceinline__ void split_bf3(f32x4 v, u32x2& p1, u32x2& p2, u32x2& p3) {
-    float r[4], q[4];
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        const float x = v[e];                     // (bit_cast of a vector ELEMENT expression misbehaved: go through a scalar)
-        const unsigned xb = __builtin_bit_cast(unsigned, x) & 0xFFFF0000u;
-        r[e] = x - __builtin_bit_cast(float, xb);
-        const float y = r[e];
-        const unsigned yb = __builtin_bit_cast(unsigned, y) & 0xFFFF0000u;
-        q[e] = y - __builtin_bit_cast(float, yb);
-    }
-    p1 = u32x2{pack_hi16(v[0], v[1]), pack_hi16(v[2], v[3])};
-    p2 = u32x2{pack_hi16(r[0], r[1]), pack_hi16(r[2], r[3])};
-    p3 = u32x2{pack_hi16(q[0], q[1]), pack_hi16(q[2], q[3])};
-}
+// split_bf3 / pack_hi16: common.hpp (shared with conv_wgrad.hip)
 
 // raw buffer descriptor over [base, base + 2 GB): offsets are 32-bit, an offset >= 2^31 reads zeros without
 // touching memory (measured, tools_dev/dma_vs_mfma.hip) — the zero fill of the convolution padding

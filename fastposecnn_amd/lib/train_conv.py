@@ -108,8 +108,9 @@ class _Conv2dFn(torch.autograd.Function):
             gw = torch.empty_like(w)
             sb, sc, sh, sw = x.stride()
             ws = nat.workspace("train_wgrad", x.device, L.fpc_conv2d_wgrad_workspace_bytes(B, Ho, Wo, Cin, Cout, Kh, Kw))
-            nat.check(L.fpc_conv2d_wgrad(x.data_ptr(), sb, sh, sw, gy.data_ptr(), gw.data_ptr(), B, H, W, Cin, Cout, Kh, Kw, stride,
-                                         pad, ws.data_ptr(), ws.numel(), nat.stream()), "fpc_conv2d_wgrad")
+            wgrad = L.fpc_conv2d_wgrad_split if SPLIT_PRECISION else L.fpc_conv2d_wgrad
+            nat.check(wgrad(x.data_ptr(), sb, sh, sw, gy.data_ptr(), gw.data_ptr(), B, H, W, Cin, Cout, Kh, Kw, stride,
+                            pad, ws.data_ptr(), ws.numel(), nat.stream()), "fpc_conv2d_wgrad")
             counters["wgrad_native"] += 1
         if aten_x or aten_w:
             ax, aw, _ = torch.ops.aten.convolution_backward(gy, x, w, None, [stride, stride], [pad, pad], [1, 1], False, [0, 0], 1,

@@ -43,7 +43,7 @@
 extern "C" {
 #endif
 
-#define FPC_ABI_VERSION 7
+#define FPC_ABI_VERSION 8
 
 #define FPC_OK 0
 #define FPC_EINVAL (-1)      /* bad argument (shape, null pointer, ...) */
@@ -356,6 +356,12 @@ size_t fpc_conv2d_wgrad_workspace_bytes(int B, int Ho, int Wo, int Cin, int Cout
 int fpc_conv2d_wgrad(const float* x, int64_t sb, int64_t sh, int64_t sw, const float* dy, float* dw, int B, int Hi,
                      int Wi, int Cin, int Cout, int Kh, int Kw, int stride, int pad, void* ws, size_t ws_bytes,
                      fpc_stream_t stream);
+/* The same sums with split-precision matrix products (see "split precision" above: three bf16 pieces per f32 operand,
+ * the six leading piece products accumulated in f32), about twice the f32 matrix rate.  Same workspace and shape rules,
+ * deterministic; differs from fpc_conv2d_wgrad in the last bits only (ABI 8). */
+int fpc_conv2d_wgrad_split(const float* x, int64_t sb, int64_t sh, int64_t sw, const float* dy, float* dw, int B, int Hi,
+                           int Wi, int Cin, int Cout, int Kh, int Kw, int stride, int pad, void* ws, size_t ws_bytes,
+                           fpc_stream_t stream);
 
 /* Bilinear upsampling with align_corners = True (the x2 steps of the FPN segmentation blocks and the x4 of the heads:
  * torch.nn.functional.interpolate / nn.UpsamplingBilinear2d in the reference's network, F/lib/pose_regressor.py:608-666),

@@ -391,6 +391,41 @@ def test_wgrad_is_deterministic_and_refuses_unsupported_shapes():
     assert rc == -2                                        # FPC_EWORKSPACE
 
 
+@pytest.mark.parametrize("shape", [(2, 128, 30, 40, 128, 3, 1, 1), (2, 64, 33, 47, 128, 3, 2, 1), (3, 128, 20, 24, 64, 1, 1, 0),
+                                   (2, 64, 24, 40, 36, 3, 1, 1)])
+def test_wgrad_split_precision_matches_float64_like_the_f32_form(shape):
+    """fpc_conv2d_wgrad_split (three bf16 pieces per operand, six piece products) against the float64 weight gradient:
+    its error is at the level of the plain-f32 matrix form's (both are f32 accumulations of ~10^3..10^4 terms)."""
+    from fastposecnn_amd import _native as nat
+    L = nat.lib()
+    dev = torch.device("cuda:0")
+    B, Cin, H, W, Cout, k, stride, pad = shape
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn((B, Cin, H, W), generator=g)
+    Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
+    dy = torch.randn((B, Cout, Ho, Wo), generator=g)
+    w64 = torch.zeros((Cout, Cin, k, k), dtype=torch.float64, requires_grad=True)
+    torch.nn.functional.conv2d(x.double(), w64, None, stride, pad).backward(dy.double())
+    ref = w64.grad
+    xd = x.permute(0, 2, 3, 1).contiguous().to(dev)
+    dyd = dy.permute(0, 2, 3, 1).contiguous().to(dev)
+    ws = torch.empty(L.fpc_conv2d_wgrad_workspace_bytes(B, Ho, Wo, Cin, Cout, k, k), dtype=torch.uint8, device=dev)
+    errs = {}
+    for name in ("fpc_conv2d_wgrad", "fpc_conv2d_wgrad_split"):
+        outs = []
+        for _ in range(2):
+            dw = torch.full((Cout, Cin, k, k), float("nan"), device=dev)
+            nat.check(getattr(L, name)(xd.data_ptr(), H * W * Cin, W * Cin, Cin, dyd.data_ptr(), dw.data_ptr(), B, H, W, Cin, Cout, k, k,
+                                       stride, pad, ws.data_ptr(), ws.numel(), nat.stream()), name)
+            outs.append(dw.clone())
+        torch.cuda.synchronize()
+        assert torch.equal(outs[0], outs[1])                              # deterministic
+        errs[name] = float((outs[0].cpu().double() - ref).abs().max() / ref.abs().max())
+    assert errs["fpc_conv2d_wgrad"] <= 2e-6, errs
+    assert errs["fpc_conv2d_wgrad_split"] <= 2e-6, errs                   # f32-level: 1e-4 is the bar, this is 50x inside it
+    assert errs["fpc_conv2d_wgrad_split"] <= 4 * errs["fpc_conv2d_wgrad"] + 2e-7, errs
+
+
 def test_training_mode_model_uses_native_convolutions_and_matches_torch_path():
     """One forward + backward of the whole network in training mode (BatchNorm on batch statistics): native convolutions
     and the same model on torch's f32 kernels, each against the model in float64.  Two f32 implementations differ from
