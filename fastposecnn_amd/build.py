@@ -67,6 +67,8 @@ def build(force=False, verbose=False, extra=()):
         from . import isa_lint
         try:
             isa_lint.check(LIB)          # no `s_mov vcc` next to a v_div_fmas (csrc/common.hpp: div_ieee)
+        except FileNotFoundError as e:   # no llvm-objdump on this machine: the library is usable, the lint did not run
+            print("fastposecnn_amd.build: ISA lint skipped (%s)" % e, file=sys.stderr)
         except Exception:
             os.remove(stamp)             # the next build links and lints again
             raise
