@@ -40,6 +40,10 @@ struct WgradArgs {
 // eight pixels of a 16-pixel group with eight 4-byte reads of one column, splits them into three bf16 pieces and issues
 // the six piece products on v_mfma_f32_32x32x16_bf16 (the same six, smallest first, as the forward kernels): 24 matrix
 // instructions of 8 passes per 16 pixels and 2 x 2 blocks against 32 of 16 passes for the f32 form.
+// (Round 3 also tried the pieces split ONCE by the staging thread into K-contiguous bf16 planes — one ds_read_b128 per
+// fragment and plane, half the vector-ALU work: 6.4 ms per training step against 5.9 for this form.  Neither is bound by
+// the matrix pipe: a 128 x 128 tile moves 1 byte per 32 flop and every tap re-reads both operands, ~13 TB/s from L2 at
+// the split-precision matrix rate.  Sharing dy across the taps of a kernel row is what would help.)
 template <int TM, int TN, bool BF3>
 __global__ __launch_bounds__(256, 2) void k_conv_wgrad(const WgradArgs a) {
     constexpr int BM = 64 * TM, BN = 64 * TN;
