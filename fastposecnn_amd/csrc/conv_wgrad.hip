@@ -43,7 +43,10 @@ struct WgradArgs {
 // (Round 3 also tried the pieces split ONCE by the staging thread into K-contiguous bf16 planes — one ds_read_b128 per
 // fragment and plane, half the vector-ALU work: 6.4 ms per training step against 5.9 for this form.  Neither is bound by
 // the matrix pipe: a 128 x 128 tile moves 1 byte per 32 flop and every tap re-reads both operands, ~13 TB/s from L2 at
-// the split-precision matrix rate.  Sharing dy across the taps of a kernel row is what would help.)
+// the split-precision matrix rate.  Sharing dy across the taps of a kernel row is what would help.  Also measured and not
+// kept: all tiles of a pixel slice on one XCD (blockIdx remap: 5.91 ms, unchanged — the operands are not missing L2) and
+// global loads leading by two K-steps through a second register set (spills at 256 VGPRs: 6.8 ms).  A split-precision
+// step lasts 0.65 us, shorter than a load's latency, with 34 KB per workgroup in flight: the bound is bytes in flight.)
 template <int TM, int TN, bool BF3>
 __global__ __launch_bounds__(256, 2) void k_conv_wgrad(const WgradArgs a) {
     constexpr int BM = 64 * TM, BN = 64 * TN;
