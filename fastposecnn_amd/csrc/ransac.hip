@@ -539,9 +539,13 @@ __global__ __launch_bounds__(64 * kFinWaves) void k_vote_final(const VoteParams 
                 for (int i = 0; i < 8; ++i) p.out_refine[(size_t)inst * 8 + i] = 0.0;
         }
     FPC_STAMP(3, 0);
+    // the first task's record is requested together with the task count (the grid never exceeds the record array: a
+    // slot past the count holds stale data that is not used), and an instance's chunk table together with its counts and
+    // hypotheses: two dependent round trips less in a kernel that is a chain of them
+    int4 rb = p.runs[blockIdx.x];
     const int nr = p.ctrl[1];
     for (int t = blockIdx.x; t < nr; t += gridDim.x) {
-        const int4 rb = p.runs[t];
+        if (t != (int)blockIdx.x) rb = p.runs[t];
         const int inst = rb.x, run = rb.y, c_lo = rb.z;
         const int fg = rb.w & 0x7fffffff, nrec = (fg + p.run_entries - 1) / p.run_entries;
         const bool thin = rb.w < 0;
@@ -550,6 +554,9 @@ __global__ __launch_bounds__(64 * kFinWaves) void k_vote_final(const VoteParams 
         int wc = -1, wi = 0x7fffffff;
         float wx = 0.0f, wy = 0.0f;
         const float* hp = p.hyp + (size_t)inst * hn * 2;
+        const bool table_in_reg = p.lds_table && nch < (int)blockDim.x;
+        int cpre_reg = 0;
+        if (table_in_reg && (int)threadIdx.x <= nch) cpre_reg = gpre[threadIdx.x];
         for (int h = threadIdx.x; h < hn; h += blockDim.x) {
             const int cv = p.counts[(size_t)inst * p.hnp + h];
             const float2 g = *reinterpret_cast<const float2*>(hp + 2 * h);
@@ -563,8 +570,11 @@ __global__ __launch_bounds__(64 * kFinWaves) void k_vote_final(const VoteParams 
         }
         __syncthreads();                                               // LDS of the previous task is free
         if (lane == 0) { s_red[wv] = wc; s_red[kFinWaves + wv] = wi; s_pt[wv] = make_float2(wx, wy); }
-        if (p.lds_table)
+        if (table_in_reg) {
+            if ((int)threadIdx.x <= nch) s_cpre[threadIdx.x] = cpre_reg;
+        } else if (p.lds_table) {
             for (int c = threadIdx.x; c <= nch; c += blockDim.x) s_cpre[c] = gpre[c];
+        }
         __syncthreads();
         wc = s_red[0]; wi = s_red[kFinWaves];
         {
