@@ -198,6 +198,12 @@ class FPNBlock(nn.Module):
         self.skip_conv = Conv2d(skip_channels, pyramid_channels, kernel_size=1)
 
     def forward(self, x, skip=None):
+        c = self.skip_conv
+        if c.training and x.is_cuda and torch.is_grad_enabled():      # the training step: lateral convolution + merge in one launch
+            from fastposecnn_amd.lib import train_conv
+            y = train_conv.conv2d_up_add(skip, c.weight, c.bias, x, c.padding[0])
+            if y is not None:
+                return y
         x = F.interpolate(x, scale_factor=2, mode="nearest")
         skip = self.skip_conv(skip)
         return x + skip

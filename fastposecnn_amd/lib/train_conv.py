@@ -31,20 +31,21 @@ def _channels_last(t):
     return t if t.stride(1) == 1 and t.is_contiguous(memory_format=torch.channels_last) else t.contiguous(memory_format=torch.channels_last)
 
 
-def _run(x, w, bias, stride, pad, code, out):
+def _run(x, w, bias, stride, pad, code, out, up=None):
     B, Cin, H, W = x.shape
     Cout, _, Kh, Kw = w.shape
     Ho, Wo = out.shape[2], out.shape[3]
     L = nat.lib()
     sb, sc, sh, sw = x.stride()
     ws = nat.workspace("train_conv", x.device, L.fpc_conv2d_workspace_bytes_for(B, Ho, Wo, Cin, Cout, Kh, Kw, 0, 0, code))
-    nat.check(L.fpc_conv2d(x.data_ptr(), sb, sh, sw, sc, w.data_ptr(), None, nat.ptr(bias), None, None, out.data_ptr(), None,
+    nat.check(L.fpc_conv2d(x.data_ptr(), sb, sh, sw, sc, w.data_ptr(), None, nat.ptr(bias), None, nat.ptr(up), out.data_ptr(), None,
                            B, H, W, Cin, Cout, Kh, Kw, stride, pad, 0, 0, 0, code, ws.data_ptr(), ws.numel(), nat.stream()),
               "fpc_conv2d (training)")
 
 
-def conv_nhwc(x, w, bias, stride, pad):
-    """x [B,Cin,H,W] channel-last, w OIHW contiguous -> [B,Cout,Ho,Wo] channel-last, on the engine's kernels."""
+def conv_nhwc(x, w, bias, stride, pad, up=None):
+    """x [B,Cin,H,W] channel-last, w OIHW contiguous -> [B,Cout,Ho,Wo] channel-last, on the engine's kernels.
+    up [B,Cout,Ho/2,Wo/2] channel-last contiguous: added nearest-x2 upsampled in the kernel's epilogue (the FPN top-down merge)."""
     B, Cin, H, W = x.shape
     Cout, _, Kh, Kw = w.shape
     Ho, Wo = (H + 2 * pad - Kh) // stride + 1, (W + 2 * pad - Kw) // stride + 1
@@ -68,12 +69,48 @@ def conv_nhwc(x, w, bias, stride, pad):
             ev[1].synchronize()
             best = min(best, (ev[0].elapsed_time(ev[1]), c))
         code = _plan_cache[key] = best[1]
-    _run(x, w, bias, stride, pad, code, out)
+    _run(x, w, bias, stride, pad, code, out, up)
     return out
 
 
 def _native_forward_ok(x, w):
     return w.shape[1] % 32 == 0 and w.shape[2] == w.shape[3]
+
+
+def _conv_backward(x, w, gy, stride, pad, needs, has_bias):
+    """(dx, dW, db) of a convolution whose forward ran on the native kernels; needs = (x, W, bias) wanted."""
+    Cout, Cin, Kh, Kw = w.shape
+    gy = _channels_last(gy)
+    need_x, need_w = needs[0], needs[1]
+    gx = gw = gb = None
+    aten_x = need_x and not (stride == 1 and Cout % 32 == 0 and pad <= Kh - 1)
+    aten_w = need_w and not (Cin % 64 == 0 and Cout % 4 == 0)
+    if need_x and not aten_x:
+        # dx = conv(dy, W'), W'[ci][co][kh][kw] = W[co][ci][K-1-kh][K-1-kw], padding K-1-pad
+        w2 = w.flip(2, 3).transpose(0, 1).contiguous() if Kh > 1 else w.transpose(0, 1).contiguous()
+        gx = conv_nhwc(gy, w2, None, 1, Kh - 1 - pad)
+        counters["dgrad_native"] += 1
+    if need_w and not aten_w:
+        L = nat.lib()
+        B, _, H, W = x.shape
+        Ho, Wo = gy.shape[2], gy.shape[3]
+        gw = torch.empty_like(w)
+        sb, sc, sh, sw = x.stride()
+        ws = nat.workspace("train_wgrad", x.device, L.fpc_conv2d_wgrad_workspace_bytes(B, Ho, Wo, Cin, Cout, Kh, Kw))
+        wgrad = L.fpc_conv2d_wgrad_split if SPLIT_PRECISION else L.fpc_conv2d_wgrad
+        nat.check(wgrad(x.data_ptr(), sb, sh, sw, gy.data_ptr(), gw.data_ptr(), B, H, W, Cin, Cout, Kh, Kw, stride,
+                        pad, ws.data_ptr(), ws.numel(), nat.stream()), "fpc_conv2d_wgrad")
+        counters["wgrad_native"] += 1
+    if aten_x or aten_w:
+        ax, aw, _ = torch.ops.aten.convolution_backward(gy, x, w, None, [stride, stride], [pad, pad], [1, 1], False, [0, 0], 1,
+                                                        [aten_x, aten_w, False])
+        if aten_x:
+            gx = ax; counters["dgrad_aten"] += 1
+        if aten_w:
+            gw = aw; counters["wgrad_aten"] += 1
+    if has_bias and needs[2]:
+        gb = gy.sum((0, 2, 3))
+    return gx, gw, gb
 
 
 class _Conv2dFn(torch.autograd.Function):
@@ -89,39 +126,45 @@ class _Conv2dFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gy):
         x, w = ctx.saved_tensors
-        stride, pad = ctx.stride, ctx.pad
-        Cout, Cin, Kh, Kw = w.shape
-        gy = _channels_last(gy)
-        need_x, need_w = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
-        gx = gw = gb = None
-        aten_x = need_x and not (stride == 1 and Cout % 32 == 0 and pad <= Kh - 1)
-        aten_w = need_w and not (Cin % 64 == 0 and Cout % 4 == 0)
-        if need_x and not aten_x:
-            # dx = conv(dy, W'), W'[ci][co][kh][kw] = W[co][ci][K-1-kh][K-1-kw], padding K-1-pad
-            w2 = w.flip(2, 3).transpose(0, 1).contiguous() if Kh > 1 else w.transpose(0, 1).contiguous()
-            gx = conv_nhwc(gy, w2, None, 1, Kh - 1 - pad)
-            counters["dgrad_native"] += 1
-        if need_w and not aten_w:
-            L = nat.lib()
-            B, _, H, W = x.shape
-            Ho, Wo = gy.shape[2], gy.shape[3]
-            gw = torch.empty_like(w)
-            sb, sc, sh, sw = x.stride()
-            ws = nat.workspace("train_wgrad", x.device, L.fpc_conv2d_wgrad_workspace_bytes(B, Ho, Wo, Cin, Cout, Kh, Kw))
-            wgrad = L.fpc_conv2d_wgrad_split if SPLIT_PRECISION else L.fpc_conv2d_wgrad
-            nat.check(wgrad(x.data_ptr(), sb, sh, sw, gy.data_ptr(), gw.data_ptr(), B, H, W, Cin, Cout, Kh, Kw, stride,
-                            pad, ws.data_ptr(), ws.numel(), nat.stream()), "fpc_conv2d_wgrad")
-            counters["wgrad_native"] += 1
-        if aten_x or aten_w:
-            ax, aw, _ = torch.ops.aten.convolution_backward(gy, x, w, None, [stride, stride], [pad, pad], [1, 1], False, [0, 0], 1,
-                                                            [aten_x, aten_w, False])
-            if aten_x:
-                gx = ax; counters["dgrad_aten"] += 1
-            if aten_w:
-                gw = aw; counters["wgrad_aten"] += 1
-        if ctx.has_bias and ctx.needs_input_grad[2]:
-            gb = gy.sum((0, 2, 3))
+        gx, gw, gb = _conv_backward(x, w, gy, ctx.stride, ctx.pad, ctx.needs_input_grad, ctx.has_bias)
         return gx, gw, gb, None, None
+
+
+class _ConvUpAddFn(torch.autograd.Function):
+    """conv(x, w, bias) + nearest_x2(top): the FPN block's lateral 1x1 convolution and top-down merge
+    (smp FPNBlock: F.interpolate(top, scale_factor=2, mode="nearest") + skip_conv(skip)) as ONE native launch — the
+    engine's convolution epilogue adds the upsampled pyramid level, as on the inference path.  Backward: the convolution's
+    as _Conv2dFn; the gradient of `top` is the 2 x 2 block sum of the output gradient."""
+
+    @staticmethod
+    def forward(ctx, x, w, bias, top, pad):
+        x = _channels_last(x)
+        w = w.contiguous()
+        top = _channels_last(top)
+        ctx.pad, ctx.has_bias = pad, bias is not None
+        ctx.save_for_backward(x, w)
+        counters["fwd_native"] += 1
+        return conv_nhwc(x, w, bias, 1, pad, up=top)
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, w = ctx.saved_tensors
+        gy = _channels_last(gy)
+        gx, gw, gb = _conv_backward(x, w, gy, 1, ctx.pad, ctx.needs_input_grad, ctx.has_bias)
+        gt = torch.nn.functional.avg_pool2d(gy, 2, divisor_override=1) if ctx.needs_input_grad[3] else None
+        return gx, gw, gb, gt, None
+
+
+def conv2d_up_add(x, w, bias, top, pad):
+    """conv(x) + nearest-x2(top) for the FPN merge; None when the shapes do not fit the fused form (the caller keeps the
+    separate ops)."""
+    if not (ENABLED and x.is_cuda and x.dtype == torch.float32 and top.dtype == torch.float32 and _native_forward_ok(x, w)):
+        return None
+    Cout = w.shape[0]
+    Ho, Wo = x.shape[2] + 2 * pad - w.shape[2] + 1, x.shape[3] + 2 * pad - w.shape[3] + 1
+    if Cout % 4 != 0 or Ho % 2 or Wo % 2 or tuple(top.shape) != (x.shape[0], Cout, Ho // 2, Wo // 2):
+        return None
+    return _ConvUpAddFn.apply(x, w, bias, top, int(pad))
 
 
 def conv2d(x, w, bias, stride, pad):

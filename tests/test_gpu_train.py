@@ -562,3 +562,33 @@ def test_native_groupnorm_relu_forward_and_backward_vs_float64(case):
         close(xd.grad, xr2.grad, "dx", 1e-4)
         close(gn.weight.grad, ref.weight.grad, "dgamma", 1e-4)
         close(gn.bias.grad, ref.bias.grad, "dbeta", 1e-4)
+
+
+def test_fpn_block_fused_lateral_conv_and_merge_matches_float64():
+    """FPNBlock in training mode: skip_conv(skip) + nearest_x2(top) as one native launch (train_conv.conv2d_up_add), forward
+    and all three gradients against the same block in float64."""
+    from fastposecnn_amd.lib import backbone, train_conv
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(5)
+    blk = backbone.FPNBlock(128, 64).to(dev).train()
+    top = torch.randn((2, 128, 15, 20), generator=g).to(dev).requires_grad_()
+    skip = torch.randn((2, 64, 30, 40), generator=g).to(dev).requires_grad_()
+    gy = torch.randn((2, 128, 30, 40), generator=g).to(dev)
+    before = train_conv.counters["fwd_native"]
+    y = blk(top, skip)
+    assert train_conv.counters["fwd_native"] == before + 1 and y.grad_fn.name().startswith("_ConvUpAddFn")
+    y.backward(gy)
+    w64 = blk.skip_conv.weight.detach().double().requires_grad_()
+    b64 = blk.skip_conv.bias.detach().double().requires_grad_()
+    t64, s64 = top.detach().double().requires_grad_(), skip.detach().double().requires_grad_()
+    r = torch.nn.functional.interpolate(t64, scale_factor=2, mode="nearest") + torch.nn.functional.conv2d(s64, w64, b64)
+    r.backward(gy.double())
+
+    def close(a, b, what, tol):
+        err = float((a.double() - b).abs().max() / b.abs().max())
+        assert err <= tol, (what, err)
+    close(y, r, "forward", 2e-6)
+    close(top.grad, t64.grad, "d top", 2e-6)
+    close(skip.grad, s64.grad, "d skip", 2e-5)
+    close(blk.skip_conv.weight.grad, w64.grad, "d weight", 2e-5)
+    close(blk.skip_conv.bias.grad, b64.grad, "d bias", 2e-5)
