@@ -122,6 +122,202 @@ __global__ __launch_bounds__(256) void k_up_bilinear_bwd_1d(const UpArgs a, int 
     a.dst[off] = acc;
 }
 
+
+// ---- vector forms (round 3).  The one-element-per-thread kernels above spend their time on index arithmetic (an integer
+// division, four 64-bit address chains, the source-index computation) per 4 bytes stored: 1.3-1.7 TB/s on the training
+// step's tensors.  These do the arithmetic once per FOUR elements that share it and move 16 bytes per access.
+
+// channel-last source and destination, C % 4 == 0: thread = (output pixel, four channels): four float4 loads, one store
+__global__ __launch_bounds__(256) void k_up_fwd_nhwc4(const UpArgs a) {
+    const int C4 = a.C >> 2;
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= a.W * C4) return;
+    const int ox = j / C4, c4 = j - ox * C4, oy = blockIdx.y, b = blockIdx.z;
+    int y0, y1, x0, x1;
+    float ly0, ly1, lx0, lx1;
+    src_index(a.ry, oy, a.h, y0, y1, ly0, ly1);
+    src_index(a.rx, ox, a.w, x0, x1, lx0, lx1);
+    const float* p = a.src + b * a.s_b + 4 * c4;
+    const f32x4 v00 = *reinterpret_cast<const f32x4*>(p + y0 * a.s_y + x0 * a.s_x), v01 = *reinterpret_cast<const f32x4*>(p + y0 * a.s_y + x1 * a.s_x);
+    const f32x4 v10 = *reinterpret_cast<const f32x4*>(p + y1 * a.s_y + x0 * a.s_x), v11 = *reinterpret_cast<const f32x4*>(p + y1 * a.s_y + x1 * a.s_x);
+    f32x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = ly0 * (lx0 * v00[e] + lx1 * v01[e]) + ly1 * (lx0 * v10[e] + lx1 * v11[e]);
+    *reinterpret_cast<f32x4*>(a.dst + b * a.d_b + (long long)oy * a.d_y + (long long)ox * a.d_x + 4 * c4) = o;
+}
+
+// x-fastest (NCHW) destination, W % 4 == 0, any source layout: block (64, 4) = 64 groups of four consecutive ox x 4 rows of
+// plane blockIdx.z; the row's y terms once per thread, one 16-byte store
+__global__ __launch_bounds__(256) void k_up_fwd_nchw4(const UpArgs a) {
+    const int x4 = blockIdx.x * 64 + threadIdx.x, oy = blockIdx.y * 4 + threadIdx.y;
+    if (4 * x4 >= a.W || oy >= a.H) return;
+    const int b = blockIdx.z / a.C, c = blockIdx.z - b * a.C;
+    int y0, y1;
+    float ly0, ly1;
+    src_index(a.ry, oy, a.h, y0, y1, ly0, ly1);
+    const float* p0 = a.src + b * a.s_b + c * a.s_c + y0 * a.s_y;
+    const float* p1 = a.src + b * a.s_b + c * a.s_c + y1 * a.s_y;
+    f32x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        int x0, x1;
+        float lx0, lx1;
+        src_index(a.rx, 4 * x4 + e, a.w, x0, x1, lx0, lx1);
+        o[e] = ly0 * (lx0 * p0[x0 * a.s_x] + lx1 * p0[x1 * a.s_x]) + ly1 * (lx0 * p1[x0 * a.s_x] + lx1 * p1[x1 * a.s_x]);
+    }
+    *reinterpret_cast<f32x4*>(a.dst + b * a.d_b + c * a.d_c + (long long)oy * a.d_y + 4 * x4) = o;
+}
+
+// channel-last source (a pixel's channels contiguous, pixels of a row contiguous) -> x-fastest (NCHW) destination: the heads'
+// x4 (24 or fewer channels at 120 x 160 -> 480 x 640).  A thread of k_up_fwd_nchw4 gathers 16 values 4 C bytes apart per
+// 16 bytes stored.  Here a workgroup owns 64 output columns x 4 output rows x all channels: the source patch (<= 4 rows x
+// <= 34 pixels x C) goes to LDS with coalesced loads, a thread keeps ONE output position and its four weights and walks the
+// channels: per channel four LDS reads and one store that is 256 contiguous bytes per wave.  dynamic LDS: 4 * 34 * C floats.
+constexpr int kUpPatchW = 34, kUpPatchH = 4;
+__global__ __launch_bounds__(256) void k_up_fwd_nhwc_to_nchw(const UpArgs a) {
+    extern __shared__ float s_patch[];                               // [row][pixel][C]
+    const int C = a.C, b = blockIdx.z;
+    const int ox0 = blockIdx.x * 64, oy0 = blockIdx.y * 4;
+    const int ox = ox0 + (threadIdx.x & 63), oy = oy0 + (threadIdx.x >> 6);
+    // the patch: source rows / columns the block's outputs read (src_index is monotone in o)
+    const int ox_last = min(a.W, ox0 + 64) - 1, oy_last = min(a.H, oy0 + 4) - 1;
+    int ya, yb, xa, xb, t0, t1;
+    float f0, f1;
+    src_index(a.ry, oy0, a.h, ya, t1, f0, f1);
+    src_index(a.ry, oy_last, a.h, t0, yb, f0, f1);
+    src_index(a.rx, ox0, a.w, xa, t1, f0, f1);
+    src_index(a.rx, ox_last, a.w, t0, xb, f0, f1);
+    const int pw = xb - xa + 1, ph = yb - ya + 1, rowf = pw * C;       // <= kUpPatchW, <= kUpPatchH (host checks the scale)
+    const float* src = a.src + b * a.s_b + ya * a.s_y + xa * a.s_x;
+    for (int r = 0; r < ph; ++r)
+        for (int i = threadIdx.x; i < rowf; i += 256) s_patch[r * kUpPatchW * C + i] = src[r * a.s_y + i];      // s_x == C, s_c == 1
+    __syncthreads();
+    if (ox >= a.W || oy >= a.H) return;
+    int y0, y1, x0, x1;
+    float ly0, ly1, lx0, lx1;
+    src_index(a.ry, oy, a.h, y0, y1, ly0, ly1);
+    src_index(a.rx, ox, a.w, x0, x1, lx0, lx1);
+    const float* p00 = s_patch + ((y0 - ya) * kUpPatchW + (x0 - xa)) * C;
+    const float* p01 = s_patch + ((y0 - ya) * kUpPatchW + (x1 - xa)) * C;
+    const float* p10 = s_patch + ((y1 - ya) * kUpPatchW + (x0 - xa)) * C;
+    const float* p11 = s_patch + ((y1 - ya) * kUpPatchW + (x1 - xa)) * C;
+    float* d = a.dst + b * a.d_b + (long long)oy * a.d_y + ox;
+#pragma unroll 4
+    for (int c = 0; c < C; ++c) d[c * a.d_c] = ly0 * (lx0 * p00[c] + lx1 * p01[c]) + ly1 * (lx0 * p10[c] + lx1 * p11[c]);
+}
+
+// adjoint, channel-last on both sides, C % 4 == 0: thread = (dst pixel, four channels); the taps' weights once per four
+// channels, float4 loads.  Same tap order as k_up_bilinear_bwd_1d: identical sums.
+template <int AXIS>
+__global__ __launch_bounds__(256) void k_up_bwd_1d_nhwc4(const UpArgs a, int n_in, int n_out, float r) {
+    const int C4 = a.C >> 2;
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= a.w * C4) return;
+    const int x = j / C4, c4 = j - x * C4, y = blockIdx.y, b = blockIdx.z;
+    const int i = AXIS == 0 ? x : y;
+    int lo, hi;
+    adjoint_range(r, i, n_out, lo, hi);
+    const float* p = a.src + b * a.s_b + 4 * c4 + (AXIS == 0 ? y * a.s_y : x * a.s_x);
+    const long long st = AXIS == 0 ? a.s_x : a.s_y;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    if (hi - lo < kUpTaps) {
+        float wgt[kUpTaps];
+        f32x4 val[kUpTaps];
+#pragma unroll
+        for (int k = 0; k < kUpTaps; ++k) {
+            wgt[k] = lo + k <= hi ? adjoint_weight(r, lo + k, n_in, i) : 0.f;
+            val[k] = wgt[k] != 0.f ? *reinterpret_cast<const f32x4*>(p + (lo + k) * st) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int k = 0; k < kUpTaps; ++k)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[e] += wgt[k] * val[k][e];
+    } else {
+        for (int o = lo; o <= hi; ++o) {
+            const float wv = adjoint_weight(r, o, n_in, i);
+            if (wv != 0.f) {
+                const f32x4 v = *reinterpret_cast<const f32x4*>(p + o * st);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[e] += wv * v[e];
+            }
+        }
+    }
+    *reinterpret_cast<f32x4*>(a.dst + b * a.d_b + (long long)y * a.d_y + (long long)x * a.d_x + 4 * c4) = acc;
+}
+
+// adjoint along x, x-fastest source and destination: block (64, 4): thread = dst column i of FOUR consecutive rows of plane
+// blockIdx.z (rows 4 (4 blockIdx.y + threadIdx.y) ..+3): the weights depend on i only
+__global__ __launch_bounds__(256) void k_up_bwd_x_nchw(const UpArgs a, int n_in, int n_out, float r) {
+    const int i = blockIdx.x * 64 + threadIdx.x, y0 = (blockIdx.y * 4 + threadIdx.y) * 4;
+    if (i >= a.w || y0 >= a.h) return;
+    const int b = blockIdx.z / a.C, c = blockIdx.z - b * a.C;
+    int lo, hi;
+    adjoint_range(r, i, n_out, lo, hi);
+    const float* p = a.src + b * a.s_b + c * a.s_c + y0 * a.s_y;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    const int rows = min(4, a.h - y0);
+    if (hi - lo < kUpTaps) {
+        float wgt[kUpTaps];
+#pragma unroll
+        for (int k = 0; k < kUpTaps; ++k) wgt[k] = lo + k <= hi ? adjoint_weight(r, lo + k, n_in, i) : 0.f;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            if (q >= rows) break;
+            float val[kUpTaps];
+#pragma unroll
+            for (int k = 0; k < kUpTaps; ++k) val[k] = wgt[k] != 0.f ? p[q * a.s_y + (lo + k) * a.s_x] : 0.f;
+#pragma unroll
+            for (int k = 0; k < kUpTaps; ++k) acc[q] += wgt[k] * val[k];
+        }
+    } else {
+        for (int o = lo; o <= hi; ++o) {
+            const float wv = adjoint_weight(r, o, n_in, i);
+            if (wv != 0.f)
+                for (int q = 0; q < rows; ++q) acc[q] += wv * p[q * a.s_y + o * a.s_x];
+        }
+    }
+    float* d = a.dst + b * a.d_b + c * a.d_c + (long long)y0 * a.d_y + i;
+    for (int q = 0; q < rows; ++q) d[q * a.d_y] = acc[q];
+}
+
+// adjoint along y, x-fastest source (rows contiguous, w % 4 == 0): block (64, 4): thread = four consecutive columns of dst
+// row blockIdx.y * 4 + threadIdx.y; float4 loads down the taps.  dst through its strides (either layout).
+__global__ __launch_bounds__(256) void k_up_bwd_y_nchw4(const UpArgs a, int n_in, int n_out, float r) {
+    const int x4 = blockIdx.x * 64 + threadIdx.x, i = blockIdx.y * 4 + threadIdx.y;
+    if (4 * x4 >= a.w || i >= a.h) return;
+    const int b = blockIdx.z / a.C, c = blockIdx.z - b * a.C;
+    int lo, hi;
+    adjoint_range(r, i, n_out, lo, hi);
+    const float* p = a.src + b * a.s_b + c * a.s_c + 4 * x4;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    if (hi - lo < kUpTaps) {
+        float wgt[kUpTaps];
+        f32x4 val[kUpTaps];
+#pragma unroll
+        for (int k = 0; k < kUpTaps; ++k) {
+            wgt[k] = lo + k <= hi ? adjoint_weight(r, lo + k, n_in, i) : 0.f;
+            val[k] = wgt[k] != 0.f ? *reinterpret_cast<const f32x4*>(p + (lo + k) * a.s_y) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int k = 0; k < kUpTaps; ++k)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[e] += wgt[k] * val[k][e];
+    } else {
+        for (int o = lo; o <= hi; ++o) {
+            const float wv = adjoint_weight(r, o, n_in, i);
+            if (wv != 0.f) {
+                const f32x4 v = *reinterpret_cast<const f32x4*>(p + o * a.s_y);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[e] += wv * v[e];
+            }
+        }
+    }
+    float* d = a.dst + b * a.d_b + c * a.d_c + (long long)i * a.d_y + (long long)(4 * x4) * a.d_x;
+    if (a.d_x == 1) *reinterpret_cast<f32x4*>(d) = acc;
+    else
+        for (int e = 0; e < 4; ++e) d[e * a.d_x] = acc[e];
+}
+
 }  // namespace fpc
 
 using namespace fpc;
@@ -158,7 +354,19 @@ extern "C" int fpc_upsample_bilinear_fwd(const float* in, int64_t sb, int64_t sc
     a.order_nhwc = out_nhwc ? 1 : 0;
     dim3 g;
     if (!up_grid(a, a.W, a.H, g)) return FPC_EINVAL;
-    hipLaunchKernelGGL(k_up_bilinear_fwd, g, dim3(256), 0, (hipStream_t)stream, a);
+    const bool al16 = (((uintptr_t)in | (uintptr_t)out) & 15) == 0;
+    if (out_nhwc && C % 4 == 0 && sc == 1 && al16 && !((sb | sh | sw) & 3)) {
+        hipLaunchKernelGGL(k_up_fwd_nhwc4, dim3((unsigned)(((long long)a.W * (C / 4) + 255) / 256), (unsigned)a.H, (unsigned)B), dim3(256), 0,
+                           (hipStream_t)stream, a);
+    } else if (!out_nhwc && sc == 1 && sw == C && C <= 32 && (a.H + 3) / 4 <= 65535 && B <= 65535) {
+        hipLaunchKernelGGL(k_up_fwd_nhwc_to_nchw, dim3((unsigned)((a.W + 63) / 64), (unsigned)((a.H + 3) / 4), (unsigned)B), dim3(256),
+                           sizeof(float) * kUpPatchH * kUpPatchW * C, (hipStream_t)stream, a);
+    } else if (!out_nhwc && a.W % 4 == 0 && al16 && (a.H + 3) / 4 <= 65535) {
+        hipLaunchKernelGGL(k_up_fwd_nchw4, dim3((unsigned)((a.W / 4 + 63) / 64), (unsigned)((a.H + 3) / 4), g.z), dim3(64, 4), 0,
+                           (hipStream_t)stream, a);
+    } else {
+        hipLaunchKernelGGL(k_up_bilinear_fwd, g, dim3(256), 0, (hipStream_t)stream, a);
+    }
     return check_launch();
 }
 
@@ -184,7 +392,17 @@ extern "C" int fpc_upsample_bilinear_bwd(const float* dout, int64_t sb, int64_t 
     const float ry = H > 1 ? (float)(h - 1) / (float)(H - 1) : 0.f;
     dim3 g;
     if (!up_grid(a1, w, H, g)) return FPC_EINVAL;
-    hipLaunchKernelGGL(k_up_bilinear_bwd_1d<0>, g, dim3(256), 0, (hipStream_t)stream, a1, w, w * scale, rx);
+    const bool al16 = (((uintptr_t)dout | (uintptr_t)din | (uintptr_t)scratch) & 15) == 0;
+    const bool vec_c = order && C % 4 == 0 && al16 && !((sb | sh | sw) & 3);           // channel-last, four channels per thread
+    const bool vec_x = !order && sw == 1 && al16 && w % 4 == 0 && !((sb | sc | sh) & 3) && (H + 15) / 16 <= 65535;   // x fastest
+    if (vec_c)
+        hipLaunchKernelGGL(k_up_bwd_1d_nhwc4<0>, dim3((unsigned)(((long long)w * (C / 4) + 255) / 256), (unsigned)H, (unsigned)B), dim3(256), 0,
+                           (hipStream_t)stream, a1, w, w * scale, rx);
+    else if (vec_x)
+        hipLaunchKernelGGL(k_up_bwd_x_nchw, dim3((unsigned)((w + 63) / 64), (unsigned)((H + 15) / 16), g.z), dim3(64, 4), 0, (hipStream_t)stream,
+                           a1, w, w * scale, rx);
+    else
+        hipLaunchKernelGGL(k_up_bilinear_bwd_1d<0>, g, dim3(256), 0, (hipStream_t)stream, a1, w, w * scale, rx);
     rc = check_launch();
     if (rc) return rc;
     // pass 2 (y axis): tmp -> din [B, C, h, w]
@@ -195,6 +413,13 @@ extern "C" int fpc_upsample_bilinear_bwd(const float* dout, int64_t sb, int64_t 
     if (rc) return rc;
     a2.h = h; a2.w = w; a2.order_nhwc = order;
     if (!up_grid(a2, w, h, g)) return FPC_EINVAL;
-    hipLaunchKernelGGL(k_up_bilinear_bwd_1d<1>, g, dim3(256), 0, (hipStream_t)stream, a2, h, H, ry);
+    if (vec_c && din_nhwc)
+        hipLaunchKernelGGL(k_up_bwd_1d_nhwc4<1>, dim3((unsigned)(((long long)w * (C / 4) + 255) / 256), (unsigned)h, (unsigned)B), dim3(256), 0,
+                           (hipStream_t)stream, a2, h, H, ry);
+    else if (vec_x)
+        hipLaunchKernelGGL(k_up_bwd_y_nchw4, dim3((unsigned)((w / 4 + 63) / 64), (unsigned)((h + 3) / 4), g.z), dim3(64, 4), 0, (hipStream_t)stream,
+                           a2, h, H, ry);
+    else
+        hipLaunchKernelGGL(k_up_bilinear_bwd_1d<1>, g, dim3(256), 0, (hipStream_t)stream, a2, h, H, ry);
     return check_launch();
 }

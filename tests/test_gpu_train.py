@@ -487,7 +487,8 @@ def test_training_mode_model_uses_native_convolutions_and_matches_torch_path():
 
 
 @pytest.mark.parametrize("case", [(2, 128, 15, 20, 2, "nhwc"), (2, 7, 30, 40, 4, "nhwc->nchw"), (1, 24, 12, 16, 4, "nchw"),
-                                  (3, 5, 3, 4, 2, "nchw"), (1, 6, 1, 9, 4, "nhwc->nchw"), (2, 128, 2, 3, 2, "nhwc")],
+                                  (3, 5, 3, 4, 2, "nchw"), (1, 6, 1, 9, 4, "nhwc->nchw"), (2, 128, 2, 3, 2, "nhwc"), (2, 6, 5, 7, 2, "nchw"), (1, 12, 30, 40, 4, "nhwc"),
+                                  (2, 3, 17, 24, 4, "nchw")],
                          ids=lambda c: "x".join(str(v) for v in c))
 def test_native_bilinear_upsample_forward_and_adjoint_vs_torch(case):
     from fastposecnn_amd.lib import train_conv
