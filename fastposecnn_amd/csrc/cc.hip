@@ -7,12 +7,11 @@
 //   k_cc_tile     64 x 16 pixel tiles: row runs (ballot + clz) and the tile's vertical unions in LDS; every pixel
 //                 points at the global index of its tile-local root
 //   k_cc_border   unions across tile borders, only where a run start / run break makes one necessary
-//   k_cc_flatten  root of every pixel; root census per 1024-pixel block
-//   k_cc_scan     exclusive scan of the block census (one block) -> N  (only beyond 1024 blocks: k_cc_rank sums a short
+//   k_cc_flatten  root of every pixel; per 64-pixel segment which pixels are roots (bit word) and how many roots its
+//                 1024-pixel block holds before it; root census per block
+//   k_cc_scan     exclusive scan of the block census (one block) -> N  (only beyond 1024 blocks: k_cc_label scans a short
 //                 census itself)
-//   k_cc_rank     roots in raster order get labels 1..N (scipy's numbering, continuing
-//                 across the batch)
-//   k_cc_relabel  labels[p] = rank of root(p)
+//   k_cc_label    labels[p] = 1 + roots before root(p) in raster order (scipy's numbering, continuing across the batch)
 // The root of a component is its minimum linear index, i.e. its first pixel in raster
 // order, so ranking the roots by index reproduces scipy.ndimage.label's order exactly.
 // (Round 3 tried flatten + scan + rank as ONE launch — blocks in ticket order, decoupled look-back over 64 predecessors per
@@ -167,11 +166,11 @@ __global__ __launch_bounds__(256) void k_cc_border(int B, int H, int W, int32_t*
 // parent is a lower lane of its own wave — every non-start pixel of a run, k_cc_init — takes that
 // lane's root by shuffle.  This removes ~60x of the finds and all of their atomic contention.
 __global__ __launch_bounds__(256) void k_cc_flatten(long long total, int32_t* __restrict__ L,
-                                                    int32_t* __restrict__ R, int32_t* __restrict__ blk_cnt) {
-    __shared__ int scratch[4];
+                                                    int32_t* __restrict__ R, int32_t* __restrict__ blk_cnt,
+                                                    unsigned long long* __restrict__ seg_bits, int32_t* __restrict__ seg_pre) {
+    __shared__ int s_seg[16];
     long long g0 = (long long)blockIdx.x * kCcBlock;
-    int lane = threadIdx.x & (kWave - 1);
-    int roots = 0;
+    int lane = threadIdx.x & (kWave - 1), w = threadIdx.x / kWave;
 #pragma unroll
     for (int it = 0; it < 4; ++it) {
         long long g = g0 + it * 256 + threadIdx.x;
@@ -191,13 +190,21 @@ __global__ __launch_bounds__(256) void k_cc_flatten(long long total, int32_t* __
             if (!__any(inseg && r < 0)) break;
         }
         if (fg && r < 0) r = cc_find(L, (int)g);
-        if (in) {
-            roots += (r == (int)g);
-            R[g] = r;
+        if (in) R[g] = r;
+        // the block's 16 segments of 64 pixels (raster order: segment it * 4 + w): which of them are roots
+        const unsigned long long m = __ballot(in && r == (int)g);
+        if (lane == 0) {
+            seg_bits[(size_t)blockIdx.x * 16 + it * 4 + w] = m;
+            s_seg[it * 4 + w] = __popcll(m);
         }
     }
-    int tot = block_sum_bcast(roots, scratch);
-    if (threadIdx.x == 0) blk_cnt[blockIdx.x] = tot;
+    __syncthreads();
+    if (threadIdx.x < 16) {                 // roots of the block before each segment; the block's census
+        int pre = 0;
+        for (int j = 0; j < (int)threadIdx.x; ++j) pre += s_seg[j];
+        seg_pre[(size_t)blockIdx.x * 16 + threadIdx.x] = pre;
+        if (threadIdx.x == 15) blk_cnt[blockIdx.x] = pre + s_seg[15];
+    }
 }
 
 __global__ __launch_bounds__(1024) void k_cc_scan(int nb, const int32_t* __restrict__ blk_cnt,
@@ -224,69 +231,58 @@ __global__ __launch_bounds__(1024) void k_cc_scan(int nb, const int32_t* __restr
     if (threadIdx.x == 1023) *n_out = s_part[1023];
 }
 
-// Thread t of a block owns pixels g0 + it*256 + t; raster order inside the block is
-// (it, t), so the block-local exclusive scan runs over it-major order.
-// blk_off == nullptr (few blocks: one or a few frames): every block sums the census of the blocks before it itself and the
-// last block writes the component count — the scan launch (4.4 us of pure latency at 640 x 480) is not needed.
-__global__ __launch_bounds__(256) void k_cc_rank(long long total, const int32_t* __restrict__ R,
-                                                 const int32_t* __restrict__ blk_off, const int32_t* __restrict__ blk_cnt,
-                                                 int32_t* __restrict__ n_out, int32_t* __restrict__ rank,
-                                                 int32_t* __restrict__ root_pix, int cap) {
-    __shared__ int s_wave[4][4];
-    __shared__ int s_red[4];
-    long long g0 = (long long)blockIdx.x * kCcBlock;
-    int lane = threadIdx.x & (kWave - 1), w = threadIdx.x / kWave;
-    bool isr[4];
-    int pre[4];
+// labels[p] = 1 + number of roots before root(p) in raster order (scipy's numbering, continuing across the batch)
+//           = roots in the blocks before the root's + roots of its block before its segment + roots of its segment before it,
+// three small reads per pixel (block prefix, k_cc_flatten's segment prefix and segment bit word; the pixels of a component
+// share them).  blk_off == nullptr (few blocks: one or a few frames): every workgroup scans the block census itself in LDS
+// and the last one writes the component count — no scan launch.  The root pixels also record themselves in root_pix.
+// (Until round 3 this was two launches: ranks written at root positions, then gathered.)
+__global__ __launch_bounds__(256) void k_cc_label(long long total, int nb, const int32_t* __restrict__ R,
+                                                  const int32_t* __restrict__ blk_off, const int32_t* __restrict__ blk_cnt,
+                                                  const unsigned long long* __restrict__ seg_bits,
+                                                  const int32_t* __restrict__ seg_pre, int32_t* __restrict__ n_out,
+                                                  int32_t* __restrict__ labels, int32_t* __restrict__ root_pix, int cap) {
+    __shared__ int s_base[1025];
+    __shared__ int s_w[4];
+    if (!blk_off) {                          // exclusive scan of blk_cnt[0 .. nb), nb <= 1024: four entries per thread
+        const int lane = threadIdx.x & (kWave - 1), w = threadIdx.x / kWave;
+        int v[4], sum = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { const int i = threadIdx.x * 4 + k; v[k] = i < nb ? blk_cnt[i] : 0; sum += v[k]; }
+        int inc = sum;
+#pragma unroll
+        for (int o = 1; o < kWave; o <<= 1) { const int t = __shfl_up(inc, o, kWave); if (lane >= o) inc += t; }
+        if (lane == kWave - 1) s_w[w] = inc;
+        __syncthreads();
+        int run = inc - sum;
+        for (int k = 0; k < w; ++k) run += s_w[k];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { const int i = threadIdx.x * 4 + k; if (i <= nb) s_base[i] = run; run += v[k]; }
+        if (threadIdx.x == 255) s_base[1024] = run;      // nb == 1024: the total has no entry of its own above
+        __syncthreads();
+        if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) *n_out = s_base[nb];
+    }
+    const long long g0 = (long long)blockIdx.x * kCcBlock;
 #pragma unroll
     for (int it = 0; it < 4; ++it) {
-        long long g = g0 + it * 256 + threadIdx.x;
-        isr[it] = g < total && R[g] == (int)g;
-        unsigned long long m = __ballot(isr[it]);
-        pre[it] = __popcll(m & ((1ull << lane) - 1ull));
-        if (lane == 0) s_wave[it][w] = __popcll(m);
-    }
-    __syncthreads();
-    int base;
-    if (blk_off) {
-        base = blk_off[blockIdx.x];
-    } else {
-        int part = 0;
-        for (int i = threadIdx.x; i < (int)blockIdx.x; i += 256) part += blk_cnt[i];
-        base = block_sum_bcast(part, s_red);
-        if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) {
-            int mine = 0;
-            for (int j = 0; j < 16; ++j) mine += s_wave[j / 4][j % 4];
-            *n_out = base + mine;
-        }
-    }
-#pragma unroll
-    for (int it = 0; it < 4; ++it) {
-        int off = base;
-        for (int j = 0; j < it * 4 + w; ++j) off += s_wave[j / 4][j % 4];
-        if (isr[it]) {
-            long long g = g0 + it * 256 + threadIdx.x;
-            int label = off + pre[it] + 1;
-            rank[g] = label;
-            if (root_pix && label <= cap) root_pix[label - 1] = (int)g;
-        }
-    }
-}
-
-__global__ __launch_bounds__(256) void k_cc_relabel(long long total, const int32_t* __restrict__ R,
-                                                    const int32_t* __restrict__ rank, int32_t* __restrict__ labels) {
-    long long g0 = (long long)blockIdx.x * kCcBlock;
-#pragma unroll
-    for (int it = 0; it < 4; ++it) {
-        long long g = g0 + it * 256 + threadIdx.x;
+        const long long g = g0 + it * 256 + threadIdx.x;
         if (g >= total) continue;
-        int r = R[g];
-        labels[g] = r >= 0 ? rank[r] : 0;
+        const int r = R[g];
+        int label = 0;
+        if (r >= 0) {
+            const int rb = r >> 10, rs = (r >> 6) & 15, rl = r & 63;
+            const int base = blk_off ? blk_off[rb] : s_base[rb];
+            const unsigned long long m = seg_bits[(size_t)rb * 16 + rs];
+            label = base + seg_pre[(size_t)rb * 16 + rs] + __popcll(m & ((1ull << rl) - 1ull)) + 1;
+            if (r == (int)g && root_pix && label <= cap) root_pix[label - 1] = (int)g;
+        }
+        labels[g] = label;
     }
 }
 
 struct CcWs {
-    int32_t *L, *R, *blk_cnt, *blk_off;
+    int32_t *L, *R, *blk_cnt, *blk_off, *seg_pre;
+    unsigned long long* seg_bits;
     size_t total;
 };
 
@@ -300,6 +296,8 @@ static CcWs cc_carve(void* base, int B, int H, int W) {
     w.R = (int32_t*)(p + off); off = align_up(off + sizeof(int32_t) * tot, 256);
     w.blk_cnt = (int32_t*)(p + off); off = align_up(off + sizeof(int32_t) * (size_t)nb, 256);
     w.blk_off = (int32_t*)(p + off); off = align_up(off + sizeof(int32_t) * (size_t)nb, 256);
+    w.seg_bits = (unsigned long long*)(p + off); off = align_up(off + sizeof(unsigned long long) * (size_t)nb * 16, 256);
+    w.seg_pre = (int32_t*)(p + off); off = align_up(off + sizeof(int32_t) * (size_t)nb * 16, 256);
     w.total = off;
     return w;
 }
@@ -334,12 +332,10 @@ extern "C" int fpc_cc_label(const int64_t* cat_mask, int B, int H, int W, int32_
     const long long nborder = (long long)B * (((H - 1) / kTileH) * (long long)W + ((W - 1) / kTileW) * (long long)H);
     if (nborder > 0)
         hipLaunchKernelGGL(k_cc_border, dim3((unsigned)((nborder + 255) / 256)), dim3(256), 0, s, B, H, W, w.L);
-    hipLaunchKernelGGL(k_cc_flatten, dim3(nb), dim3(256), 0, s, total, w.L, w.R, w.blk_cnt);
-    const bool fold_scan = nb <= 1024;          // each block then reads <= 4 KB of census itself
+    hipLaunchKernelGGL(k_cc_flatten, dim3(nb), dim3(256), 0, s, total, w.L, w.R, w.blk_cnt, w.seg_bits, w.seg_pre);
+    const bool fold_scan = nb <= 1024;          // each workgroup then scans <= 4 KB of census itself
     if (!fold_scan) hipLaunchKernelGGL(k_cc_scan, dim3(1), dim3(1024), 0, s, nb, w.blk_cnt, w.blk_off, n_out);
-    // rank is written only at root positions; L is dead after k_cc_flatten and is reused for it
-    hipLaunchKernelGGL(k_cc_rank, dim3(nb), dim3(256), 0, s, total, w.R, fold_scan ? nullptr : w.blk_off, w.blk_cnt, n_out, w.L,
-                       root_pix, cap);
-    hipLaunchKernelGGL(k_cc_relabel, dim3(nb), dim3(256), 0, s, total, w.R, w.L, labels);
+    hipLaunchKernelGGL(k_cc_label, dim3(nb), dim3(256), 0, s, total, nb, w.R, fold_scan ? nullptr : w.blk_off, w.blk_cnt, w.seg_bits,
+                       w.seg_pre, n_out, labels, root_pix, cap);
     return check_launch();
 }
