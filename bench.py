@@ -82,6 +82,7 @@ def parse(argv=None):
     ap.add_argument("--vote-only", action="store_true", help="time only the post-network stages (profiling aid)")
     ap.add_argument("--tune-mode", type=int, default=0, help="conv autotune objective: 0 latency, 1 latency x sqrt(chip share)")
     ap.add_argument("--net-streams", type=int, default=4, help="frame streams: native plans on their own HIP streams that take consecutive frames")
+    ap.add_argument("--frames-in-flight", type=int, default=0, help="frames submitted before the oldest is collected (0 = frame streams + 1)")
     ap.add_argument("--post-stream", action="store_true", help="run the post-network stages of all frames on one extra stream instead of the frame's own")
     ap.add_argument("--no-pipeline", action="store_true", help="finish every frame before starting the next (latency mode)")
     ap.add_argument("--train", action="store_true", help="BASELINE.json configs[4]: train step (fwd + losses + bwd + gradient reduction + optimiser)")
@@ -308,7 +309,7 @@ def run_inference(args, encoder, Bq, hn, steps, warmup, world, rank, dev, want_b
     streamer = FrameStreamer(model_gpu, net_streams=1 if args.no_pipeline else args.net_streams,
                              post_inline=not args.post_stream)
     s_net = streamer.net_streams[0]
-    depth = 0 if args.no_pipeline else len(streamer.models)
+    depth = 0 if args.no_pipeline else (args.frames_in_flight - 1 if args.frames_in_flight > 0 else len(streamer.models))
     pending = []
     # pose records of `gather_every` frames per RCCL all-gather, issued on a side stream: no frame waits for it
     gatherer = parallel.PoseGatherer(cap, every=args.gather_every or max(1, depth + 1), device=dev) if world > 1 else None
