@@ -229,12 +229,18 @@ def test_class_compress_fullsize_properties(lib, dev):
 
 # ----------------------------------------------------------------------------- connected components
 
-@pytest.mark.parametrize("shape,p", [((3, 37, 53), 0.55), ((2, 64, 64), 0.6), ((1, 480, 640), 0.58), ((4, 40, 56), 0.3)])
+# (40, 240, 320): 3000 blocks of 1024 pixels — the separate census scan (beyond 1024 blocks) with many tiny components;
+# (1, 1024, 1024) = exactly 1024 blocks (the in-kernel scan's last entry); (5, 33, 31): 1023 pixels per image, blocks
+# straddle images and the last block is partial; (2, 16, 2048): segments of 64 pixels inside one long row
+@pytest.mark.parametrize("shape,p", [((3, 37, 53), 0.55), ((2, 64, 64), 0.6), ((1, 480, 640), 0.58), ((4, 40, 56), 0.3),
+                                     ((40, 240, 320), 0.45), ((1, 1024, 1024), 0.5), ((5, 33, 31), 0.5), ((2, 16, 2048), 0.62),
+                                     ((1, 1, 1), 1.0), ((7, 3, 5), 0.0)])
 def test_cc_label_matches_oracle(lib, oracle, dev, shape, p):
     import aggregation_layer as al
     rng = np.random.default_rng(shape[1])
     fg = rng.random(shape) < p
-    fg[0, :, 0] = True; fg[-1, -1, :] = True                   # long vertical / horizontal runs
+    if p > 0.0:
+        fg[0, :, 0] = True; fg[-1, -1, :] = True               # long vertical / horizontal runs
     layer = al.AggregationLayer(None, 7)
     labels, N = layer.batchwise_break_segmentation_mask(T(fg, dev))
     want, M = oracle.cc_label(fg)
