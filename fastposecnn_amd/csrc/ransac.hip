@@ -776,7 +776,10 @@ extern "C" int fpc_ransac_voting_v3_bits(const float* mask, const uint64_t* mask
     const bool vec4 = (HW % 4 == 0) && (((uintptr_t)mask & 15) == 0);
     const bool vg4 = (HW % 4 == 0) && W % 4 == 0 && vs_w == 1 && vs_h % 4 == 0 && vs_n % 4 == 0 && vs_c % 4 == 0 &&
                      (((uintptr_t)vertex & 15) == 0);
-    const int scan_grid = (int)std::min<long long>((long long)n * p.nch, 256 * 4);       // resident: the loop prefetches
+#ifndef FPC_SCAN_WGS             // (diagnostic builds sweep it: tools_dev/scan_sweep.sh)
+#define FPC_SCAN_WGS (256 * 8)   // 32 frames, hn = 128: 768: 153.4 us, 1024: 147.9, 1536: 156.4, 2048: 146.9 per vote (f32 masks)
+#endif
+    const int scan_grid = (int)std::min<long long>((long long)n * p.nch, FPC_SCAN_WGS);       // resident: the loop prefetches
     const ScanParams sp{mask, mask_bits, vertex, vs_n, vs_h, vs_w, vs_c, n, n_dev, W, HW, p.nch, p.ls, p.ctrl, p.chunk_fg, p.chunk_box, p.list, p.stamps};
 #define FPC_LAUNCH_SCAN(A, B) hipLaunchKernelGGL((k_vote_scan<A, B>), dim3(scan_grid), dim3(256), 0, s, sp)
     if (mask_bits) {      // the foreground as bit words: the f32 planes are not read
