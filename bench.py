@@ -41,8 +41,10 @@ Extra objects on the JSON line:
   train             BASELINE.json configs[4] at batch 8 on this GPU (fastposecnn_amd/train_bench.py; 1-GPU runs)
   cpu_baseline      the same step on the host: torch-CPU backbone + the C oracle's post-network path (1 thread and the
                     job's CPU share), three samples each
-`value` is the MEDIAN of the repeated K-step timed regions (`repeats`, `ms_per_step_min_max`); `scaling_measured` is false:
-no N > 1 run has been measured by this repository.
+`value` is the MEDIAN of the repeated K-step timed regions (`repeats`, `ms_per_step_min_max`).  `scaling_measured` is true
+exactly when this line comes from an N > 1 run; such a line also carries `per_rank_img_per_s`, `rccl_ranks_seen` (what an
+all-reduce of ones over the job's backend summed to), `collective_backend`, `cores_per_rank` (each rank pins itself to its
+own share of the host cores before touching the GPU) and `config.pose_gather.us_per_collective`.
 """
 import argparse
 import json
@@ -79,6 +81,7 @@ def parse(argv=None):
     ap.add_argument("--no-train-line", action="store_true", help="skip the `train` object (configs[4] at B=8 on this GPU, 1-GPU runs only)")
     ap.add_argument("--min-seconds", type=float, default=0.5, help="the K-step timed region is repeated until this much time is covered; `value` is the median repeat")
     ap.add_argument("--gather-every", type=int, default=0, help="frames per pose all-gather on the side stream (0 = frames in flight)")
+    ap.add_argument("--check-gather", action="store_true", help="N > 1: verify the gathered pose records against every rank's records rebuilt locally")
     ap.add_argument("--vote-only", action="store_true", help="time only the post-network stages (profiling aid)")
     ap.add_argument("--tune-mode", type=int, default=0, help="conv autotune objective: 0 latency, 1 latency x sqrt(chip share)")
     ap.add_argument("--net-streams", type=int, default=4, help="frame streams: native plans on their own HIP streams that take consecutive frames")
@@ -114,6 +117,41 @@ def launch_ranks(n, argv):
     for p in procs:
         rc = max(rc, p.wait())
     return rc
+
+
+def pin_rank_to_cores(local_rank, local_world):
+    """Give this rank its own contiguous share of the host cores (before anything touches the GPU; no re-exec).  Eight
+    ranks x one enqueue thread at ~80 launches per frame plus their PNG / staging helpers otherwise migrate over all cores
+    and onto each other.  FPC_BENCH_NO_AFFINITY=1 leaves the launcher's mask alone.  Returns the cores kept (or None)."""
+    if local_world <= 1 or os.environ.get("FPC_BENCH_NO_AFFINITY") or not hasattr(os, "sched_setaffinity"):
+        return None
+    try:
+        cores = sorted(os.sched_getaffinity(0))
+        per = len(cores) // local_world
+        if per < 1:
+            return None
+        mine = cores[local_rank * per:(local_rank + 1) * per]
+        os.sched_setaffinity(0, mine)
+        os.environ.setdefault("OMP_NUM_THREADS", str(max(1, min(per, 16))))
+        return mine
+    except OSError:
+        return None
+
+
+def multi_rank_fields(dist, torch, world, rank, dev, local_s, units_per_rank, backend, cores):
+    """What makes an N > 1 line self-describing: every rank's own rate, how many ranks the backend's all-reduce really
+    summed over, the backend, the cores each rank was pinned to.  All ranks call this (collectives inside)."""
+    t = torch.tensor([float(local_s)], dtype=torch.float64, device=dev)
+    every = [torch.zeros_like(t) for _ in range(world)]
+    dist.all_gather(every, t)
+    one = torch.ones(1, dtype=torch.float32, device=dev)
+    dist.all_reduce(one)
+    ncores = torch.tensor([float(len(cores) if cores else 0)], dtype=torch.float32, device=dev)
+    dist.all_reduce(ncores, op=dist.ReduceOp.MIN)
+    return {"scaling_measured": True,
+            "per_rank_img_per_s": [round(units_per_rank / max(float(x.item()), 1e-9), 2) for x in every],
+            "rccl_ranks_seen": int(round(float(one.item()))), "collective_backend": backend,
+            "cores_per_rank": int(ncores.item()) or None}
 
 
 # --------------------------------------------------------------------------------------------------- pieces
@@ -263,6 +301,28 @@ def post_network_rates(model_gpu, cat1, n1, cat32, n32, reps=15, calls=6):
     return out
 
 
+def encode_png_rgb_paeth(img):
+    """8-bit RGB PNG with every row Paeth-filtered (type 4: the decoder's most expensive un-filter), written with zlib and
+    numpy only — fixture set-up for `img_per_s_from_png_files`, outside every timed region."""
+    import struct
+    import zlib
+    import numpy as np
+    h, w, _ = img.shape
+    x = img.astype(np.int16)
+    a = np.zeros_like(x); a[:, 1:] = x[:, :-1]                 # left
+    b = np.zeros_like(x); b[1:] = x[:-1]                       # up
+    c = np.zeros_like(x); c[1:, 1:] = x[:-1, :-1]              # up-left
+    pa, pb, pc = np.abs(b - c), np.abs(a - c), np.abs(a + b - 2 * c)
+    pred = np.where((pa <= pb) & (pa <= pc), a, np.where(pb <= pc, b, c))
+    rows = ((x - pred) & 0xFF).astype(np.uint8).reshape(h, w * 3)
+    raw = np.concatenate([np.full((h, 1), 4, np.uint8), rows], axis=1).tobytes()
+
+    def chunk(tag, data):
+        return struct.pack(">I", len(data)) + tag + data + struct.pack(">I", zlib.crc32(tag + data) & 0xFFFFFFFF)
+    return (b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, 8, 2, 0, 0, 0))
+            + chunk(b"IDAT", zlib.compress(raw, 6)) + chunk(b"IEND", b""))
+
+
 def measure_copy_ceiling(dev):
     import torch
     try:
@@ -277,6 +337,36 @@ def measure_copy_ceiling(dev):
         return round(10 * 2 * src.numel() / (c0.elapsed_time(c1) * 1e-3) / 1e9, 1)
     except Exception:
         return None
+
+
+def check_gather(model_gpu, gatherer, cat, Bq, world, rank, cap, dev):
+    """--check-gather: one more frame per rank through the post-network path and the gatherer; every rank then rebuilds
+    EVERY rank's records on its own (the fixtures are functions of the frame index) and compares them with what the
+    collective delivered: same records, rank order, sample ids offset by the shard's first image."""
+    import torch
+    import torch.distributed as dist
+    from fastposecnn_amd import synth, parallel
+    with torch.no_grad():
+        agg = model_gpu.post_network_finish(model_gpu.post_network_enqueue(cat, seed=777))
+    gatherer.add(agg, rank * Bq)
+    if gatherer.pending:
+        gatherer.flush()
+    got = gatherer.latest().clone()
+    slot = (gatherer.every if not gatherer.last_frames else gatherer.last_frames) - 1
+    ok = True
+    for r in range(world):
+        cat_r_cpu, _ = synth.make_vote_batch(range(r * Bq, r * Bq + Bq))
+        cat_r = {k: v.to(dev) for k, v in cat_r_cpu.items()}
+        with torch.no_grad():
+            agg_r = model_gpu.post_network_finish(model_gpu.post_network_enqueue(cat_r, seed=777))
+        want = parallel.pack_pose_records(agg_r, r * Bq, cap)
+        n = int(want[0, 0].view(torch.int32))
+        ok = ok and n > 0 and torch.equal(got[r, slot, :n + 1], want[:n + 1])
+        ids = got[r, slot, 1:n + 1, 0].contiguous().view(torch.int32)
+        ok = ok and bool(((ids >= r * Bq) & (ids < (r + 1) * Bq)).all())
+    flag = torch.tensor([1.0 if ok else 0.0], device=dev)
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    return bool(flag.item() > 0.5)
 
 
 def run_inference(args, encoder, Bq, hn, steps, warmup, world, rank, dev, want_backbone=True, split_precision=None):
@@ -335,8 +425,8 @@ def run_inference(args, encoder, Bq, hn, steps, warmup, world, rank, dev, want_b
     def drain():
         while pending:
             finish(pending.pop(0))
-        if gatherer is not None:
-            gatherer.flush()
+        if gatherer is not None and gatherer.pending:
+            gatherer.flush()         # every rank runs the same number of steps here: the same number of collectives
 
     def barrier():
         if world > 1:
@@ -360,6 +450,8 @@ def run_inference(args, encoder, Bq, hn, steps, warmup, world, rank, dev, want_b
         for _ in range(steps):
             step()
         drain()
+        torch.cuda.synchronize()
+        local.append(time.perf_counter() - t0)               # this rank's own time, before it waits for the others
         barrier()
         d = time.perf_counter() - t0
         if world > 1:
@@ -368,6 +460,7 @@ def run_inference(args, encoder, Bq, hn, steps, warmup, world, rank, dev, want_b
             d = float(t.item())
         return d
 
+    local = []
     dts = [timed_region()]
     repeats = 1
     if args.min_seconds > 0:
@@ -390,10 +483,26 @@ def run_inference(args, encoder, Bq, hn, steps, warmup, world, rank, dev, want_b
     torch.cuda.synchronize()
     latency_ms = (time.perf_counter() - t1) / nlat * 1e3
 
+    pose_gather = None
+    if gatherer is not None:
+        # one collective, issue -> complete, serial (nothing else in flight): the cost the side stream hides per round
+        ncol = gatherer.collectives
+        barrier()
+        t_c = time.perf_counter()
+        for _ in range(20):
+            gatherer.flush()
+            gatherer.latest()
+        us_col = (time.perf_counter() - t_c) / 20 * 1e6
+        pose_gather = {"frames_per_collective": gatherer.every, "collectives": ncol, "stream": "side", "record_bytes": 160,
+                       "capacity_per_frame": cap, "bytes_per_rank_per_collective": gatherer.every * (cap + 1) * 160,
+                       "us_per_collective": round(us_col, 1),
+                       "us_per_collective_note": "20 serial empty rounds after the timed region, issue -> host-visible completion; "
+                                                 "warmed by the warm-up steps' collectives; inside the timed region it runs on a side stream"}
+        if args.check_gather:
+            pose_gather["verified"] = check_gather(model_gpu, gatherer, cat, Bq, world, rank, cap, dev)
     res = {"value": round(world * Bq * steps / dt, 3), "ms_per_step": round(dt / steps * 1e3, 4), "steps": steps, "warmup": warmup,
            "repeats": repeats, "ms_per_step_min_max": [round(min(dts) / steps * 1e3, 4), round(max(dts) / steps * 1e3, 4)],
-           "pose_gather": None if gatherer is None else {"frames_per_collective": gatherer.every, "collectives": gatherer.collectives,
-                                                         "stream": "side", "record_bytes": 160, "capacity_per_frame": cap},
+           "local_s": median(local), "pose_gather": pose_gather,
            "workload": f"{encoder}-FPN + all heads, batch={Bq} 640x480 per GPU per step, {1 + depth} frames in flight on "
                        f"{len(streamer.models)} streams, hn={hn}, {n_inst} instances per step (vote-bench fixture), random-init weights",
            "global_batch": world * Bq, "frames_in_flight": 1 + depth, "net_streams": len(streamer.models),
@@ -428,13 +537,12 @@ def run_inference(args, encoder, Bq, hn, steps, warmup, world, rank, dev, want_b
         # ... and from ENCODED frames: `*_color.png` files (in memory, as a loader's read-ahead would hold them) -> native PNG
         # decode on a few host threads straight into the pinned staging slot -> the same path (F/tools/dataset.py:158 on
         # our side of the boundary).  Synthetic 640x480 RGB frames with smooth + noisy content (~600 KB each as PNG).
-        from oracle import png_oracle                      # fixture set-up only: the encoder that writes the test frames
         yy, xx = np.mgrid[0:480, 0:640]
         pngs = []
         for i in range(4):
             img = np.stack([(128 + 100 * np.sin(xx / (23.0 + i)) * np.cos(yy / 31.0)), (xx * 255 / 639 + 20 * i) % 256, (yy * 255 / 479)], -1)
             img = (img + np.random.default_rng(i).integers(0, 24, (480, 640, 3))).clip(0, 255).astype(np.uint8)
-            pngs.append(png_oracle.encode(img, filters=[4] * 480))
+            pngs.append(encode_png_rgb_paeth(img))
         from fastposecnn_amd.tools.dataset import PngFramePrefetcher
         workers = max(1, min(14, (os.cpu_count() or 2) - 2))        # the job's CPU share is 16 on a GPU box
         npng = max(6, nh // 2) if Bq > 1 else max(40, nh)
@@ -527,31 +635,39 @@ def main():
         from fastposecnn_amd import train_bench
         return train_bench.main(args)
 
-    import torch
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} does not match WORLD_SIZE {world}")
+    # this rank's share of the host cores, before torch starts its thread pools and before anything touches the GPU
+    cores = pin_rank_to_cores(local_rank, int(os.environ.get("LOCAL_WORLD_SIZE", str(world))))
+    import torch
+    if cores:
+        torch.set_num_threads(max(1, min(len(cores), 16)))
     if os.environ.get("FPC_BENCH_DRYRUN"):
         # launch-path check without a GPU (tests/test_host_logic.py): rendezvous over gloo, one collective, rank 0 reports
         import torch.distributed as dist
+        extra = {"scaling_measured": False}
         if world > 1:
             dist.init_process_group("gloo")
             t = torch.tensor([float(rank + 1)])
             dist.all_reduce(t)
             dist.barrier()
             total = float(t.item())
+            # the same self-description the real N > 1 line carries (here over gloo, with made-up per-rank times)
+            extra = multi_rank_fields(dist, torch, world, rank, torch.device("cpu"), 0.5 * (rank + 1), 100.0, "gloo", cores)
             dist.destroy_process_group()
         else:
             total = 1.0
         if rank == 0:
             print(json.dumps({"dryrun": True, "n_gpus": world, "rank_sum": total, "local_rank": local_rank,
-                              "master": os.environ.get("MASTER_ADDR")}), flush=True)
+                              "master": os.environ.get("MASTER_ADDR"), **extra}), flush=True)
         return
     dev = torch.device("cuda", local_rank % max(1, torch.cuda.device_count()))    # (several ranks on one GPU only in tests)
     torch.cuda.set_device(dev)
     import torch.distributed as dist
+    backend = None
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         backend = os.environ.get("FPC_BENCH_BACKEND", "nccl")        # "gloo": lets two ranks share one GPU in a smoke test
@@ -561,6 +677,8 @@ def main():
     _native.lib()      # fail loudly if the HIP library is missing
 
     res, ctx = run_inference(args, args.encoder, args.batch, args.hn, args.steps, args.warmup, world, rank, dev)
+    multi = (multi_rank_fields(dist, torch, world, rank, dev, res["local_s"], args.batch * args.steps, backend, cores)
+             if world > 1 else {"scaling_measured": False})
 
     line = None
     if rank == 0:
@@ -575,7 +693,7 @@ def main():
             "metric": "img/s end-to-end 640x480 inference; hough-vote kernel HBM GB/s vs roofline",
             "value": res["value"], "unit": "img/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": res["ms_per_step"], "higher_is_better": True,
-            "scaling": "weak", "scaling_measured": False, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "scaling": "weak", **multi, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "repeats": res["repeats"], "ms_per_step_min_max": res["ms_per_step_min_max"],
             "config": {"workload": res["workload"], "global_batch": res["global_batch"],
                        "parallelism": f"image-sharded dp{world}" if world > 1 else "single GPU",

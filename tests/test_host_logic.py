@@ -193,8 +193,8 @@ def _gatherer_worker(rank, world, port, q):
     G.flush()
     seen.append(G.latest().clone())
     rows = []
-    for block in seen:                                       # [world, frames, capacity + 1, 40]
-        for fr in range(block.shape[1]):
+    for block in seen:                                       # [world, every, capacity + 1, 40]; unfilled slots are empty
+        for fr in range(block.shape[1] if block is not seen[-1] else 2):
             u = parallel.unpack_pose_records(block[:, fr])
             rows.append((u["class_ids"].tolist(), u["sample_ids"].tolist(), round(float(u["RT"].sum()), 4)))
     q.put((rank, G.collectives, rows))
@@ -224,6 +224,69 @@ def test_pose_gatherer_batches_frames_gloo_world2():
         assert cls == a0["class_ids"].tolist() + a1["class_ids"].tolist()
         assert sid == a0["sample_ids"].tolist() + (a1["sample_ids"] + 2).tolist()
         assert abs(rt - float(a0["RT"].sum() + a1["RT"].sum())) < 1e-3
+
+
+def _uneven_worker(rank, world, port, q):
+    import torch.distributed as dist
+    sys.path.insert(0, REPO)
+    from fastposecnn_amd import parallel
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    num_images, every = 7, 3                                  # shards of 4 and 3 frames: 1 full round + (1 | 0) pending
+    imgs = parallel.shard_indices(num_images, rank, world)
+    G = parallel.PoseGatherer(capacity=6, every=every)
+    rows = []
+    def take(block):
+        for fr in range(block.shape[1]):
+            u = parallel.unpack_pose_records(block[:, fr])
+            rows.append((u["class_ids"].tolist(), u["sample_ids"].tolist()))
+    for k, img in enumerate(imgs):
+        before = G.collectives
+        G.add(_gather_agg(1 + img % 3, 100 + img, 1), sample_offset=img)
+        if G.collectives != before:
+            take(G.latest().clone())
+    G.finish(parallel.PoseGatherer.rounds_for(num_images, world, every), device="cpu")
+    take(G.latest().clone())
+    q.put((rank, G.collectives, rows))
+    dist.destroy_process_group()
+
+
+def test_pose_gatherer_uneven_shards_stay_in_lockstep_gloo_world2():
+    """ranks with different frame counts must issue the same number of collectives (7 images on 2 ranks,
+    3 frames per collective: 4 / 3 frames -> rank 1 has nothing pending at the end and still takes part in round 2)."""
+    import torch.multiprocessing as mp
+    from fastposecnn_amd import parallel
+    assert parallel.PoseGatherer.rounds_for(17, 4, 4) == 2 and parallel.PoseGatherer.rounds_for(7, 2, 3) == 2
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_uneven_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert res[0][1] == res[1][1] == 2 and res[0][2] == res[1][2]
+    # every image's records arrive exactly once, with its global sample id
+    want = sorted((_gather_agg(1 + img % 3, 100 + img, 1)["class_ids"].tolist(), img) for img in range(7))
+    got = []
+    shards = [list(parallel.shard_indices(7, r, 2)) for r in range(2)]
+    for slot, (cls, sid) in enumerate(res[0][2]):
+        rnd, fr = divmod(slot, 3)
+        pos = 0
+        for r in range(2):
+            k = rnd * 3 + fr
+            if k < len(shards[r]):
+                n = 1 + shards[r][k] % 3
+                assert sid[pos:pos + n] == [shards[r][k]] * n
+                got.append((cls[pos:pos + n], shards[r][k]))
+                pos += n
+        assert pos == len(cls)
+    assert sorted(got) == want
 
 
 def test_config1_cpu_mask_head_plumbing():
@@ -343,12 +406,19 @@ def test_bench_launches_its_own_ranks():
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, out.stdout                       # ONE line, from rank 0 only
     rec = json.loads(lines[0])
-    assert rec == {"dryrun": True, "n_gpus": 2, "rank_sum": 3.0, "local_rank": 0, "master": "127.0.0.1"}
+    base = {k: rec[k] for k in ("dryrun", "n_gpus", "rank_sum", "local_rank", "master")}
+    assert base == {"dryrun": True, "n_gpus": 2, "rank_sum": 3.0, "local_rank": 0, "master": "127.0.0.1"}
+    # an N > 1 line describes itself: measured, every rank's own rate, the ranks the backend's all-reduce summed over
+    assert rec["scaling_measured"] is True and rec["rccl_ranks_seen"] == 2 and rec["collective_backend"] == "gloo"
+    assert rec["per_rank_img_per_s"] == [200.0, 100.0]
+    ncpu = len(os.sched_getaffinity(0))
+    assert rec["cores_per_rank"] == (ncpu // 2 if ncpu >= 2 else None)
     # under an external launcher (WORLD_SIZE already set) the script is a rank, it does not spawn again
     env1 = dict(env, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1")
     out = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "1"], env=env1, capture_output=True,
                          text=True, timeout=300)
-    assert out.returncode == 0 and json.loads(out.stdout.strip().splitlines()[-1])["n_gpus"] == 1
+    one = json.loads(out.stdout.strip().splitlines()[-1])
+    assert out.returncode == 0 and one["n_gpus"] == 1 and one["scaling_measured"] is False
     # a mismatch between --gpus and the launcher's world size is refused
     out = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "4"], env=env1, capture_output=True,
                          text=True, timeout=300)
