@@ -14,6 +14,7 @@ ap.add_argument("--frames", type=int, default=1)
 ap.add_argument("--agg", action="store_true")
 ap.add_argument("--bits", action="store_true", help="pass the aggregation layer's mask bit words (the scan skips the f32 planes)")
 ap.add_argument("--sets", type=int, default=1, help="distinct copies of the inputs, used in rotation (cold reads, as in bench.py)")
+ap.add_argument("--fuse-min", type=int, default=0, help="fpc_vote_set_fuse_min_instances (0: library default)")
 a = ap.parse_args()
 dev = torch.device("cuda:0")
 cat_cpu, _ = synth.make_vote_batch(range(a.frames))
@@ -25,6 +26,7 @@ n, H, W = mask.shape
 vertex = xy.permute(0, 2, 3, 1)
 sn, sh, sw, sc = vertex.stride()
 lib = nat.lib()
+if a.fuse_min: lib.fpc_vote_set_fuse_min_instances(a.fuse_min)
 ws = torch.empty(lib.fpc_ransac_workspace_bytes(n, H, W, a.hn), dtype=torch.uint8, device=dev)
 out = torch.empty((n, 2), device=dev)
 st = torch.cuda.current_stream().cuda_stream
