@@ -32,7 +32,11 @@ _SIGNATURES = {
                                   _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "fpc_ransac_voting_v3_bits": (_i, [_vp, _vp, _vp, _i64, _i64, _i64, _i64, _i, _vp, _i, _i, _i, _vp, _vp, _u64, _f, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "fpc_class_compress": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "fpc_class_compress_bits": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "fpc_cc_workspace_bytes": (_sz, [_i, _i, _i]),
+    "fpc_cc_bits_supported": (_i, [_i, _i, _i]),
+    "fpc_fg_bits": (_i, [_vp, _i, _i, _i, _vp, _vp]),
+    "fpc_cc_label_bits": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _i, _vp, _sz, _vp]),
     "fpc_cc_label": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _i, _vp, _sz, _vp]),
     "fpc_aggregate_workspace_bytes": (_sz, [_i]),
     "fpc_aggregate": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz,
@@ -66,6 +70,7 @@ _SIGNATURES = {
     "fpc_net_workspace_bytes": (_sz, [_vp]),
     "fpc_net_load_params": (_i, [_vp, _vp, _i, _vp, _sz, _vp]),
     "fpc_net_forward": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "fpc_net_forward_bits": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "fpc_net_autotune_next": (_i, [_vp, _i]),
     "fpc_net_conv_count": (_i, [_vp]),
     "fpc_net_conv_plan": (_i, [_vp, _i, ctypes.POINTER(_i)]),

@@ -18,6 +18,8 @@
 // step: 43.4 us against 45.6 us for the six launches at B = 1, 225 us against 181 us at B = 32, where one ticket word
 // serves ~88 draws / us and batching the draws serialises the tree walks; not kept.  What was kept is the tile-local first
 // stage below: 60 -> 35 us at 640 x 480, 178 -> 119 us for 32 frames.)
+#include <algorithm>
+
 #include "common.hpp"
 
 namespace fpc {
@@ -280,6 +282,268 @@ __global__ __launch_bounds__(256) void k_cc_label(long long total, int nb, const
     }
 }
 
+// ---- whole-image labelling from foreground BIT WORDS (round 4) ------------------------------------------------------------
+// The foreground of a 640 x 480 frame is 38 KB as bit words (bit j of word w = pixel 64 w + j) — it fits the LDS of ONE
+// workgroup, and so does a union-find over its row RUNS (maximal sequences of foreground pixels of a row).  Two launches
+// instead of four or five, no per-pixel parent plane in global memory:
+//   k_cca_image   one 1024-thread workgroup per image: bit words -> LDS; run starts per word and their raster-order prefix
+//                 (a run's id = the number of run starts before it); unions of the runs of adjacent rows, one per maximal
+//                 sequence of columns in which both rows are foreground, in log2(H) levels of row pairs, block pairs, ...
+//                 (trees a few links deep instead of as deep as a blob is tall); roots ranked in id order =
+//                 raster order of each component's first pixel = scipy.ndimage.label's numbering; per run its image-local
+//                 label (+ a root flag), per word its id base, per image its component count -> global memory.
+//   k_cca_label   per pixel: word -> run id (id base + run starts up to the pixel) -> label + the components of the images
+//                 before it (summed here: no scan launch); root pixels record themselves in root_pix; the last block writes N.
+// (The band / border variant that preceded the levels is in the git history of this file.)
+// The parent array sits in LDS for up to `cap` runs (23 000 at 640 x 480: a segmentation mask has ~1 000) and in global
+// memory beyond (speckle noise: slower, same result; its accesses bypass the CU's vector cache, which would serve the
+// values it held before another wave's atomic).  Requires W % 64 == 0 (rows start on word boundaries) and bit words +
+// id bases within ~100 KB of LDS; every other shape keeps the tile pipeline above.
+#ifndef FPC_CCA_THREADS
+#define FPC_CCA_THREADS 1024
+#endif
+constexpr int kCcaThreads = FPC_CCA_THREADS;
+#ifdef FPC_STAMP_CC      // diagnostic build: phase times of image 0 into the (then unused) global parent area
+#define CCA_STAMP(k) do { if (blockIdx.x == 0 && threadIdx.x == 0) reinterpret_cast<unsigned long long*>(a.gparent)[k] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define CCA_STAMP(k) do { } while (0)
+#endif
+
+struct CcaArgs {
+    const unsigned long long* bits; size_t bstride;      // [B][bstride] words, bstride >= nwords
+    int B, H, W, wpr, nwords, cap;                        // wpr = W / 64 words per row, nwords = H * wpr; cap = LDS parent entries
+    unsigned wpr_inv;                                     // floor(2^32 / wpr) + 1: w / wpr = umulhi(w, wpr_inv) for w < 2^16 words
+    int32_t* wbase;        // [B][nwords]  run starts of the image before word w
+    int32_t* runlabel;     // [B][rstride] image-local label (1 ..) of run id, bit 31 = the run is its component's first
+    int32_t* gparent;      // [B][rstride] parent array of an image with more than cap runs
+    int32_t* ncomp;        // [B]
+    size_t rstride;
+};
+
+// w / wpr without a division (one workgroup labels an image: every instruction costs all of its waves)
+__device__ __forceinline__ int cca_div(int w, int wpr, unsigned inv) { return wpr == 1 ? w : (int)__umulhi((unsigned)w, inv); }
+
+struct LdsParent {
+    int* a;
+    __device__ __forceinline__ int ld(int i) const { return a[i]; }
+    __device__ __forceinline__ void st(int i, int v) const { a[i] = v; }
+    __device__ __forceinline__ int amin(int i, int v) const { return atomicMin(&a[i], v); }
+};
+struct GlobalParent {      // past the CU's vector cache: values other waves' atomics have changed must be seen
+    int32_t* a;
+    __device__ __forceinline__ int ld(int i) const { return __hip_atomic_load(a + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+    __device__ __forceinline__ void st(int i, int v) const { __hip_atomic_store(a + i, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+    __device__ __forceinline__ int amin(int i, int v) const { return atomicMin(&a[i], v); }
+};
+
+template <typename P>
+__device__ __forceinline__ int run_find(const P& p, int a) {       // with path halving; parents only ever decrease
+    while (true) {
+        const int pa = p.ld(a);
+        if (pa == a) return a;
+        const int gpa = p.ld(pa);
+        if (gpa == pa) return pa;
+        p.amin(a, gpa);
+        a = gpa;
+    }
+}
+template <typename P>
+__device__ __forceinline__ void run_unite(const P& p, int a, int b) {
+    while (true) {
+        a = run_find(p, a);
+        b = run_find(p, b);
+        if (a == b) return;
+        if (a < b) { const int t = a; a = b; b = t; }
+        const int old = p.amin(a, b);
+        if (old == a) return;
+        a = old;
+    }
+}
+
+// exclusive scan of one value per thread over the 1024-thread workgroup; returns the prefix, `total` = the sum
+__device__ __forceinline__ int cca_block_scan(int v, int* s_part /* 17 */, int& total) {
+    const int lane = threadIdx.x & (kWave - 1), w = threadIdx.x / kWave;
+    int inc = v;
+#pragma unroll
+    for (int o = 1; o < kWave; o <<= 1) { const int t = __shfl_up(inc, o, kWave); if (lane >= o) inc += t; }
+    __syncthreads();                                    // s_part of a previous scan has been read
+    if (lane == kWave - 1) s_part[w] = inc;
+    __syncthreads();
+    int off = 0, tot = 0;
+#pragma unroll
+    for (int k = 0; k < kCcaThreads / kWave; ++k) { const int x = s_part[k]; if (k < w) off += x; tot += x; }
+    total = tot;
+    return off + inc - v;
+}
+
+template <typename P>
+__device__ __forceinline__ void cca_body(const CcaArgs& a, const P par, const unsigned long long* sb, const int* wb, int R,
+                                         int* s_part) {
+    const int b = blockIdx.x, wpr = a.wpr;
+    for (int r = threadIdx.x; r < R; r += kCcaThreads) par.st(r, r);
+    __syncthreads();
+    CCA_STAMP(3);
+    // unions: word (y, k) against the word above it, one per maximal column sequence in which both rows are foreground.
+    // Level g = 1, 4, 16, ... takes the rows y = g q with q % 4 != 0: each joins finished blocks of g rows, three borders of a
+    // group of four at once, so a tree grows by at most three links per level and a find stays a handful of steps — with every row united at
+    // once a blob's runs formed a chain as long as the blob is tall, and the finds walking it were the kernel (5.6 + 4.4 us
+    // of 16.5 at 640 x 480 with 16-row bands and a border pass).  One workgroup: every instruction costs 16 waves, hence
+    // no division in the loops (umulhi by the reciprocal of the row's word count).
+    for (int g = 1; g < a.H; g *= 4) {                          // level: rows y = g q, q % 4 != 0 (radix 4: five levels at H = 480)
+        const int nq = (a.H - 1) / g;                             // q = 1 .. nq
+        const int nrows = nq - nq / 4;
+        for (int it = threadIdx.x; it < nrows * wpr; it += kCcaThreads) {
+            const int j = cca_div(it, wpr, a.wpr_inv), k = it - j * wpr;
+            const int j3 = (int)__umulhi((unsigned)j, 0xAAAAAAABu) >> 1;       // j / 3
+            const int w = g * (4 * j3 + (j - 3 * j3) + 1) * wpr + k;
+            const unsigned long long m = sb[w], up = sb[w - wpr];
+            const unsigned long long ov = m & up;
+            if (!ov) continue;
+            const unsigned long long ml = k ? sb[w - 1] : 0ull, ul = k ? sb[w - wpr - 1] : 0ull;
+            unsigned long long os = ov & ~((ov << 1) | ((ml & ul) >> 63));
+            if (!os) continue;
+            const unsigned long long st = m & ~((m << 1) | (ml >> 63)), su = up & ~((up << 1) | (ul >> 63));
+            const int bm = wb[w], bu = wb[w - wpr];
+            while (os) {
+                const int x = __ffsll((long long)os) - 1;
+                os &= os - 1ull;
+                const unsigned long long upto = (2ull << x) - 1ull;
+                run_unite(par, bm + __popcll(st & upto) - 1, bu + __popcll(su & upto) - 1);
+            }
+        }
+        __syncthreads();
+    }
+    CCA_STAMP(5);
+    // every run -> its root (no union is in flight any more: the value written is the root)
+    for (int r = threadIdx.x; r < R; r += kCcaThreads) par.st(r, run_find(par, r));
+    __syncthreads();
+    CCA_STAMP(6);
+    // roots ranked in id order; a root's entry becomes -(label), a run's label = -(entry of its root)
+    const int per = (R + kCcaThreads - 1) / kCcaThreads;
+    const int r_lo = min(R, (int)threadIdx.x * per), r_hi = min(R, r_lo + per);
+    int cnt = 0;
+    for (int r = r_lo; r < r_hi; ++r) cnt += par.ld(r) == r ? 1 : 0;
+    int total;
+    int rank = cca_block_scan(cnt, s_part, total);
+    __syncthreads();                                    // every root test above has been made
+    for (int r = r_lo; r < r_hi; ++r)
+        if (par.ld(r) == r) par.st(r, -(++rank));
+    __syncthreads();
+    CCA_STAMP(7);
+    int32_t* rl = a.runlabel + (size_t)b * a.rstride;
+    for (int r = threadIdx.x; r < R; r += kCcaThreads) {
+        const int v = par.ld(r);
+        rl[r] = v < 0 ? (-v) | (int)0x80000000 : -par.ld(v);
+    }
+    if (threadIdx.x == 0) a.ncomp[b] = total;
+    CCA_STAMP(8);
+}
+
+__global__ __launch_bounds__(kCcaThreads) void k_cca_image(const CcaArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned long long s_raw[];      // bits [nwords] | id bases [nwords] | parents [cap]
+    __shared__ int s_part[kCcaThreads / kWave + 1];
+    const int b = blockIdx.x, nwords = a.nwords, wpr = a.wpr;
+    unsigned long long* sb = s_raw;
+    int* wb = reinterpret_cast<int*>(sb + nwords);
+    int* pl = wb + nwords;
+    const unsigned long long* gb = a.bits + (size_t)b * a.bstride;
+    CCA_STAMP(0);
+    for (int w = threadIdx.x; w < nwords; w += kCcaThreads) sb[w] = gb[w];
+    __syncthreads();
+    CCA_STAMP(1);
+    // run starts of this thread's words (a contiguous range), their prefix over the image
+    const int per = (nwords + kCcaThreads - 1) / kCcaThreads;
+    const int w_lo = min(nwords, (int)threadIdx.x * per), w_hi = min(nwords, w_lo + per);
+    const int k_lo = w_lo - cca_div(w_lo, wpr, a.wpr_inv) * wpr;          // position of the first word in its row
+    int cnt = 0;
+    {
+        int k = k_lo;
+        for (int w = w_lo; w < w_hi; ++w) {
+            const unsigned long long m = sb[w], left = k ? sb[w - 1] >> 63 : 0ull;
+            cnt += __popcll(m & ~((m << 1) | left));
+            if (++k == wpr) k = 0;
+        }
+    }
+    int R;
+    int base = cca_block_scan(cnt, s_part, R);
+    int32_t* gw = a.wbase + (size_t)b * nwords;
+    {
+        int k = k_lo;
+        for (int w = w_lo; w < w_hi; ++w) {
+            const unsigned long long m = sb[w], left = k ? sb[w - 1] >> 63 : 0ull;
+            wb[w] = base; gw[w] = base;
+            base += __popcll(m & ~((m << 1) | left));
+            if (++k == wpr) k = 0;
+        }
+    }
+    __syncthreads();
+    CCA_STAMP(2);
+    if (R <= a.cap) cca_body(a, LdsParent{pl}, sb, wb, R, s_part);                // uniform
+    else cca_body(a, GlobalParent{a.gparent + (size_t)b * a.rstride}, sb, wb, R, s_part);
+}
+
+// grid (ceil(nwords / 64), B): 4096 pixels per workgroup, four consecutive pixels per thread and sweep
+__global__ __launch_bounds__(256) void k_cca_label(const CcaArgs a, int32_t* __restrict__ labels, int32_t* __restrict__ n_out,
+                                                   int32_t* __restrict__ root_pix, int cap_roots) {
+    __shared__ int s_sum[4];
+    const int b = blockIdx.y, nwords = a.nwords, wpr = a.wpr;
+    const int lane = threadIdx.x & (kWave - 1), wv = threadIdx.x / kWave;
+    // components of the images before this one
+    int part = 0;
+    for (int i = threadIdx.x; i < b; i += 256) part += a.ncomp[i];
+    part = wave_reduce_add(part);
+    if (lane == 0) s_sum[wv] = part;
+    __syncthreads();
+    const int off = s_sum[0] + s_sum[1] + s_sum[2] + s_sum[3];
+    if (b == a.B - 1 && blockIdx.x == 0 && threadIdx.x == 0) *n_out = off + a.ncomp[b];
+    const unsigned long long* gb = a.bits + (size_t)b * a.bstride;
+    const int32_t* gw = a.wbase + (size_t)b * nwords;
+    const int32_t* rl = a.runlabel + (size_t)b * a.rstride;
+    const size_t HW = (size_t)nwords * 64;
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        const int p0 = blockIdx.x * 4096 + it * 1024 + threadIdx.x * 4;
+        const int w = p0 >> 6;
+        if (w >= nwords) continue;
+        const unsigned long long m = gb[w];
+        int4 out = make_int4(0, 0, 0, 0);
+        const int x0 = p0 & 63;
+        if ((m >> x0) & 15ull) {
+            const unsigned long long left = (w - cca_div(w, wpr, a.wpr_inv) * wpr) ? gb[w - 1] >> 63 : 0ull;
+            const unsigned long long st = m & ~((m << 1) | left);
+            const int base = gw[w];
+            int lab[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                lab[j] = 0;
+                const int x = x0 + j;
+                if ((m >> x) & 1ull) {
+                    const int v = rl[base + __popcll(st & ((2ull << x) - 1ull)) - 1];
+                    lab[j] = off + (v & 0x7fffffff);
+                    if (v < 0 && ((st >> x) & 1ull) && root_pix && lab[j] <= cap_roots) root_pix[lab[j] - 1] = (int)((size_t)b * HW + p0 + j);
+                }
+            }
+            out = make_int4(lab[0], lab[1], lab[2], lab[3]);
+        }
+        *reinterpret_cast<int4*>(labels + (size_t)b * HW + p0) = out;
+    }
+}
+
+// foreground bit words of an i64 class mask (the drop-in entry's first step): one word per wave and sweep
+__global__ __launch_bounds__(256) void k_cc_fg_bits(const int64_t* __restrict__ cm, int B, long long HW, size_t bstride,
+                                                    unsigned long long* __restrict__ bits) {
+    const int lane = threadIdx.x & (kWave - 1);
+    const long long wpi = (long long)bstride;                    // words per image incl. padding
+    const long long total = (long long)B * wpi;
+    for (long long w = (long long)blockIdx.x * 4 + threadIdx.x / kWave; w < total; w += (long long)gridDim.x * 4) {
+        const long long b = w / wpi, wi = w - b * wpi;
+        const long long p = wi * 64 + lane;
+        const bool fg = p < HW && cm[b * HW + p] != 0;
+        const unsigned long long m = __ballot(fg);
+        if (lane == 0) bits[w] = m;
+    }
+}
+
 struct CcWs {
     int32_t *L, *R, *blk_cnt, *blk_off, *seg_pre;
     unsigned long long* seg_bits;
@@ -306,10 +570,93 @@ static CcWs cc_carve(void* base, int B, int H, int W) {
 
 using namespace fpc;
 
+// ---- host side of the bit-word path
+constexpr size_t kCcaLdsBytes = 152 * 1024;      // of the CU's 160 KB: one 1024-thread workgroup per CU
+
+static bool cca_eligible(int B, int H, int W) {
+    if (W % 64 != 0 || B > 65535) return false;
+    const long long nwords = (long long)H * (W / 64);
+    return nwords * 12 + 4096 <= (long long)kCcaLdsBytes - 32 * 1024;      // bit words + id bases, and at least 8 000 parents
+}
+
+struct CcaWs {
+    unsigned long long* bits;
+    int32_t *wbase, *runlabel, *gparent, *ncomp;
+    size_t bstride, rstride, total;
+};
+
+static CcaWs cca_carve(void* base, int B, int H, int W) {
+    CcaWs w;
+    const size_t HW = (size_t)H * W, nwords = HW / 64;
+    w.bstride = (size_t)cdiv((int)HW, 4096) * 64;              // fpc_mask_bits_words(H, W)
+    w.rstride = align_up(HW / 2 + 1, 64);
+    char* p = (char*)base;
+    size_t off = 0;
+    w.bits = (unsigned long long*)(p + off); off = align_up(off + sizeof(unsigned long long) * (size_t)B * w.bstride, 256);
+    w.wbase = (int32_t*)(p + off); off = align_up(off + sizeof(int32_t) * (size_t)B * nwords, 256);
+    w.runlabel = (int32_t*)(p + off); off = align_up(off + sizeof(int32_t) * (size_t)B * w.rstride, 256);
+    w.gparent = (int32_t*)(p + off); off = align_up(off + sizeof(int32_t) * (size_t)B * w.rstride, 256);
+    w.ncomp = (int32_t*)(p + off); off = align_up(off + sizeof(int32_t) * (size_t)B, 256);
+    w.total = off;
+    return w;
+}
+
+static int cca_run(const unsigned long long* bits, size_t bstride, int B, int H, int W, int32_t* labels, int32_t* n_out,
+                   int32_t* root_pix, int cap, const CcaWs& w, hipStream_t s) {
+    static bool attr_set = false;      // (idempotent; a race sets it twice)
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_cca_image), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kCcaLdsBytes);
+        if (e != hipSuccess) { set_hip_error(e); return FPC_ELAUNCH; }
+        attr_set = true;
+    }
+    CcaArgs a{};
+    a.bits = bits; a.bstride = bstride; a.B = B; a.H = H; a.W = W; a.wpr = W / 64; a.nwords = H * a.wpr;
+    a.wpr_inv = a.wpr > 1 ? (unsigned)((1ull << 32) / (unsigned)a.wpr + 1) : 0u;       // exact quotients below 2^16 (cca_eligible: nwords < 10 000); wpr = 1: see cca_div
+    a.wbase = w.wbase; a.runlabel = w.runlabel; a.gparent = w.gparent; a.ncomp = w.ncomp; a.rstride = w.rstride;
+    const size_t fixed = (size_t)a.nwords * 12;
+    a.cap = (int)std::min<size_t>((kCcaLdsBytes - 1024 - fixed) / 4, w.rstride);
+    const size_t lds = fixed + (size_t)a.cap * 4;
+    hipLaunchKernelGGL(k_cca_image, dim3(B), dim3(kCcaThreads), lds, s, a);
+    hipLaunchKernelGGL(k_cca_label, dim3(cdiv(a.nwords, 64), B), dim3(256), 0, s, a, labels, n_out, root_pix, cap);
+    return check_launch();
+}
+
 extern "C" size_t fpc_cc_workspace_bytes(int B, int H, int W) {
     if (B <= 0 || H < 1 || W < 1) return 256;
-    return cc_carve(nullptr, B, H, W).total;
+    const size_t tile = cc_carve(nullptr, B, H, W).total;
+    return cca_eligible(B, H, W) ? std::max(tile, cca_carve(nullptr, B, H, W).total) : tile;
 }
+
+extern "C" int fpc_fg_bits(const int64_t* cat_mask, int B, int H, int W, uint64_t* fg_bits, fpc_stream_t stream) {
+    if (B < 0 || H < 1 || W < 1) return FPC_EINVAL;
+    if (B == 0) return FPC_OK;
+    if (!cat_mask || !fg_bits || ((uintptr_t)fg_bits & 7)) return FPC_EINVAL;
+    const size_t bstride = (size_t)cdiv(H * W, 4096) * 64;
+    const long long words = (long long)B * bstride;
+    hipLaunchKernelGGL(k_cc_fg_bits, dim3((unsigned)std::min<long long>((words + 3) / 4, 4096)), dim3(256), 0, (hipStream_t)stream, cat_mask, B,
+                       (long long)H * W, bstride, reinterpret_cast<unsigned long long*>(fg_bits));
+    return check_launch();
+}
+
+extern "C" int fpc_cc_label_bits(const uint64_t* fg_bits, int B, int H, int W, int32_t* labels, int32_t* n_out,
+                                 int32_t* root_pix, int cap, void* ws, size_t ws_bytes, fpc_stream_t stream) {
+    if (B < 0 || H < 1 || W < 1 || !n_out) return FPC_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    if (B == 0) {
+        hipError_t e = hipMemsetAsync(n_out, 0, sizeof(int32_t), s);
+        if (e != hipSuccess) { set_hip_error(e); return FPC_ELAUNCH; }
+        return FPC_OK;
+    }
+    if ((long long)B * H * W >= (1ll << 31)) return FPC_EINVAL;
+    if (!fg_bits || !labels || !ws || ((uintptr_t)fg_bits & 7) || ((uintptr_t)labels & 15)) return FPC_EINVAL;
+    if (!cca_eligible(B, H, W)) return FPC_EINVAL;             // callers ask fpc_cc_bits_supported first
+    if (((uintptr_t)ws & 255) != 0) return FPC_EWORKSPACE;
+    CcaWs w = cca_carve(ws, B, H, W);
+    if (ws_bytes < w.total) return FPC_EWORKSPACE;
+    return cca_run(reinterpret_cast<const unsigned long long*>(fg_bits), w.bstride, B, H, W, labels, n_out, root_pix, cap, w, s);
+}
+
+extern "C" int fpc_cc_bits_supported(int B, int H, int W) { return (B >= 0 && H >= 1 && W >= 1 && cca_eligible(B, H, W)) ? 1 : 0; }
 
 extern "C" int fpc_cc_label(const int64_t* cat_mask, int B, int H, int W, int32_t* labels, int32_t* n_out,
                             int32_t* root_pix, int cap, void* ws, size_t ws_bytes, fpc_stream_t stream) {
@@ -324,6 +671,16 @@ extern "C" int fpc_cc_label(const int64_t* cat_mask, int B, int H, int W, int32_
     if (total >= (1ll << 31)) return FPC_EINVAL;  // linear indices are i32
     if (!cat_mask || !labels || !ws) return FPC_EINVAL;
     if (((uintptr_t)ws & 255) != 0) return FPC_EWORKSPACE;
+    if (cca_eligible(B, H, W) && ((uintptr_t)labels & 15) == 0) {
+        // rows on word boundaries and an image whose bit words fit one workgroup's LDS: i64 mask -> bit words, then the
+        // whole-image labelling (three launches; a caller that already holds the words calls fpc_cc_label_bits: two)
+        CcaWs cw = cca_carve(ws, B, H, W);
+        if (ws_bytes < cw.total) return FPC_EWORKSPACE;
+        const long long words = (long long)B * cw.bstride;
+        hipLaunchKernelGGL(k_cc_fg_bits, dim3((unsigned)std::min<long long>((words + 3) / 4, 4096)), dim3(256), 0, s, cat_mask, B, (long long)H * W,
+                           cw.bstride, cw.bits);
+        return cca_run(cw.bits, cw.bstride, B, H, W, labels, n_out, root_pix, cap, cw, s);
+    }
     CcWs w = cc_carve(ws, B, H, W);
     if (ws_bytes < w.total) return FPC_EWORKSPACE;
     int nb = (int)((total + kCcBlock - 1) / kCcBlock);

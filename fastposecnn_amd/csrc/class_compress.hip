@@ -16,7 +16,7 @@ __global__ __launch_bounds__(256) void k_class_compress(
     const float* __restrict__ ml, const float* __restrict__ quat, const float* __restrict__ scales,
     const float* __restrict__ xy, const float* __restrict__ z, const int64_t* __restrict__ cm_in, int C, int HW,
     int64_t* __restrict__ cat_mask, float* __restrict__ oq, float* __restrict__ os, float* __restrict__ oxy,
-    float* __restrict__ oz) {
+    float* __restrict__ oz, unsigned long long* __restrict__ fg_bits, size_t fg_stride) {
     int b = blockIdx.y;
     for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < HW; p += gridDim.x * blockDim.x) {
         int cls;
@@ -46,6 +46,10 @@ __global__ __launch_bounds__(256) void k_class_compress(
                 }
         }
         cat_mask[(size_t)b * HW + p] = cls;
+        if (fg_bits) {      // a wave's pixels are 64 consecutive ones starting on a word boundary; lanes past HW are not in the loop
+            const unsigned long long fgm = __ballot(cls != 0);
+            if ((threadIdx.x & 63) == 0) fg_bits[(size_t)b * fg_stride + (p >> 6)] = fgm;
+        }
         float q0 = 0, q1 = 0, q2 = 0, q3 = 0, s0 = 0, s1 = 0, s2 = 0, v0 = 0, v1 = 0, zz = 0;
         if (cls > 0) {
             int g = cls - 1, G = C - 1;
@@ -79,6 +83,16 @@ extern "C" int fpc_class_compress(const float* mask_logits, const float* quat, c
                                   const float* z, const int64_t* cat_mask_in, int B, int C, int HW,
                                   int64_t* cat_mask, float* oq, float* os, float* oxy, float* oz,
                                   fpc_stream_t stream) {
+    return fpc_class_compress_bits(mask_logits, quat, scales, xy, z, cat_mask_in, B, C, HW, cat_mask, oq, os, oxy, oz, nullptr, stream);
+}
+
+extern "C" int fpc_class_compress_bits(const float* mask_logits, const float* quat, const float* scales, const float* xy,
+                                       const float* z, const int64_t* cat_mask_in, int B, int C, int HW,
+                                       int64_t* cat_mask, float* oq, float* os, float* oxy, float* oz, uint64_t* fg_bits,
+                                       fpc_stream_t stream) {
+    if ((uintptr_t)fg_bits & 7) return FPC_EINVAL;
+    unsigned long long* fb = reinterpret_cast<unsigned long long*>(fg_bits);
+    const size_t fstride = (size_t)((HW + 4095) / 4096) * 64;
     if (B < 0 || C < 2 || C > 32 || HW < 1) return FPC_EINVAL;
     if (B == 0) return FPC_OK;
     if (B > 65535) return FPC_EINVAL;
@@ -90,9 +104,9 @@ extern "C" int fpc_class_compress(const float* mask_logits, const float* quat, c
     hipStream_t s = (hipStream_t)stream;
     if (C <= 8)
         hipLaunchKernelGGL(k_class_compress<8>, grid, block, 0, s, mask_logits, quat, scales, xy, z, cat_mask_in, C,
-                           HW, cat_mask, oq, os, oxy, oz);
+                           HW, cat_mask, oq, os, oxy, oz, fb, fstride);
     else
         hipLaunchKernelGGL(k_class_compress<32>, grid, block, 0, s, mask_logits, quat, scales, xy, z, cat_mask_in, C,
-                           HW, cat_mask, oq, os, oxy, oz);
+                           HW, cat_mask, oq, os, oxy, oz, fb, fstride);
     return check_launch();
 }

@@ -645,7 +645,14 @@ static int forward_middle(fpc_net* n, hipStream_t s) {
 extern "C" int fpc_net_forward(fpc_net_t* n, const float* x, float* logits_mask, float* logits_quat,
                                float* logits_scales, float* logits_xy, float* logits_z, int64_t* cat_mask, float* cq,
                                float* cs, float* cxy, float* cz, fpc_stream_t stream) {
+    return fpc_net_forward_bits(n, x, logits_mask, logits_quat, logits_scales, logits_xy, logits_z, cat_mask, cq, cs, cxy, cz, nullptr, stream);
+}
+
+extern "C" int fpc_net_forward_bits(fpc_net_t* n, const float* x, float* logits_mask, float* logits_quat,
+                                    float* logits_scales, float* logits_xy, float* logits_z, int64_t* cat_mask, float* cq,
+                                    float* cs, float* cxy, float* cz, uint64_t* fg_bits, fpc_stream_t stream) {
     if (!n || !n->loaded || !x || !cat_mask || !cq || !cs || !cxy || !cz) return FPC_EINVAL;
+    if (fg_bits && (n->W % 64 != 0 || ((uintptr_t)fg_bits & 7))) return FPC_EINVAL;
     bool any = logits_mask || logits_quat || logits_scales || logits_xy || logits_z;
     bool all = logits_mask && logits_quat && logits_scales && logits_xy && logits_z;
     if (any && !all) return FPC_EINVAL;
@@ -682,6 +689,7 @@ extern "C" int fpc_net_forward(fpc_net_t* n, const float* x, float* logits_mask,
         u.o_mask = logits_mask; u.o_quat = logits_quat; u.o_scales = logits_scales; u.o_xy = logits_xy; u.o_z = logits_z;
         u.cat_mask = (long long*)cat_mask; u.cq = cq; u.cs = cs; u.cxy = cxy; u.cz = cz;
         u.B = B; u.hl = n->a_low[0].H; u.wl = n->a_low[0].W; u.H = H; u.W = W; u.C = n->classes;
+        u.fg_bits = reinterpret_cast<unsigned long long*>(fg_bits); u.fg_stride = (size_t)((H * W + 4095) / 4096) * 64;
         if (u.hl * 4 != H || u.wl * 4 != W) return FPC_EINVAL;
         FPC_TRY(launch_up4_compress(u, s));
     }

@@ -914,6 +914,10 @@ __global__ __launch_bounds__(256) void k_up4_compress(const Up4Args a) {
             if (val > best) { best = val; cls = c; }
         }
     a.cat_mask[(size_t)b * HW + p] = cls;
+    if (a.fg_bits) {            // rows start on word boundaries (the host checked W % 64 == 0): a wave = one word
+        const unsigned long long fgm = __ballot(cls != 0);
+        if ((threadIdx.x & 63) == 0) a.fg_bits[(size_t)b * a.fg_stride + (p >> 6)] = fgm;
+    }
     const int g = cls - 1;
     float q[4] = {0, 0, 0, 0}, sc[3] = {0, 0, 0}, vxy[2] = {0, 0}, zz = 0.f;
     for (int k = 0; k < G; ++k) {
@@ -997,6 +1001,10 @@ __global__ __launch_bounds__(256) void k_up4_compress7(const Up4Args a) {
         if (val > best) { best = val; cls = c; }
     }
     a.cat_mask[(size_t)b * HW + p] = cls;
+    if (a.fg_bits) {            // rows start on word boundaries (the host checked W % 64 == 0): a wave = one word
+        const unsigned long long fgm = __ballot(cls != 0);
+        if ((threadIdx.x & 63) == 0) a.fg_bits[(size_t)b * a.fg_stride + (p >> 6)] = fgm;
+    }
     if (a.o_mask) {
 #pragma unroll
         for (int c = 0; c < C; ++c) a.o_mask[((size_t)b * C + c) * HW + p] = vm[c];
@@ -1155,6 +1163,7 @@ int launch_merge_head(const MergeHeadArgs& a, int groups, hipStream_t s) {
 
 int launch_up4_compress(const Up4Args& a, hipStream_t s) {
     if (a.C < 2 || a.C > 32 || a.H > 65535 || a.B > 65535) return FPC_EINVAL;
+    if (a.fg_bits && a.W % 64 != 0) return FPC_EINVAL;
     dim3 grid(cdiv(a.W, 256), a.H, a.B);
     if (a.C == 7 && a.pm == 8 && a.pq == 24 && a.pt == 20 && a.ps == 20)
         hipLaunchKernelGGL(k_up4_compress7, dim3(cdiv(a.W, 128), a.H, a.B), dim3(128), 0, s, a);

@@ -74,6 +74,7 @@ struct Up4Args {
     float* o_mask; float* o_quat; float* o_scales; float* o_xy; float* o_z;   // full-res NCHW logits (nullable as a set)
     long long* cat_mask; float* cq; float* cs; float* cxy; float* cz;          // categorical outputs
     int B, hl, wl, H, W, C;                                               // C classes incl. background
+    unsigned long long* fg_bits; size_t fg_stride;                        // nullable: foreground bit words [B][fg_stride] (W % 64 == 0)
 };
 
 // Winograd F(2x2,3x3) convolution (3x3, stride 1, pad 1, NHWC, Cin % 8 == 0, Cout % 64 == 0)

@@ -116,11 +116,18 @@ class NetEngine:
         cat = {'mask': torch.empty((B, H, W), dtype=torch.int64, device=dev),
                'quaternion': torch.empty((B, 4, H, W), **f32), 'scales': torch.empty((B, 3, H, W), **f32),
                'xy': torch.empty((B, 2, H, W), **f32), 'z': torch.empty((B, H, W), **f32)}
+        # the foreground of the class mask also as bit words (1/64 of its bytes): the connected-component labelling reads
+        # those instead of the i64 mask; they ride on the mask tensor (aggregation_layer.fg_bits_of), not in the dict
+        bits = None
+        if W % 64 == 0 and self._lib.fpc_cc_bits_supported(B, H, W):
+            bits = torch.empty((B, self._lib.fpc_mask_bits_words(H, W)), dtype=torch.int64, device=dev)
         with torch.cuda.device(dev):
-            nat.check(self._lib.fpc_net_forward(self._h, x.data_ptr(), *lp, cat['mask'].data_ptr(),
-                                                cat['quaternion'].data_ptr(), cat['scales'].data_ptr(),
-                                                cat['xy'].data_ptr(), cat['z'].data_ptr(), nat.stream()),
-                      "fpc_net_forward")
+            nat.check(self._lib.fpc_net_forward_bits(self._h, x.data_ptr(), *lp, cat['mask'].data_ptr(),
+                                                     cat['quaternion'].data_ptr(), cat['scales'].data_ptr(),
+                                                     cat['xy'].data_ptr(), cat['z'].data_ptr(), nat.ptr(bits), nat.stream()),
+                      "fpc_net_forward_bits")
+        if bits is not None:
+            cat['mask']._fpc_fg_bits = (bits, cat['mask']._version)
         return logits, cat
 
     def tensor(self, name):

@@ -23,6 +23,31 @@ def mask_bits_of(masks):
     return tag[0]
 
 
+def fg_bits_of(class_mask):
+    """The foreground bit words the class compression wrote beside this very mask tensor (engine.NetEngine.forward,
+    gtf.class_compression_fused), or None: any other tensor, a copy / slice / cast of it, or the tensor after an in-place
+    write.  `attach_fg_bits` builds them for a mask that came from somewhere else (one launch)."""
+    tag = getattr(class_mask, "_fpc_fg_bits", None)
+    if tag is None or tag[1] != class_mask._version or tag[0].shape[0] != class_mask.shape[0]:
+        return None
+    return tag[0]
+
+
+def attach_fg_bits(class_mask):
+    """i64 [B,H,W] class mask -> the same tensor with its foreground bit words attached (fpc_fg_bits), where the labelling
+    supports them; a fixture's stand-in for what the class compression does on the way."""
+    nat.require_gpu(class_mask, what="attach_fg_bits")
+    B, H, W = class_mask.shape
+    L = nat.lib()
+    if class_mask.dtype != torch.int64 or not class_mask.is_contiguous() or not L.fpc_cc_bits_supported(B, H, W):
+        return class_mask
+    bits = torch.empty((B, L.fpc_mask_bits_words(H, W)), dtype=torch.int64, device=class_mask.device)
+    with torch.cuda.device(class_mask.device):
+        nat.check(L.fpc_fg_bits(nat.ptr(class_mask), B, H, W, nat.ptr(bits), nat.stream()), "fpc_fg_bits")
+    class_mask._fpc_fg_bits = (bits, class_mask._version)
+    return class_mask
+
+
 class AggregationLayer(nn.Module):
 
     def __init__(self, HPARAM, classes):
@@ -40,6 +65,7 @@ class AggregationLayer(nn.Module):
         nat.require_gpu(class_mask, what="AggregationLayer")
         B, H, W = class_mask.shape
         dev = class_mask.device
+        fg_bits = fg_bits_of(class_mask)
         cm = class_mask if class_mask.dtype == torch.int64 else class_mask.to(torch.int64)
         cm = cm.contiguous()
         labels = torch.empty((B, H, W), dtype=torch.int32, device=dev)
@@ -50,8 +76,13 @@ class AggregationLayer(nn.Module):
         L = nat.lib()
         with torch.cuda.device(dev):
             ws = nat.workspace("cc", dev, L.fpc_cc_workspace_bytes(B, H, W))
-            nat.check(L.fpc_cc_label(nat.ptr(cm), B, H, W, nat.ptr(labels), nat.ptr(n_dev), nat.ptr(root_pix), root_pix.numel(),
-                                     nat.ptr(ws), ws.numel(), nat.stream()), "fpc_cc_label")
+            if fg_bits is not None and L.fpc_cc_bits_supported(B, H, W):
+                # the class compression left the foreground as bit words: the labelling never reads the i64 mask
+                nat.check(L.fpc_cc_label_bits(nat.ptr(fg_bits), B, H, W, nat.ptr(labels), nat.ptr(n_dev), nat.ptr(root_pix),
+                                              root_pix.numel(), nat.ptr(ws), ws.numel(), nat.stream()), "fpc_cc_label_bits")
+            else:
+                nat.check(L.fpc_cc_label(nat.ptr(cm), B, H, W, nat.ptr(labels), nat.ptr(n_dev), nat.ptr(root_pix), root_pix.numel(),
+                                         nat.ptr(ws), ws.numel(), nat.stream()), "fpc_cc_label")
         labels._fpc_root_pix = (root_pix, labels._version)
         if return_device_count:
             return labels, n_dev

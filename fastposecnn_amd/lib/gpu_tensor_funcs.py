@@ -50,11 +50,19 @@ def _class_compress_hip(num_of_classes, cat_mask_in, logits):
     os_ = torch.empty((B, 3, H, W), dtype=torch.float32, device=dev)
     oxy = torch.empty((B, 2, H, W), dtype=torch.float32, device=dev)
     oz = torch.empty((B, H, W), dtype=torch.float32, device=dev)
+    # the foreground also as bit words for the connected-component labelling (they ride on the mask tensor, see
+    # aggregation_layer.fg_bits_of; only where that labelling can use them)
+    bits = None
+    L = nat.lib()
+    if L.fpc_cc_bits_supported(B, H, W):
+        bits = torch.empty((B, L.fpc_mask_bits_words(H, W)), dtype=torch.int64, device=dev)
     with torch.cuda.device(dev):
-        nat.check(nat.lib().fpc_class_compress(nat.ptr(ml), nat.ptr(q), nat.ptr(s), nat.ptr(xy), nat.ptr(z),
-                                               nat.ptr(cat_mask_in), B, C, HW, nat.ptr(cat_mask), nat.ptr(oq),
-                                               nat.ptr(os_), nat.ptr(oxy), nat.ptr(oz), nat.stream()),
-                  "fpc_class_compress")
+        nat.check(L.fpc_class_compress_bits(nat.ptr(ml), nat.ptr(q), nat.ptr(s), nat.ptr(xy), nat.ptr(z),
+                                            nat.ptr(cat_mask_in), B, C, HW, nat.ptr(cat_mask), nat.ptr(oq),
+                                            nat.ptr(os_), nat.ptr(oxy), nat.ptr(oz), nat.ptr(bits), nat.stream()),
+                  "fpc_class_compress_bits")
+    if bits is not None:
+        cat_mask._fpc_fg_bits = (bits, cat_mask._version)
     return {"quaternion": oq, "scales": os_, "xy": oxy, "z": oz}, cat_mask
 
 

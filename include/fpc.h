@@ -130,6 +130,15 @@ int fpc_class_compress(const float* mask_logits, const float* quat, const float*
                        int B, int C, int HW,
                        int64_t* cat_mask, float* oq, float* os, float* oxy, float* oz,
                        fpc_stream_t stream);
+/* The same, also writing the foreground (cat_mask != 0) as bit words for fpc_cc_label_bits: fg_bits u64
+ * [B][fpc_mask_bits_words-style stride = ceil(HW / 4096) * 64], bit j of word w = pixel 64 w + j; words past ceil(HW / 64)
+ * are not written.  NULL fg_bits = fpc_class_compress. */
+int fpc_class_compress_bits(const float* mask_logits, const float* quat, const float* scales,
+                            const float* xy, const float* z, const int64_t* cat_mask_in,
+                            int B, int C, int HW,
+                            int64_t* cat_mask, float* oq, float* os, float* oxy, float* oz,
+                            uint64_t* fg_bits, fpc_stream_t stream);
+
 
 /* ---- connected components ---------------------------------------------------
  * cat_mask i64 [B,H,W]; foreground iff != 0; 4-connectivity inside an image, none
@@ -141,6 +150,17 @@ size_t fpc_cc_workspace_bytes(int B, int H, int W);
 int fpc_cc_label(const int64_t* cat_mask, int B, int H, int W,
                  int32_t* labels, int32_t* n_out, int32_t* root_pix, int cap,
                  void* ws, size_t ws_bytes, fpc_stream_t stream);
+/* The same labelling from the foreground as BIT WORDS: fg_bits u64 [B][fpc_mask_bits_words(H, W)], bit j of word w = pixel
+ * 64 w + j of the image, zero past H W (8-byte aligned).  No reference counterpart: the reference hands cupy an f32 copy of
+ * the mask (F/lib/aggregation_layer.py:165); here the class compression (fpc_class_compress_bits, the network engine) writes
+ * the words beside the i64 mask and the labelling never reads the mask itself — 1/64 of its bytes, two launches.  Available
+ * when fpc_cc_bits_supported(B, H, W) (rows on word boundaries: W % 64 == 0, and an image whose words fit one workgroup's LDS:
+ * up to ~630 000 pixels); fpc_cc_label takes the same path by itself on such shapes after converting the mask (fpc_fg_bits). */
+int fpc_cc_bits_supported(int B, int H, int W);
+int fpc_fg_bits(const int64_t* cat_mask, int B, int H, int W, uint64_t* fg_bits, fpc_stream_t stream);
+int fpc_cc_label_bits(const uint64_t* fg_bits, int B, int H, int W, int32_t* labels, int32_t* n_out,
+                      int32_t* root_pix, int cap, void* ws, size_t ws_bytes, fpc_stream_t stream);
+
 
 /* ---- aggregation ------------------------------------------------------------
  * labels i32 [B,H,W] from fpc_cc_label, N instances (host value: the count read back by the caller,
@@ -303,6 +323,12 @@ int fpc_net_load_params(fpc_net_t* net, const float* const* params, int count, v
 int fpc_net_forward(fpc_net_t* net, const float* x, float* logits_mask, float* logits_quat,
                     float* logits_scales, float* logits_xy, float* logits_z, int64_t* cat_mask,
                     float* cq, float* cs, float* cxy, float* cz, fpc_stream_t stream);
+/* The same, also writing the foreground of cat_mask as bit words (see fpc_class_compress_bits; the plan's W must be a
+ * multiple of 64 when fg_bits is not NULL). */
+int fpc_net_forward_bits(fpc_net_t* net, const float* x, float* logits_mask, float* logits_quat,
+                         float* logits_scales, float* logits_xy, float* logits_z, int64_t* cat_mask,
+                         float* cq, float* cs, float* cxy, float* cz, uint64_t* fg_bits, fpc_stream_t stream);
+
 /* Autotuning: after fpc_net_autotune_next the NEXT fpc_net_forward times every candidate tiling
  * (block tile, split-K factor) of every convolution on the device, keeps the fastest, and is itself
  * a valid forward; it synchronises the stream, so it must not be captured into a graph.

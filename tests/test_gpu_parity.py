@@ -264,6 +264,77 @@ def test_cc_label_structures(lib, oracle, dev):
     assert N == 0 and int(labels.abs().sum()) == 0
 
 
+def _pack_fg_words(fg):
+    """bool [B,H,W] -> u64 words [B, ceil(HW / 4096) * 64] as the kernels lay them out (bit j of word w = pixel 64 w + j)."""
+    B = fg.shape[0]
+    flat = fg.reshape(B, -1)
+    words = -(-flat.shape[1] // 4096) * 64
+    pad = np.zeros((B, words * 64), bool)
+    pad[:, :flat.shape[1]] = flat
+    return np.packbits(pad.reshape(B, words, 64), axis=2, bitorder="little").view(np.uint64).reshape(B, words)
+
+
+@pytest.mark.parametrize("shape,kind", [((1, 480, 640), "blobs"), ((3, 480, 640), "blobs+specks"), ((2, 64, 64), "noise"),
+                                        ((1, 480, 640), "noise"), ((2, 96, 128), "structures"), ((33, 120, 192), "blobs+specks")])
+def test_cc_label_from_bit_words(lib, oracle, dev, shape, kind):
+    """fpc_cc_label_bits (round 4): whole-image run labelling from the foreground bit words, two launches.  Labels and
+    their order bit-exact against the oracle (= scipy's numbering), root_pix = each component's first pixel; "noise" at
+    640 x 480 has ~75 000 runs: the parent array leaves LDS for global memory."""
+    import aggregation_layer as al
+    B, H, W = shape
+    rng = np.random.default_rng(B * 1000 + H)
+    yy, xx = np.mgrid[0:H, 0:W]
+    fg = np.zeros(shape, bool)
+    if kind.startswith("blobs"):
+        for b in range(B):
+            for k in range(6):
+                cy, cx, ry, rx = rng.integers(0, H), rng.integers(0, W), rng.integers(H // 16 + 2, H // 4), rng.integers(W // 16 + 2, W // 4)
+                fg[b] |= ((yy - cy) / ry) ** 2 + ((xx - cx) / rx) ** 2 <= 1.0
+        if "specks" in kind:
+            fg ^= rng.random(shape) < 0.003
+    elif kind == "noise":
+        fg = rng.random(shape) < 0.58
+    else:
+        fg[0] = ((xx // 3 + yy // 3) % 2 == 0)
+        fg[1] = ((xx % 8 < 4) | (yy == H - 1))
+    from fastposecnn_amd import _native as nat
+    assert nat.lib().fpc_cc_bits_supported(B, H, W) == 1
+    cm = T(fg.astype(np.int64) * 3, dev)
+    al.attach_fg_bits(cm)
+    bits = al.fg_bits_of(cm)
+    assert bits is not None and np.array_equal(bits.cpu().numpy().view(np.uint64), _pack_fg_words(fg))
+    layer = al.AggregationLayer(None, 7)
+    labels, N = layer.batchwise_break_segmentation_mask(cm)
+    want, M = oracle.cc_label(fg)
+    assert N == M and np.array_equal(labels.cpu().numpy(), want)
+    root_pix = labels._fpc_root_pix[0].cpu().numpy()
+    flat = want.reshape(-1)
+    n_chk = min(M, root_pix.shape[0])
+    first = np.full(M + 1, -1, np.int64)
+    idx = np.nonzero(flat)[0]
+    first[flat[idx][::-1]] = idx[::-1]                          # first (lowest) linear index of every label
+    assert np.array_equal(root_pix[:n_chk], first[1:n_chk + 1])
+    # the i64 entry takes the same path after converting the mask itself
+    labels2, N2 = layer.batchwise_break_segmentation_mask(T(fg, dev))
+    assert N2 == M and torch.equal(labels2, labels)
+
+
+def test_class_compression_writes_the_foreground_bit_words(lib, dev):
+    import aggregation_layer as al
+    import gpu_tensor_funcs as gtf
+    g = torch.Generator().manual_seed(5)
+    B, C, H, W = 2, 7, 64, 128
+    logits = {"mask": torch.randn(B, C, H, W, generator=g), "quaternion": torch.randn(B, 24, H, W, generator=g),
+              "scales": torch.randn(B, 18, H, W, generator=g), "xy": torch.randn(B, 12, H, W, generator=g),
+              "z": torch.randn(B, 6, H, W, generator=g)}
+    cat = gtf.class_compression_fused(C, {k: v.to(dev) for k, v in logits.items()})
+    bits = al.fg_bits_of(cat["mask"])
+    assert bits is not None
+    assert np.array_equal(bits.cpu().numpy().view(np.uint64), _pack_fg_words(cat["mask"].cpu().numpy() != 0))
+    cat["mask"][0, 0, 0] = 1                                     # an in-place write retires the words
+    assert al.fg_bits_of(cat["mask"]) is None
+
+
 # ----------------------------------------------------------------------------- aggregation / pose
 
 def test_aggregate_golden(lib, oracle, dev):
