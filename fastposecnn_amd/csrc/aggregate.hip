@@ -4,8 +4,10 @@
 //   k_agg_accum     one pass over labels + cat_mask + the 8 averaged planes: per-instance
 //                   pixel count, smallest class id, fp64 sums (wave-level pre-reduction when a
 //                   wave sees a single label, which is the common case)
-//   k_agg_planes    the drop-in outputs instance_masks [N,H,W] and masked xy [N,2,H,W]; the first workgroup of an
-//                   instance also takes its means, exp(z), quaternion re-normalisation, class / sample ids
+//   k_agg_planes_img  the drop-in outputs instance_masks [N,H,W] and masked xy [N,2,H,W] (+ bit words): one label read per
+//                   image chunk for all of the image's instances; the workgroup of chunk 0 also takes their means, exp(z),
+//                   quaternion re-normalisation, class / sample ids
+//   k_agg_fused     (<= 4 frames) both halves in one launch
 #include "common.hpp"
 
 namespace fpc {
@@ -299,21 +301,120 @@ __device__ __forceinline__ void agg_planes_block(int bx, int i, int b, const int
     }
 }
 
-// grid (ceil(HW/4096), N): a workgroup writes one 4096-pixel chunk of one instance (four 4-pixel groups per lane, their
-// label loads issued together); the first block of every instance also finalises it (no launch of its own).
-__global__ __launch_bounds__(256) void k_agg_planes(const int32_t* __restrict__ labels, const float* __restrict__ xy,
-                                                    const int32_t* __restrict__ sample, int HW,
-                                                    const int32_t* __restrict__ n_dev,
-                                                    float* __restrict__ inst_masks, float* __restrict__ oxy,
-                                                    const double* __restrict__ sums, const int32_t* __restrict__ cnt,
-                                                    const uint32_t* __restrict__ cls_min, int64_t* __restrict__ class_ids,
-                                                    int64_t* __restrict__ sample_ids, float* __restrict__ oq,
-                                                    float* __restrict__ os, float* __restrict__ oz, float* __restrict__ stats,
-                                                    uint64_t* __restrict__ bits, int nwords) {
-    const int i = blockIdx.y;
-    if (n_dev && i >= *n_dev) return;     // capacity rows past the device-side instance count
-    if (blockIdx.x == 0 && threadIdx.x == 0) agg_finalize_one(i, sums, cnt, cls_min, sample, class_ids, sample_ids, oq, os, oz, stats);
-    agg_planes_block(blockIdx.x, i, sample[i], labels, xy, HW, inst_masks, oxy, bits, nwords);
+// grid (ceil(HW/4096), B): the large-batch form.  A workgroup reads ONE 4096-pixel chunk of an image's label plane and of
+// its two vote planes and writes that chunk of EVERY instance of the image (masks, masked vote field, bit words): the labels
+// of an image are read once, not once per instance (round 3: 236 of the 944 MB the kernel moved on 32 frames).  The
+// instances of image b are a contiguous label range (components are numbered image by image): found from `sample`, which
+// the accumulation wrote, by one sweep of the workgroup.  The workgroup of chunk 0 finalises the image's instances.
+__global__ __launch_bounds__(256) void k_agg_planes_img(const int32_t* __restrict__ labels, const float* __restrict__ xy,
+                                                        const int32_t* __restrict__ sample, int HW, int N,
+                                                        const int32_t* __restrict__ n_dev,
+                                                        float* __restrict__ inst_masks, float* __restrict__ oxy,
+                                                        const double* __restrict__ sums, const int32_t* __restrict__ cnt,
+                                                        const uint32_t* __restrict__ cls_min, int64_t* __restrict__ class_ids,
+                                                        int64_t* __restrict__ sample_ids, float* __restrict__ oq,
+                                                        float* __restrict__ os, float* __restrict__ oz, float* __restrict__ stats,
+                                                        uint64_t* __restrict__ bits, int nwords) {
+    __shared__ int s_rng[2];
+    const int b = blockIdx.y, bx = blockIdx.x;
+    const int n = n_dev ? min(N, *n_dev) : N;
+    if (threadIdx.x == 0) { s_rng[0] = 0x7fffffff; s_rng[1] = -1; }
+    __syncthreads();
+    int lo = 0x7fffffff, hi = -1;
+    for (int i = threadIdx.x; i < n; i += blockDim.x)
+        if (sample[i] == b && cnt[i] > 0) { lo = min(lo, i); hi = max(hi, i); }
+#pragma unroll
+    for (int o = kWave / 2; o > 0; o >>= 1) { lo = min(lo, __shfl_xor(lo, o, kWave)); hi = max(hi, __shfl_xor(hi, o, kWave)); }
+    if ((threadIdx.x & (kWave - 1)) == 0 && hi >= 0) { atomicMin(&s_rng[0], lo); atomicMax(&s_rng[1], hi); }
+    __syncthreads();
+    lo = s_rng[0]; hi = s_rng[1];
+    if (hi < 0) return;                                  // an image without instances
+    if (bx == 0)
+        for (int i = lo + (int)threadIdx.x; i <= hi; i += blockDim.x)
+            agg_finalize_one(i, sums, cnt, cls_min, sample, class_ids, sample_ids, oq, os, oz, stats);
+    const int32_t* L = labels + (size_t)b * HW;
+    const bool vec = (HW & 3) == 0;
+    const int lane = threadIdx.x & (kWave - 1);
+    int4 lab[4];
+    float4 vx[4], vy[4];
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        const int p0 = bx * 4096 + it * 1024 + threadIdx.x * 4;
+        lab[it] = make_int4(0, 0, 0, 0);
+        vx[it] = vy[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (vec) {
+            if (p0 < HW) lab[it] = *reinterpret_cast<const int4*>(L + p0);
+        } else {
+            if (p0 < HW) lab[it].x = L[p0];
+            if (p0 + 1 < HW) lab[it].y = L[p0 + 1];
+            if (p0 + 2 < HW) lab[it].z = L[p0 + 2];
+            if (p0 + 3 < HW) lab[it].w = L[p0 + 3];
+        }
+    }
+    if (oxy) {
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int p0 = bx * 4096 + it * 1024 + threadIdx.x * 4;
+            if ((lab[it].x | lab[it].y | lab[it].z | lab[it].w) == 0) continue;      // labels are >= 0: a background group
+            if (vec) {
+                vx[it] = *reinterpret_cast<const float4*>(xy + ((size_t)b * 2 + 0) * HW + p0);
+                vy[it] = *reinterpret_cast<const float4*>(xy + ((size_t)b * 2 + 1) * HW + p0);
+            } else {
+                float ax[4] = {0, 0, 0, 0}, ay[4] = {0, 0, 0, 0};
+                for (int k = 0; k < 4 && p0 + k < HW; ++k) { ax[k] = xy[((size_t)b * 2 + 0) * HW + p0 + k]; ay[k] = xy[((size_t)b * 2 + 1) * HW + p0 + k]; }
+                vx[it] = make_float4(ax[0], ax[1], ax[2], ax[3]); vy[it] = make_float4(ay[0], ay[1], ay[2], ay[3]);
+            }
+        }
+    }
+    for (int i = lo; i <= hi; ++i) {
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int p0 = bx * 4096 + it * 1024 + threadIdx.x * 4;
+            const bool f0 = lab[it].x == i + 1, f1 = lab[it].y == i + 1, f2 = lab[it].z == i + 1, f3 = lab[it].w == i + 1;
+            if (bits) {
+                // four ballots, lanes 0..3 interleave the wave's four words (as agg_planes_block)
+                const uint64_t b0 = __ballot(f0), b1 = __ballot(f1), b2 = __ballot(f2), b3 = __ballot(f3);
+                if (lane < 4) {
+                    auto spread = [](uint64_t x) {      // bit m of the low 16 -> bit 4 m
+                        x &= 0xFFFFull;
+                        x = (x | (x << 24)) & 0x000000FF000000FFull;
+                        x = (x | (x << 12)) & 0x000F000F000F000Full;
+                        x = (x | (x << 6)) & 0x0303030303030303ull;
+                        x = (x | (x << 3)) & 0x1111111111111111ull;
+                        return x;
+                    };
+                    const int sh = 16 * lane;
+                    const uint64_t word = spread(b0 >> sh) | (spread(b1 >> sh) << 1) | (spread(b2 >> sh) << 2) | (spread(b3 >> sh) << 3);
+                    const int wi = bx * 64 + it * 16 + (threadIdx.x / kWave) * 4 + lane;
+                    if (wi < nwords) bits[(size_t)i * nwords + wi] = word;
+                }
+            }
+            if (p0 >= HW) continue;
+            if (vec) {
+                // streaming stores: 3.7 MB per instance that this kernel never reads back
+                if (inst_masks)
+                    __builtin_nontemporal_store(f32x4{f0 ? 1.f : 0.f, f1 ? 1.f : 0.f, f2 ? 1.f : 0.f, f3 ? 1.f : 0.f},
+                                                reinterpret_cast<f32x4*>(inst_masks + (size_t)i * HW + p0));
+                if (oxy) {
+                    __builtin_nontemporal_store(f32x4{f0 ? vx[it].x : 0.f, f1 ? vx[it].y : 0.f, f2 ? vx[it].z : 0.f, f3 ? vx[it].w : 0.f},
+                                                reinterpret_cast<f32x4*>(oxy + ((size_t)i * 2 + 0) * HW + p0));
+                    __builtin_nontemporal_store(f32x4{f0 ? vy[it].x : 0.f, f1 ? vy[it].y : 0.f, f2 ? vy[it].z : 0.f, f3 ? vy[it].w : 0.f},
+                                                reinterpret_cast<f32x4*>(oxy + ((size_t)i * 2 + 1) * HW + p0));
+                }
+            } else {
+                const bool fl[4] = {f0, f1, f2, f3};
+                const float ax[4] = {vx[it].x, vx[it].y, vx[it].z, vx[it].w}, ay[4] = {vy[it].x, vy[it].y, vy[it].z, vy[it].w};
+                for (int k = 0; k < 4 && p0 + k < HW; ++k) {
+                    const int p = p0 + k;
+                    if (inst_masks) inst_masks[(size_t)i * HW + p] = fl[k] ? 1.f : 0.f;
+                    if (oxy) {
+                        oxy[((size_t)i * 2 + 0) * HW + p] = fl[k] ? ax[k] : 0.f;
+                        oxy[((size_t)i * 2 + 1) * HW + p] = fl[k] ? ay[k] : 0.f;
+                    }
+                }
+            }
+        }
+    }
 }
 
 // ONE launch for both halves when the image of an instance is known without the accumulation (root_pix, from
@@ -429,7 +530,7 @@ extern "C" int fpc_aggregate_bits(const int32_t* labels, const int64_t* cat_mask
                        H, W, N, n_dev, w.sums,
                        w.cnt, w.cls_min, w.sample);
     if (inst_masks || oxy || inst_bits)
-        hipLaunchKernelGGL(k_agg_planes, dim3(gx, N), dim3(256), 0, s, labels, xy, w.sample, HW, n_dev, inst_masks, oxy, w.sums, w.cnt,
+        hipLaunchKernelGGL(k_agg_planes_img, dim3(gx, B), dim3(256), 0, s, labels, xy, w.sample, HW, N, n_dev, inst_masks, oxy, w.sums, w.cnt,
                            w.cls_min, class_ids, sample_ids, oq, os, oz, out_stats, inst_bits, nwords);
     else
         hipLaunchKernelGGL(k_agg_finalize, dim3(cdiv(N, 64)), dim3(64), 0, s, N, n_dev, w.sums, w.cnt, w.cls_min, w.sample,
