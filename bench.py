@@ -30,8 +30,9 @@ Extra objects on the JSON line:
                     layer's mask bit words: fpc_ransac_voting_v3_bits): algorithmic bytes n_instances * 12*H*W per call /
                     HIP-event time of 10 back-to-back calls on cold inputs, against the 8 TB/s HBM peak of MI355X_MICROARCH.md;
                     `traffic` and `valu` are PMC counters of a separately profiled run (`from_profile` names file and commit:
-                    profiles/r03_vote_bits_traffic_*.json)
+                    profiles/r04_vote_bits_traffic_*.json)
   roofline_hn128    the same sequence at the training value hn = 128 (F/config.py:93) on a 32-frame batch (192 instances)
+  roofline_hn128_f32_masks  ... and through the reference's own interface: f32 mask planes, no bit words (every algorithmic byte read)
   post_network      connected components and aggregation at B = 1 and B = 32: time, algorithmic bytes, fraction of 8 TB/s
   backbone          the network part: executed f32-equivalent multiply-add FLOP of the engine's plans (Winograd sites count
                     1/2.25) / device time per network, against the 157.3 TFLOP/s f32 matrix peak (and, second figure,
@@ -206,7 +207,7 @@ def cpu_baseline(model_cpu, image, cat_cpu, hn, inv_k, encoder):
             "value_1_thread_post": round(1.0 / (t_net + t_post1), 4)}
 
 
-def vote_roofline(model_gpu, cat, n_inst, reps, label, calls=10):
+def vote_roofline(model_gpu, cat, n_inst, reps, label, calls=10, use_bits=True):
     """Average duration of the hough-voting launch sequence: HIP events on the launch stream around `calls` back-to-back
     enqueues of the call (its inputs produced just before), divided by `calls`; median over `reps` such groups.  Back to
     back, the host's enqueue time hides behind the previous call's kernels, so this is the device time of the sequence —
@@ -217,6 +218,9 @@ def vote_roofline(model_gpu, cat, n_inst, reps, label, calls=10):
     with torch.no_grad():
         for _ in range(reps):
             aggs = [model_gpu.aggregate(cat) for _ in range(calls)]
+            if not use_bits:                                   # the stand-alone interface: f32 mask planes, no side channel
+                for agg in aggs:
+                    agg["instance_masks"]._fpc_mask_bits = None
             ev[0].record()
             for agg in aggs:
                 model_gpu.hough_voting(agg)
@@ -228,11 +232,14 @@ def vote_roofline(model_gpu, cat, n_inst, reps, label, calls=10):
     alg = n_inst * 12 * H * W
     ach = alg / t / 1e9
     return {"bound": "hbm", "achieved": round(ach, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBPS, 5),
-            "traffic": None, "kernel": "fpc_ransac_voting_v3_bits launch sequence (k_vote_scan, k_vote_plan, k_vote_count, k_vote_final)",
-            "mask_source": "bit words written by the aggregation layer (the model's pipeline): the scan does not read the f32 mask "
-                           "planes, so `traffic` is below the algorithmic bytes; `achieved` still prices SURVEY 8(d)'s 12 H W per "
-                           "instance, the bytes of the reference's own interface.  The stand-alone entry on f32 masks: "
-                           "profiles/r03_vote_traffic_*.json, r03_vote_*_kernel_stats.csv",
+            "traffic": None, "kernel": ("fpc_ransac_voting_v3_bits" if use_bits else "fpc_ransac_voting_v3") +
+                                       " launch sequence (k_vote_scan, k_vote_plan, k_vote_count, k_vote_final)",
+            "mask_source": ("bit words written by the aggregation layer (the model's pipeline): the scan does not read the f32 mask "
+                            "planes, so `traffic` is below the algorithmic bytes; `achieved` still prices SURVEY 8(d)'s 12 H W per "
+                            "instance, the bytes of the reference's own interface.  The stand-alone entry on f32 masks: "
+                            "roofline_hn128_f32_masks, profiles/r04_vote_traffic_*.json, r04_vote_*_kernel_stats.csv") if use_bits else
+                           "f32 mask planes through the reference's own interface (ransac_voting_layer_v3(mask, vertex, ...)): every "
+                           "algorithmic byte is read",
             "workload": label, "algorithmic_bytes_per_launch": alg, "launch_ms": round(t * 1e3, 4),
             "timing": f"HIP events around {calls} back-to-back calls on the launch stream / {calls}, median of {reps}"}
 
@@ -247,7 +254,8 @@ def post_network_rates(model_gpu, cat1, n1, cat32, n32, reps=15, calls=6):
     out = {}
     for tag, cat, n_inst in (("b1", cat1, n1), ("b32", cat32, n32)):
         B = cat["mask"].shape[0]
-        cm = cat["mask"].to(torch.int64).contiguous()
+        import aggregation_layer as al
+        cm = al.attach_fg_bits(cat["mask"].to(torch.int64).contiguous())      # as the class compression hands the mask over
         ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
         t_cc, t_agg = [], []
         # device time: the enqueues of one stage are captured into a HIP graph and replayed (on one frame a stage is 15-30 us of
@@ -298,6 +306,9 @@ def post_network_rates(model_gpu, cat1, n1, cat32, n32, reps=15, calls=6):
                                   "frac": round(agg_b / agg_s / 1e9 / HBM_PEAK_GBPS, 4)},
                     "us": round((cc_s + agg_s) * 1e6, 2)}
     out["timing"] = f"HIP events around {calls} back-to-back calls / {calls}, median of {reps}, {timing_mode}; fractions of the 8 TB/s HBM peak"
+    out["cc_mask_source"] = ("foreground bit words written by the class compression beside the i64 mask (the model's pipeline): "
+                             "fpc_cc_label_bits reads 1/64 of the mask's bytes; `bytes` still prices the i64 mask of the reference's "
+                             "interface (8 H W read + 4 H W written per frame).  The i64 entry fpc_cc_label: tools_dev/cc_time.py")
     return out
 
 
@@ -393,6 +404,10 @@ def run_inference(args, encoder, Bq, hn, steps, warmup, world, rank, dev, want_b
     cat_cpu, _ = synth.make_vote_batch(range(rank * Bq, rank * Bq + Bq))
     x = image.to(dev)
     cat = {k: v.to(dev) for k, v in cat_cpu.items()}
+    # the fixture stands in for the class compression's output: it carries the foreground bit words that stage writes beside
+    # the i64 mask (engine.NetEngine.forward / gtf.class_compression_fused), which the connected-component labelling reads
+    import aggregation_layer as al
+    cat["mask"] = al.attach_fg_bits(cat["mask"].to(torch.int64).contiguous())
     n_inst = 6 * Bq                                           # vote-bench fixture: 6 instances per frame
     cap = 64 * Bq
 
@@ -685,7 +700,7 @@ def main():
         roof = vote_roofline(ctx["model_gpu"], ctx["cat"], ctx["n_inst"], max(5, min(args.steps, 20)),
                              f"batch {args.batch}, hn {args.hn}, {ctx['n_inst']} instances")
         roof["measured_copy_GBps"] = measure_copy_ceiling(dev)
-        attach_profiled_counters(roof, "r03_vote_bits_traffic_b1_hn1000.json" if (args.hn == 1000 and args.batch == 1) else None)
+        attach_profiled_counters(roof, "r04_vote_bits_traffic_b1_hn1000.json" if (args.hn == 1000 and args.batch == 1) else None)
         roof["note"] = ("HIP events on the launch stream around the whole call, live in this run; `traffic` and `valu` are PMC "
                         "counters of a separate profiled run of the same call (`from_profile` names the file and the commit it was "
                         "taken at): rocprofv3 cannot collect them inside this process")
@@ -729,8 +744,13 @@ def main():
             hp128.HV_NUM_OF_HYPOTHESES = 128
             cat32_cpu, _ = synth.make_vote_batch(range(32))
             cat32 = {k: v.to(dev) for k, v in cat32_cpu.items()}
+            import aggregation_layer as al
+            cat32["mask"] = al.attach_fg_bits(cat32["mask"].to(torch.int64).contiguous())
             line["roofline_hn128"] = vote_roofline(ctx["model_gpu"], cat32, 6 * 32, 9, "batch 32, hn 128, 192 instances", calls=10)
-            attach_profiled_counters(line["roofline_hn128"], "r03_vote_bits_traffic_b32_hn128.json")
+            attach_profiled_counters(line["roofline_hn128"], "r04_vote_bits_traffic_b32_hn128.json")
+            line["roofline_hn128_f32_masks"] = vote_roofline(ctx["model_gpu"], cat32, 6 * 32, 9, "batch 32, hn 128, 192 instances, f32 masks",
+                                                             calls=10, use_bits=False)
+            attach_profiled_counters(line["roofline_hn128_f32_masks"], "r04_vote_traffic_b32_hn128.json")
             line["post_network"] = post_network_rates(ctx["model_gpu"], ctx["cat"], ctx["n_inst"], cat32, 6 * 32)
             hp128.HV_NUM_OF_HYPOTHESES = args.hn
             del cat32
@@ -762,6 +782,10 @@ def main():
             if "backbone" in r3:
                 c3["backbone"] = r3["backbone"]
             c3["roofline"] = vote_roofline(ctx3["model_gpu"], ctx3["cat"], ctx3["n_inst"], 5, f"batch 32, hn {args.hn}, 192 instances", calls=10)
+            attach_profiled_counters(c3["roofline"], "r04_vote_bits_traffic_b32_hn1000.json" if args.hn == 1000 else None)
+            c3["roofline"]["bound_note"] = ("this configuration's count kernel is bound by vector-ALU issue, not HBM: 2 instructions per "
+                                            "(entry, hypothesis) register pair behind 1/512 MFMA, ~3.0e9 pairs per call (`valu`); "
+                                            "tools_dev/r4_vote_fused/README.md")
             line["configs"] = {"config3": c3}
     if world == 1 and not args.no_train_line and not args.vote_only:
         # BASELINE.json configs[4] at its per-GPU share (B = 8) on this GPU, so that the driver's run times it as well
