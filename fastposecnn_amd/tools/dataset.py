@@ -13,16 +13,26 @@ File decoding (:158-176: skimage.io.imread of `*_color.png` / `*_mask.png`, cv2.
 (csrc/png_decode.hip over zlib; libpng's headers are not in the image): `imread_png` returns what imread returns,
 `read_frame_files` mirrors the first lines of `__getitem__` (image, mask with background 255 -> 0, standardised depth),
 and `FrameUploader.upload_png` decodes a batch of colour files straight into its pinned staging slot on a few host
-threads.  The dataset walk, the meta+.json instance filtering and `generate_agg_data` stay out of scope (training-set
-ground truth; SURVEY.md 8: not on the hot path).
+threads.
+
+The ground-truth half of a dataset item (round 4, SURVEY.md 8f rank 3 remainder): `NOCSDataset` / `CAMERADataset` /
+`REALDataset` mirror F/tools/dataset.py:99-434 — the directory walk for `*_color.png` frames with wanted instances
+(:278-357), `__getitem__` (:138-272: file reads, `*_meta+.json`, distractor and class filtering of the instance mask, the
+per-instance ground truth of `generate_agg_data` :373-434, z <= 0 rejection, class mask, preprocessing chain) — and return the
+reference's sample dict key for key (pinned by tests/golden/nocs_sample.npz, which the reference's own class wrote:
+oracle/gen_golden.py).  `evaluate.py:148` and the training step feed `batchwise_find_matches` from exactly this dict.
+Augmentation is not mirrored (the reference has it commented out, :239-242).
 """
 import ctypes
 import os
+import pathlib
 
 import numpy as np
 import torch
 
 from fastposecnn_amd import _native as nat
+from fastposecnn_amd.tools import data_manipulation as dm
+from fastposecnn_amd.tools import json_tools as jt
 
 # segmentation_models_pytorch's preprocessing parameters for the resnet encoders with "imagenet" weights
 # (smp.encoders.get_preprocessing_params; upstream package, absent from the reference tree): RGB, range [0, 1]
@@ -226,6 +236,188 @@ class PngFramePrefetcher:
             self._pool.shutdown(wait=False)
             raise StopIteration
         return self._pending.pop(0).result()
+
+
+# ------------------------------------------------------------------------------------------------ ground-truth samples
+
+# F/tools/project.py:78-126
+CAMERA_CLASSES = ['bg', 'bottle', 'bowl', 'camera', 'can', 'laptop', 'mug']
+CAMERA_SYMMETRIC_CLASSES = ['bowl', 'can', 'bottle']
+REAL_SYMMETRIC_CLASSES = ['bowl', 'can', 'bottle']
+INTRINSICS = {'CAMERA': np.array([[577.5, 0, 319.5], [0., 577.5, 239.5], [0., 0., 1.]]),
+              'REAL': np.array([[591.0125, 0, 322.525], [0, 590.16775, 244.11084], [0, 0, 1]])}
+
+
+def smp_preprocess_input(x, mean=None, std=None, input_space="RGB", input_range=None, **kwargs):
+    """segmentation_models_pytorch's `preprocess_input` (encoders/_preprocessing.py; upstream package, absent from the
+    reference tree): the host-side form of what fpc_preprocess_u8 does on the device, float64 like numpy's defaults."""
+    if input_space == "BGR":
+        x = x[..., ::-1].copy()
+    if input_range is not None:
+        if x.max() > 1 and input_range[1] == 1:
+            x = x / 255.0
+    if mean is not None:
+        x = x - np.array(mean)
+    if std is not None:
+        x = x / np.array(std)
+    return x
+
+
+def get_preprocessing_fn(encoder_name="resnet18", pretrained="imagenet"):
+    """smp.encoders.get_preprocessing_fn (F/tools/dataset.py:567)."""
+    import functools
+    return functools.partial(smp_preprocess_input, **get_preprocessing_params(encoder_name, pretrained))
+
+
+def get_preprocessing(preprocessing_fn):
+    """F/tools/transforms/pose_regression.py:22-28 (an albumentations Compose of one Lambda on the image): a callable
+    `sample = f(**sample)` that applies preprocessing_fn to sample['image'] and passes every other key through."""
+    def apply(**sample):
+        sample = dict(sample)
+        sample['image'] = preprocessing_fn(sample['image'])
+        return sample
+    return apply
+
+
+def to_tensor(x, **kwargs):
+    """F/tools/transforms/general.py:7-8"""
+    return x.transpose(2, 0, 1) if len(x.shape) == 3 else x
+
+
+class NOCSDataset(torch.utils.data.Dataset):
+    """F/tools/dataset.py:99-434.  dataset_dir: a pathlib.Path (or str) searched recursively for `*_color.png` frames
+    whose `*_meta+.json` holds at least one instance of the wanted `classes` (names from CLASSES; default: all)."""
+
+    CLASSES = CAMERA_CLASSES
+    SYMMETRIC_CLASSES = CAMERA_SYMMETRIC_CLASSES
+    INTRINSICS = INTRINSICS['CAMERA']
+    CAMERA_MASKS = True            # masks are RGBA files whose first channel holds the instance ids (REAL: single channel)
+
+    def __init__(self, dataset_dir, max_size=None, classes=None, augmentation=None, preprocessing=None):
+        if classes is None:
+            classes = self.CLASSES
+        self.classes = classes
+        self.class_values_map = {self.CLASSES.index(cls.lower()): self.classes.index(cls) for cls in self.classes}
+        self.symmetric_classes = [self.classes.index(cls.lower()) for cls in self.SYMMETRIC_CLASSES if cls in self.classes]
+        self.images_fps = self.get_image_paths_in_dir(pathlib.Path(dataset_dir), max_size=max_size)
+        self.augmentation = augmentation
+        self.preprocessing = preprocessing
+
+    def __len__(self):
+        return len(self.images_fps)
+
+    def get_image_paths_in_dir(self, dir_path, max_size=None):
+        """breadth-first over the directory tree, colour frames of a directory in the file system's listing order"""
+        total, eval_paths, i = [], [dir_path], 0
+        while i < len(eval_paths):
+            eval_path = eval_paths[i]
+            i += 1
+            files = [x for x in eval_path.iterdir() if x.is_file()]
+            color_images = [x for x in files if x.name.find('color') != -1 and x.suffix == '.png']
+            total += self.remove_empty_samples(color_images)
+            eval_paths += [x for x in eval_path.iterdir() if x.is_dir()]
+            if max_size is not None and len(total) >= max_size:
+                break
+        total = [x for x in total if x]
+        return total[:max_size] if max_size is not None else total
+
+    def remove_empty_samples(self, file_paths):
+        good = []
+        for fp in file_paths:
+            json_data = jt.load_from_json(str(fp).replace('_color.png', '_meta+.json'))
+            if any(class_value in self.class_values_map for class_value in json_data['instance_dict'].values()):
+                good.append(fp)
+        return good
+
+    def __getitem__(self, i):
+        color_fp = str(self.images_fps[i])
+        image = imread_png(color_fp)
+        mask = imread_png(color_fp.replace('_color.png', '_mask.png'))
+        mask = (mask[:, :, 0] if self.CAMERA_MASKS else mask).astype('float')
+        mask[mask == 255] = 0                                      # background
+        depth = standardize_depth(imread_png(color_fp.replace('_color.png', '_depth.png')))
+        json_data = jt.load_from_json(color_fp.replace('_color.png', '_meta+.json'))
+
+        # distractor objects (ids the side file does not list) go
+        instances_mask = np.zeros_like(mask)
+        for instance_id in json_data['instance_dict'].keys():
+            instances_mask[mask == int(instance_id)] = int(instance_id)
+        # ... and so do instances of classes that are not wanted
+        good_json_data = {'instance_dict': {}}
+        good_instances_mask = np.zeros_like(instances_mask)
+        for enumerate_id, (id_value, class_id) in enumerate(json_data['instance_dict'].items()):
+            if class_id in self.class_values_map.keys():
+                good_instances_mask[instances_mask == int(id_value)] = int(id_value)
+                good_json_data['instance_dict'][int(id_value)] = self.class_values_map[class_id]
+                for key in json_data.keys():
+                    if key != 'instance_dict':
+                        good_json_data.setdefault(key, []).append(json_data[key][enumerate_id])
+        for key in good_json_data.keys():
+            if key != 'instance_dict':
+                good_json_data[key] = np.stack(good_json_data[key])
+
+        agg_data = self.generate_agg_data(good_instances_mask, good_json_data)
+        if (agg_data['z'] <= 0).any():                             # invalid / corrupt sample
+            return None
+
+        class_mask = np.zeros_like(good_instances_mask)
+        for instance_id, class_id in good_json_data['instance_dict'].items():
+            class_mask[good_instances_mask == int(instance_id)] = class_id
+
+        sample = {'clean_image': image, 'image': image, 'mask': class_mask, 'depth': depth}
+        if self.preprocessing:
+            sample = self.preprocessing(**sample)
+        sample['image'] = to_tensor(sample['image'])               # numpy_to_torch(): the image target only
+        if sample['image'].dtype != np.uint8:
+            sample['image'] /= np.max(np.abs(sample['image']))
+        sample.update({
+            'path': self.images_fps[i],
+            'image': sample['image'].astype(np.float32),           # skimage.img_as_float32 of a float array
+            'mask': sample['mask'].astype('long'),
+            'depth': sample['depth'].astype('float32'),
+            'agg_data': agg_data,
+        })
+        return sample
+
+    def get_random_batched_sample(self, batch_size=1, device=None):
+        ids = np.random.choice(np.arange(len(self)), size=batch_size, replace=False)
+        return my_collate_fn([self[int(k)] for k in ids], device)
+
+    def generate_agg_data(self, instances_mask, json_data):
+        """F/tools/dataset.py:373-434: per-instance ground truth in the order of the side file's instance_dict."""
+        h, w = instances_mask.shape
+        n = np.unique(instances_mask).shape[0] - 1
+        agg_data = {
+            'class_ids': np.zeros((n,)), 'symmetric_ids': np.zeros((n,)), 'instance_masks': np.zeros((n, h, w)),
+            'quaternion': np.zeros((n, 4)), 'scales': np.zeros((n, 3)), 'xy': np.zeros((n, 2)), 'z': np.zeros((n, 1)),
+            'T': np.zeros((n, 3)), 'R': np.zeros((n, 3, 3)), 'RT': np.zeros((n, 4, 4)),
+        }
+        json_data['quaternion'] = json_data['quaternions']
+        json_data['RT'] = json_data['RTs']
+        json_data.update(dm.extract_xyz_R_T_from_RTs(json_data['RTs'], self.INTRINSICS))
+        for enumerate_id, (instance_id, class_id) in enumerate(json_data['instance_dict'].items()):
+            for data_name in agg_data.keys():
+                if data_name == 'class_ids':
+                    agg_data[data_name][enumerate_id] = class_id
+                elif data_name == 'symmetric_ids':
+                    agg_data[data_name][enumerate_id] = 1 * (class_id in self.symmetric_classes)
+                elif data_name == 'instance_masks':
+                    agg_data[data_name][enumerate_id] = np.where(instances_mask == instance_id, 1, 0)
+                else:
+                    agg_data[data_name][enumerate_id] = np.array(json_data[data_name])[enumerate_id]
+        agg_data['scales'] /= np.expand_dims(json_data['norm_factors'], axis=1)
+        agg_data['xy'] = np.flip(agg_data['xy'], axis=1)           # (row, col) -> the other style
+        return agg_data
+
+
+class CAMERADataset(NOCSDataset):
+    pass
+
+
+class REALDataset(NOCSDataset):
+    SYMMETRIC_CLASSES = REAL_SYMMETRIC_CLASSES
+    INTRINSICS = INTRINSICS['REAL']
+    CAMERA_MASKS = False
 
 
 def my_collate_fn(batch, device=None):

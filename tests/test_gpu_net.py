@@ -269,6 +269,37 @@ def test_net_fullsize_vs_torch_modules(lib, dev, encoder, B):
     assert out["categorical"]["mask"].dtype == torch.int64 and tuple(out["categorical"]["z"].shape) == (B, 480, 640)
 
 
+def test_net_fullsize_config2_vs_float64(lib, dev):
+    """BASELINE.json configs[1] at the size the bench runs (ResNet18, B = 1, 640 x 480): the engine's logits against the
+    float64 CPU module path at north_star's 1e-4 of each tensor's scale — with the split-precision products the autotuner
+    may pick (the default) AND with plain f32 products only.  (The MIOpen comparison above is 2e-4 against a backend with
+    its own Winograd error; this is the reference arithmetic itself, ~15 s of float64 convolutions on the host.)"""
+    import copy
+    from fastposecnn_amd import synth
+    x = synth.make_image(0)[None]
+    m, hp = _model(lib, dev, "resnet18")
+    ref_m = copy.deepcopy(m).double()
+    ref_m.HPARAM = copy.copy(hp); ref_m.HPARAM.USE_NATIVE_ENGINE = False
+    with torch.no_grad():
+        ref = ref_m.pure_model_forward(x.double())
+    assert tuple(ref["mask"].shape) == (1, 7, 480, 640)
+    for split in (True, False):
+        m2, hp2 = _model(lib, dev, "resnet18")
+        hp2.ENGINE_SPLIT_PRECISION = split
+        m2 = m2.to(dev)
+        with torch.no_grad():
+            out = m2(x.to(dev))
+        assert m2._engines, "the native engine did not run"
+        plans = next(iter(m2._engines.values())).conv_plans()
+        assert split or not any(p[2] == -5 for p in plans)
+        for k in ("mask", "quaternion", "scales", "xy", "z"):
+            got = out["logits"][k].cpu().double()
+            err = (got - ref[k]).abs().max().item()
+            assert err <= 1e-4 * max(1.0, ref[k].abs().max().item()), (split, k, err, ref[k].abs().max().item())
+        del m2, out
+        torch.cuda.empty_cache()
+
+
 def test_engine_invalidation(lib, dev):
     """Packed weights are a snapshot keyed on (address, version) of every bound tensor: in-place updates, a
     load_state_dict on the model OR on a sub-module, and FrameStreamer's plan copies all pick the new values up
