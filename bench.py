@@ -215,12 +215,17 @@ def vote_roofline(model_gpu, cat, n_inst, reps, label, calls=10, use_bits=True):
     import torch
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
     ms = []
+    cover = torch.empty(96 << 20, dtype=torch.float32, device=cat["mask"].device)      # see below
     with torch.no_grad():
         for _ in range(reps):
             aggs = [model_gpu.aggregate(cat) for _ in range(calls)]
             if not use_bits:                                   # the stand-alone interface: f32 mask planes, no side channel
                 for agg in aggs:
                     agg["instance_masks"]._fpc_mask_bits = None
+            # a ~100 us fill in front of the first event: the GPU is busy while the host enqueues the first call, so the
+            # region does not start with the device waiting for Python (that idle time was 5-9 us per call of a 10-call
+            # group); it also leaves the inputs cold
+            cover.fill_(0.0)
             ev[0].record()
             for agg in aggs:
                 model_gpu.hough_voting(agg)

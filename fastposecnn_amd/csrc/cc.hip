@@ -182,9 +182,9 @@ __global__ __launch_bounds__(256) void k_cc_flatten(long long total, int32_t* __
         long long seg0 = g - lane;
         bool inseg = fg && p >= seg0 && p < g;
         int r = -1;
-        // a tile root (its own parent after k_cc_tile, unless a border union re-pointed it) walks with path halving; every
-        // other pixel starts at its tile root and only reads: the few writers shorten the chains the many readers follow,
-        // and the readers' loads of a shared chain hit in cache (all pixels halving at once: 24 us instead of 9 at 640 x 480)
+        // a pixel that is still its own parent is its component's root; a tile root that a border union re-pointed, like every
+        // other pixel, walks read-only from its tile root (p) — the chains cross tile borders only, and the readers' loads of
+        // a shared chain hit in cache (all pixels halving at once: 24 us instead of 9 at 640 x 480)
         if (fg && !inseg) r = (p == (int)g || L[p] == p) ? (p == (int)g ? cc_find_halve(L, (int)g) : p) : cc_find(L, p);
         for (int k = 0; k < 8; ++k) {      // in-segment chains are one link deep unless runs of one row were united
             int pr = __shfl(r, inseg ? (int)(p - seg0) : lane, kWave);

@@ -31,23 +31,44 @@ struct GnArgs {
     float eps;
 };
 
-// sums of the chunk's values and squares per group (= channel quad)
+// per group (= channel quad) of the chunk: the sum of its values and the sum of squares ABOUT THE CHUNK'S OWN MEAN (second sweep,
+// served by the caches).  E[x^2] - mean^2 from plain sums loses every digit once |mean| >> std (activations with a large
+// offset: the variance clamped to 0 and rstd blown up where torch's Welford form is exact); per-chunk centred sums combined
+// by Chan's formula in double do not.
 __global__ __launch_bounds__(256) void k_gn4_stats(const GnArgs a) {
     __shared__ float red[256][2];
+    __shared__ float s_mean[64];
     const int t = threadIdx.x, Q = a.Q, q = t % Q, r = t / Q, R = 256 / Q;
     const int chunk = blockIdx.x, b = blockIdx.y;
     const int p0 = chunk * kGnChunk, p1 = min(a.HW, p0 + kGnChunk);
-    float s = 0.f, ss = 0.f;
+    float s = 0.f;
     for (int p = p0 + r; p < p1; p += R) {
         const f32x4 v = *reinterpret_cast<const f32x4*>(a.x + ((size_t)b * a.HW + p) * a.C + 4 * q);
         s += (v[0] + v[1]) + (v[2] + v[3]);
-        ss += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
     }
-    red[t][0] = s; red[t][1] = ss;
+    red[t][0] = s;
+    __syncthreads();
+    double ds = 0.0;
+    if (r == 0) {
+        for (int k = 0; k < R; ++k) ds += red[k * Q + q][0];
+        ds = (double)(float)ds;                                   // the partial as it is stored: the fold recomputes this very mean
+        s_mean[q] = (float)(ds / (4.0 * (p1 - p0)));
+    }
+    __syncthreads();
+    const float m = s_mean[q];
+    float ss = 0.f;
+    for (int p = p0 + r; p < p1; p += R) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(a.x + ((size_t)b * a.HW + p) * a.C + 4 * q);
+        const float d0 = v[0] - m, d1 = v[1] - m, d2 = v[2] - m, d3 = v[3] - m;
+        ss += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+    }
+    red[t][1] = ss;
     __syncthreads();
     if (r == 0) {
-        double ds = 0.0, dss = 0.0;
-        for (int k = 0; k < R; ++k) { ds += red[k * Q + q][0]; dss += red[k * Q + q][1]; }
+        double dss = 0.0;
+        for (int k = 0; k < R; ++k) dss += red[k * Q + q][1];
+        // the centred sum is about the ROUNDED chunk mean m: sum (x - m)^2 = M2 + n (mean_c - m)^2, folded back below through
+        // the exact identity with the stored sum
         float* o = a.part + (((size_t)b * a.chunks + chunk) * Q + q) * 2;
         o[0] = (float)ds; o[1] = (float)dss;
     }
@@ -57,13 +78,18 @@ __global__ __launch_bounds__(256) void k_gn4_stats(const GnArgs a) {
 __device__ __forceinline__ void gn4_fold_stats(const GnArgs& a, int b, float (*st)[2], bool publish) {
     const int t = threadIdx.x;
     if (t < a.Q) {
-        double s = 0.0, ss = 0.0;
+        double s = 0.0;
+        for (int k = 0; k < a.chunks; ++k) s += a.part[(((size_t)b * a.chunks + k) * a.Q + t) * 2];
+        const double n = 4.0 * a.HW, mean = s / n;
+        // sum (x - mean)^2 = sum_c [ sum (x - m_c)^2 + 2 (m_c - mean) (sum_c - n_c m_c) + n_c (m_c - mean)^2 ],  m_c = the f32 chunk mean
+        double m2 = 0.0;
         for (int k = 0; k < a.chunks; ++k) {
             const float* o = a.part + (((size_t)b * a.chunks + k) * a.Q + t) * 2;
-            s += o[0]; ss += o[1];
+            const double nc = 4.0 * (min(a.HW, (k + 1) * kGnChunk) - k * kGnChunk);
+            const double mc = (double)(float)((double)o[0] / nc), d = mc - mean;
+            m2 += (double)o[1] + 2.0 * d * ((double)o[0] - nc * mc) + nc * d * d;
         }
-        const double n = 4.0 * a.HW, mean = s / n;
-        double var = ss / n - mean * mean;
+        double var = m2 / n;
         if (var < 0.0) var = 0.0;
         st[t][0] = (float)mean;
         st[t][1] = (float)(1.0 / sqrt(var + (double)a.eps));

@@ -90,6 +90,9 @@ int unfilter(uint8_t* raw, const PngHeader& h) {
 int inflate_scanlines(const uint8_t* d, size_t n, const PngHeader& h, std::vector<uint8_t>& raw, uint8_t* palette /*[768]*/,
                       int* palette_n) {
     const size_t stride = (size_t)h.w * h.bpp;
+    // the header alone must not size a multi-gigabyte buffer (a 60-byte file can claim 65535 x 65535 x 8): frames of this
+    // path are megabytes; beyond 1 GiB of scanlines the file is refused (also keeps zlib's 32-bit avail_out exact)
+    if ((size_t)h.h * (stride + 1) > ((size_t)1 << 30)) return FPC_EFORMAT;
     raw.resize((size_t)h.h * (stride + 1));
     z_stream zs;
     memset(&zs, 0, sizeof(zs));
@@ -130,7 +133,18 @@ int inflate_scanlines(const uint8_t* d, size_t n, const PngHeader& h, std::vecto
 
 // mode 0: samples as stored ([H, W, C] u8, or u16 in HOST byte order for 16-bit files; a palette is expanded to RGB8);
 // mode 3: 8-bit RGB whatever the file holds (grey replicated, alpha dropped, 16-bit samples by their high byte)
+int decode_one_unguarded(const uint8_t* d, size_t n, void* out, size_t out_bytes, int mode);
+
+// no exception may cross the C boundary (or unwind out of a worker thread): an allocation failure is a format error here
 int decode_one(const uint8_t* d, size_t n, void* out, size_t out_bytes, int mode) {
+    try {
+        return decode_one_unguarded(d, n, out, out_bytes, mode);
+    } catch (...) {
+        return FPC_EFORMAT;
+    }
+}
+
+int decode_one_unguarded(const uint8_t* d, size_t n, void* out, size_t out_bytes, int mode) {
     PngHeader h;
     int rc = parse_header(d, n, h);
     if (rc != FPC_OK) return rc;

@@ -565,6 +565,25 @@ def test_native_groupnorm_relu_forward_and_backward_vs_float64(case):
         close(gn.bias.grad, ref.bias.grad, "dbeta", 1e-4)
 
 
+def test_native_groupnorm_statistics_survive_a_large_offset():
+    """activations with |mean| >> std.  E[x^2] - mean^2 from f32 partial sums cancels to nothing there (variance
+    clamped to 0, rstd blown up); the per-chunk centred sums combined by Chan's formula track the float64 statistics."""
+    from fastposecnn_amd.lib import train_conv
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(3)
+    B, C, H, W = 2, 128, 40, 56
+    x = torch.randn((B, C, H, W), generator=g) * 0.05 + 100.0
+    gn = torch.nn.GroupNorm(C // 4, C)
+    ref = torch.nn.GroupNorm(C // 4, C).double()
+    want = torch.relu(ref(x.double()))
+    y = train_conv.groupnorm_relu(x.to(dev).contiguous(memory_format=torch.channels_last), gn.to(dev))
+    torch.cuda.synchronize()
+    # x itself carries 100 * 2^-24 = 6e-6 of f32 rounding against a spread of 0.05: 2e-4 of a normalised unit
+    err = (y.cpu().double() - want).abs().max().item()
+    assert err <= 2e-3, err
+    assert abs(y.cpu().double().std().item() - want.std().item()) <= 1e-3
+
+
 def test_fpn_block_fused_lateral_conv_and_merge_matches_float64():
     """FPNBlock in training mode: skip_conv(skip) + nearest_x2(top) as one native launch (train_conv.conv2d_up_add), forward
     and all three gradients against the same block in float64."""
