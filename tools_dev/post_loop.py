@@ -13,7 +13,7 @@ a = ap.parse_args()
 dev = torch.device("cuda:0")
 cat = {k: v.to(dev) for k, v in synth.make_vote_batch(range(a.frames))[0].items()}
 layer = al.AggregationLayer(None, 7)
-cm = cat["mask"].to(torch.int64).contiguous()
+cm = al.attach_fg_bits(cat["mask"].to(torch.int64).contiguous())      # as the class compression hands it over
 for _ in range(10):
     labels, n_dev = layer.batchwise_break_segmentation_mask(cm, return_device_count=True)
     layer._aggregate(cat, cm, labels, 6 * a.frames, n_dev)
