@@ -6,9 +6,15 @@ autograd.Function over three native pieces, all on channel-last (NHWC) activatio
 
   forward        fpc_conv2d: the inference engine's implicit-GEMM / Winograd kernels (csrc/net_kernels.hip), bias fused
   data gradient  stride 1: the SAME kernels on the flipped, transposed weights (a convolution of dy);
-                 stride 2 (three encoder convolutions, their 1x1 shortcuts) and the 7x7 stem: aten's backward
+                 stride 2 (three encoder convolutions, their 1x1 shortcuts): the same kernels once per output parity
+                 (round 4: dx[2a + r] only sees the taps of parity r — 1, 2, 2 and 4 of a 3x3 kernel's nine — so four small
+                 stride-1 convolutions of dy write the four interleaved quarter planes; no zero-insertion, 13/9 of the
+                 minimal multiply-adds);  heads whose width is not a multiple of 32: dy and W zero-padded to 32 channels
   weight gradient  fpc_conv2d_wgrad (csrc/conv_wgrad.hip): pixels-as-K GEMM on the f32 matrix cores, fixed-order
-                 split over the pixels; Cin % 64 != 0 (stem) or Cout % 4 != 0 (odd-width heads): aten's backward
+                 split over the pixels; a width that is not a multiple of 4 (mask / scales / xyz heads) is padded likewise
+The 7x7 stem (Cin = 3) is the one convolution left to torch, forward and backward: its input needs no gradient and its
+weight gradient is a K = 147 GEMM no tile of these kernels fits (counted neither as native nor as aten below: it never
+enters this module's autograd functions).
 
 The tiling / Winograd form of a shape is chosen once, by timing the candidates on the first call with that shape (this
 synchronises: it happens in the warm-up steps).  f32 operands, accumulation and results, products in plain f32 or as the
@@ -77,18 +83,65 @@ def _native_forward_ok(x, w):
     return w.shape[1] % 32 == 0 and w.shape[2] == w.shape[3]
 
 
+def _dgrad_stride2(gy, w, H, W, pad):
+    """dx [B,Cin,H,W] of a stride-2 convolution (1x1 pad 0, or 3x3 pad 1; H, W even) from dy [B,Cout,H/2,W/2]:
+    y[i] = sum_k x[2 i + k - pad] w[k]  =>  dx[2 a] = dy[a] w[1],  dx[2 a + 1] = dy[a] w[2] + dy[a + 1] w[0]  per axis (3x3), i.e.
+    per output parity (ry, rx) a 2-tap correlation of dy (zero past its end) with taps g_even = (w[1], 0), g_odd = (w[2], w[0])."""
+    B, Cout, Ho, Wo = gy.shape
+    Cin, K = w.shape[1], w.shape[2]
+    gx = torch.empty((B, Cin, H, W), dtype=torch.float32, device=gy.device, memory_format=torch.channels_last)
+    wt = w.transpose(0, 1)                                              # [Cin, Cout, K, K]: output channels of the dgrad first
+    if K == 1:
+        gx.zero_()
+        gx[:, :, ::2, ::2] = conv_nhwc(gy, wt.contiguous(), None, 1, 0)
+        return gx
+    gyp = torch.nn.functional.pad(gy, (0, 1, 0, 1))                     # one zero row / column past the end (channel-last stays)
+    gyp = _channels_last(gyp)
+    taps = ((1, None), (2, 0))                                           # parity -> kernel index of tap t = 0, 1 (None: no tap)
+    for ry in range(2):
+        for rx in range(2):
+            if ry == 0 and rx == 0:
+                out = conv_nhwc(gy, wt[:, :, 1:2, 1:2].contiguous(), None, 1, 0)
+            else:
+                g = torch.zeros((Cin, Cout, 2, 2), dtype=torch.float32, device=gy.device)
+                for ty, ky in enumerate(taps[ry]):
+                    for tx, kx in enumerate(taps[rx]):
+                        if ky is not None and kx is not None:
+                            g[:, :, ty, tx] = wt[:, :, ky, kx]
+                out = conv_nhwc(gyp, g, None, 1, 0)
+            gx[:, :, ry::2, rx::2] = out
+    return gx
+
+
 def _conv_backward(x, w, gy, stride, pad, needs, has_bias):
     """(dx, dW, db) of a convolution whose forward ran on the native kernels; needs = (x, W, bias) wanted."""
     Cout, Cin, Kh, Kw = w.shape
     gy = _channels_last(gy)
     need_x, need_w = needs[0], needs[1]
     gx = gw = gb = None
-    aten_x = need_x and not (stride == 1 and Cout % 32 == 0 and pad <= Kh - 1)
-    aten_w = need_w and not (Cin % 64 == 0 and Cout % 4 == 0)
+    if has_bias and needs[2]:
+        gb = gy.sum((0, 2, 3))
+    # a width the kernels' tiles do not divide (the heads: 7, 18, 24 channels): zero-padded copies of dy and W — the extra
+    # channels contribute nothing to dx and their rows of dW are dropped
+    w_full = w
+    if (need_x and Cout % 32 != 0) or (need_w and Cout % 4 != 0):
+        Cp = (Cout + 31) // 32 * 32
+        gyp = torch.zeros((gy.shape[0], Cp, gy.shape[2], gy.shape[3]), dtype=torch.float32, device=gy.device, memory_format=torch.channels_last)
+        gyp[:, :Cout] = gy
+        wp = torch.zeros((Cp, Cin, Kh, Kw), dtype=torch.float32, device=w.device)
+        wp[:Cout] = w
+        gy, w = gyp, wp
+    Cw = w.shape[0]
+    s2_native = (stride == 2 and pad == (Kh - 1) // 2 and Kh in (1, 3) and x.shape[2] % 2 == 0 and x.shape[3] % 2 == 0)
+    aten_x = need_x and not ((stride == 1 and pad <= Kh - 1) or s2_native)
+    aten_w = need_w and Cin % 64 != 0
     if need_x and not aten_x:
-        # dx = conv(dy, W'), W'[ci][co][kh][kw] = W[co][ci][K-1-kh][K-1-kw], padding K-1-pad
-        w2 = w.flip(2, 3).transpose(0, 1).contiguous() if Kh > 1 else w.transpose(0, 1).contiguous()
-        gx = conv_nhwc(gy, w2, None, 1, Kh - 1 - pad)
+        if stride == 1:
+            # dx = conv(dy, W'), W'[ci][co][kh][kw] = W[co][ci][K-1-kh][K-1-kw], padding K-1-pad
+            w2 = w.flip(2, 3).transpose(0, 1).contiguous() if Kh > 1 else w.transpose(0, 1).contiguous()
+            gx = conv_nhwc(gy, w2, None, 1, Kh - 1 - pad)
+        else:
+            gx = _dgrad_stride2(gy, w, x.shape[2], x.shape[3], pad)
         counters["dgrad_native"] += 1
     if need_w and not aten_w:
         L = nat.lib()
@@ -96,20 +149,20 @@ def _conv_backward(x, w, gy, stride, pad, needs, has_bias):
         Ho, Wo = gy.shape[2], gy.shape[3]
         gw = torch.empty_like(w)
         sb, sc, sh, sw = x.stride()
-        ws = nat.workspace("train_wgrad", x.device, L.fpc_conv2d_wgrad_workspace_bytes(B, Ho, Wo, Cin, Cout, Kh, Kw))
+        ws = nat.workspace("train_wgrad", x.device, L.fpc_conv2d_wgrad_workspace_bytes(B, Ho, Wo, Cin, Cw, Kh, Kw))
         wgrad = L.fpc_conv2d_wgrad_split if SPLIT_PRECISION else L.fpc_conv2d_wgrad
-        nat.check(wgrad(x.data_ptr(), sb, sh, sw, gy.data_ptr(), gw.data_ptr(), B, H, W, Cin, Cout, Kh, Kw, stride,
+        nat.check(wgrad(x.data_ptr(), sb, sh, sw, gy.data_ptr(), gw.data_ptr(), B, H, W, Cin, Cw, Kh, Kw, stride,
                         pad, ws.data_ptr(), ws.numel(), nat.stream()), "fpc_conv2d_wgrad")
+        if Cw != Cout:
+            gw = gw[:Cout].contiguous()
         counters["wgrad_native"] += 1
     if aten_x or aten_w:
-        ax, aw, _ = torch.ops.aten.convolution_backward(gy, x, w, None, [stride, stride], [pad, pad], [1, 1], False, [0, 0], 1,
-                                                        [aten_x, aten_w, False])
+        ax, aw, _ = torch.ops.aten.convolution_backward(gy[:, :Cout] if Cw != Cout else gy, x, w_full, None, [stride, stride], [pad, pad],
+                                                        [1, 1], False, [0, 0], 1, [aten_x, aten_w, False])
         if aten_x:
             gx = ax; counters["dgrad_aten"] += 1
         if aten_w:
             gw = aw; counters["wgrad_aten"] += 1
-    if has_bias and needs[2]:
-        gb = gy.sum((0, 2, 3))
     return gx, gw, gb
 
 

@@ -3,9 +3,9 @@ batch 8 per GPU (64 on 8 GPUs), forward + HEAD_TRAINING losses + backward + grad
 
 What runs where (stated in the JSON line as well):
   * encoder / decoder / head convolutions: lib/train_conv.py — forward on the engine's implicit-GEMM / Winograd kernels,
-    data gradient of the stride-1 convolutions on the same kernels (flipped weights), weight gradient on
-    csrc/conv_wgrad.hip; aten (MIOpen) keeps the 7x7 stem, the data gradient of the stride-2 convolutions and the
-    odd-width heads; bilinear upsampling forward / backward on csrc/upsample.hip; BatchNorm / GroupNorm / ReLU / adds: torch
+    data gradient on the same kernels (stride 1: flipped weights; stride 2: four parity convolutions of dy; heads of odd
+    width: zero-padded to 32 channels), weight gradient on csrc/conv_wgrad.hip; torch keeps the 7x7 stem (Cin = 3);
+    bilinear upsampling forward / backward on csrc/upsample.hip; BatchNorm / GroupNorm / ReLU / adds: torch
     (FPC_TRAIN_NATIVE_CONV=0 returns every convolution and upsampling to torch: the A/B this file's numbers come with);
   * everything after the logits, forward: the inference kernels (class compression, connected components, aggregation,
     RANSAC vote, RT); backward: csrc/train.hip through lib/train_functions.py;
@@ -60,9 +60,10 @@ def _conv_note():
     if not train_conv.ENABLED:
         return "torch modules (MIOpen / rocBLAS) forward and backward (FPC_TRAIN_NATIVE_CONV=0)"
     c = train_conv.counters
-    return ("native: forward fpc_conv2d (implicit GEMM / Winograd), data gradient of stride-1 convolutions on the same kernels, weight "
-            "gradient fpc_conv2d_wgrad, bilinear upsampling fpc_upsample_bilinear_fwd/bwd; aten for the 7x7 stem, stride-2 data "
-            f"gradients and odd-width heads (calls so far: {dict(c)})")
+    return ("native: forward fpc_conv2d (implicit GEMM / Winograd), data gradient on the same kernels (stride 2: four parity "
+            "convolutions of dy; odd-width heads zero-padded), weight gradient fpc_conv2d_wgrad, bilinear upsampling "
+            "fpc_upsample_bilinear_fwd/bwd; torch for the 7x7 stem alone (Cin = 3: outside these counters) "
+            f"(calls so far: {dict(c)})")
 
 
 def main(args):

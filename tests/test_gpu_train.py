@@ -314,12 +314,15 @@ def test_fused_mask_losses_match_torch_forms(monkeypatch):
 TRAIN_CONV_CASES = [
     # B, Cin, H, W, Cout, k, stride, pad, bias
     (2, 64, 30, 40, 64, 3, 1, 1, False),        # encoder block: Winograd candidates forward and for the data gradient
-    (2, 64, 30, 40, 128, 3, 2, 1, False),       # stride 2: data gradient through aten, weight gradient native
+    (2, 64, 30, 40, 128, 3, 2, 1, False),       # stride 2: data gradient as four parity convolutions of dy (round 4)
     (2, 64, 30, 40, 128, 1, 2, 0, False),       # 1x1 shortcut, stride 2
+    (2, 128, 16, 24, 256, 3, 2, 1, True),       # stride 2 deeper in the encoder
+    (2, 64, 15, 20, 128, 3, 2, 1, False),       # odd height: the parity form does not apply, aten's data gradient
     (3, 128, 15, 20, 256, 1, 1, 0, True),       # FPN lateral: 1x1 + bias
     (2, 256, 15, 20, 128, 3, 1, 1, False),      # decoder block
-    (1, 128, 17, 23, 7, 1, 1, 0, True),         # odd-width head: both gradients through aten
-    (1, 128, 17, 23, 24, 1, 1, 0, True),        # head with Cout % 4 == 0 but not % 32: weight gradient native, data gradient aten
+    (1, 128, 17, 23, 7, 1, 1, 0, True),         # odd-width head: dy and W zero-padded to 32 channels, both gradients native (round 4)
+    (1, 128, 17, 23, 24, 1, 1, 0, True),        # head with Cout % 4 == 0 but not % 32
+    (2, 128, 12, 16, 18, 1, 1, 0, True),        # scales / xyz heads
     (2, 64, 9, 11, 68, 3, 1, 1, True),          # Cout not a multiple of the 64-row tile, pixel count not a multiple of 32
     (2, 256, 6, 8, 256, 3, 1, 1, False),        # the small maps of a 96 x 128 input: fewer pixels than one tile
     (2, 512, 3, 4, 512, 3, 1, 1, False),
@@ -359,10 +362,11 @@ def test_training_conv_forward_and_gradients_vs_float64_autograd(case):
     close(wd.grad, wr.grad, "dw", 1e-4)          # sums over B*Ho*Wo pixels in f32
     if has_bias:
         close(bd.grad, br.grad, "db", 1e-4)
-    native_w = Cin % 64 == 0 and Cout % 4 == 0
-    native_x = stride == 1 and Cout % 32 == 0
+    native_w = Cin % 64 == 0
+    native_x = stride == 1 or (H % 2 == 0 and W % 2 == 0)
     assert train_conv.counters["wgrad_native"] - before["wgrad_native"] == int(native_w)
     assert train_conv.counters["dgrad_native"] - before["dgrad_native"] == int(native_x)
+    assert train_conv.counters["dgrad_aten"] - before["dgrad_aten"] == int(not native_x)
 
 
 def test_wgrad_is_deterministic_and_refuses_unsupported_shapes():
@@ -472,6 +476,7 @@ def test_training_mode_model_uses_native_convolutions_and_matches_torch_path():
     lt, ot, gt, unused = res["torch32"]
     lr, orf, gr, _ = res["torch64"]
     assert used["fwd_native"] >= 50 and used["wgrad_native"] >= 45 and used["dgrad_native"] >= 40, used
+    assert used["dgrad_aten"] == 0 and used["wgrad_aten"] == 0, used      # round 4: stride-2 data gradients and odd-width heads native too
     assert unused["fwd_native"] == 0
     assert abs(ln - lr) <= 1e-5 * max(1.0, abs(lr))
     for k in orf:
