@@ -126,7 +126,8 @@ def _conv_backward(x, w, gy, stride, pad, needs, has_bias):
     w_full = w
     if (need_x and Cout % 32 != 0) or (need_w and Cout % 4 != 0):
         Cp = (Cout + 31) // 32 * 32
-        gyp = torch.zeros((gy.shape[0], Cp, gy.shape[2], gy.shape[3]), dtype=torch.float32, device=gy.device, memory_format=torch.channels_last)
+        gyp = torch.empty((gy.shape[0], Cp, gy.shape[2], gy.shape[3]), dtype=torch.float32, device=gy.device, memory_format=torch.channels_last)
+        gyp[:, Cout:] = 0.0
         gyp[:, :Cout] = gy
         wp = torch.zeros((Cp, Cin, Kh, Kw), dtype=torch.float32, device=w.device)
         wp[:Cout] = w
