@@ -52,6 +52,9 @@ cats = []
 for i in range(K):
     c, _ = synth.make_vote_batch(range(i, i + 1))
     cats.append({k: v.to(dev) for k, v in c.items()})
+    if not os.environ.get("SOAK_NO_FG_BITS"):      # as the class compression hands the mask over: with its foreground bit words
+        import aggregation_layer as _al3
+        cats[-1]["mask"] = _al3.attach_fg_bits(cats[-1]["mask"].to(torch.int64).contiguous())
 st = FrameStreamer(model)
 nplan = len(st.models)
 
