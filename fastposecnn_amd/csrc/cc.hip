@@ -614,7 +614,11 @@ static int cca_run(const unsigned long long* bits, size_t bstride, int B, int H,
     a.wpr_inv = a.wpr > 1 ? (unsigned)((1ull << 32) / (unsigned)a.wpr + 1) : 0u;       // exact quotients below 2^16 (cca_eligible: nwords < 10 000); wpr = 1: see cca_div
     a.wbase = w.wbase; a.runlabel = w.runlabel; a.gparent = w.gparent; a.ncomp = w.ncomp; a.rstride = w.rstride;
     const size_t fixed = (size_t)a.nwords * 12;
+#ifndef FPC_CCA_PARENTS
+#define FPC_CCA_PARENTS 0
+#endif
     a.cap = (int)std::min<size_t>((kCcaLdsBytes - 1024 - fixed) / 4, w.rstride);
+    if (FPC_CCA_PARENTS > 0) a.cap = std::min(a.cap, FPC_CCA_PARENTS);
     const size_t lds = fixed + (size_t)a.cap * 4;
     hipLaunchKernelGGL(k_cca_image, dim3(B), dim3(kCcaThreads), lds, s, a);
     hipLaunchKernelGGL(k_cca_label, dim3(cdiv(a.nwords, 64), B), dim3(256), 0, s, a, labels, n_out, root_pix, cap);
