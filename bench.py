@@ -28,7 +28,7 @@ every rank runs its own frames; `value` = N * B * K / max-over-ranks(time).
 Extra objects on the JSON line:
   roofline          the hough-vote launch sequence at the headline config, as the model's pipeline calls it (the aggregation
                     layer's mask bit words: fpc_ransac_voting_v3_bits): algorithmic bytes n_instances * 12*H*W per call /
-                    HIP-event time of 10 back-to-back calls on cold inputs, against the 8 TB/s HBM peak of MI355X_MICROARCH.md;
+                    HIP-event device time of 10 calls on cold inputs (graph replay), against the 8 TB/s HBM peak of MI355X_MICROARCH.md;
                     `traffic` and `valu` are PMC counters of a separately profiled run (`from_profile` names file and commit:
                     profiles/r04_vote_bits_traffic_*.json)
   roofline_hn128    the same sequence at the training value hn = 128 (F/config.py:93) on a 32-frame batch (192 instances)
@@ -207,32 +207,55 @@ def cpu_baseline(model_cpu, image, cat_cpu, hn, inv_k, encoder):
             "value_1_thread_post": round(1.0 / (t_net + t_post1), 4)}
 
 
-def vote_roofline(model_gpu, cat, n_inst, reps, label, calls=10, use_bits=True):
-    """Average duration of the hough-voting launch sequence: HIP events on the launch stream around `calls` back-to-back
-    enqueues of the call (its inputs produced just before), divided by `calls`; median over `reps` such groups.  Back to
-    back, the host's enqueue time hides behind the previous call's kernels, so this is the device time of the sequence —
-    what the rocprofv3 kernel trace of the same call adds up to (profiles/)."""
+def vote_roofline(model_gpu, cat, n_inst, reps, label, calls=30, use_bits=True):
+    """Average DEVICE time of the hough-voting launch sequence: `calls` enqueues of the call — each on its own freshly
+    aggregated (cold) inputs — are captured into a HIP graph and the replay is bracketed by HIP events on its stream;
+    median over `reps` replays, divided by `calls`.  This is what the rocprofv3 kernel trace of the same call adds up to
+    (profiles/).  30 calls per group: a replay carries ~0.1 ms of fixed launch / completion cost (10 calls: 155 us per call
+    on the 32-frame f32 sequence, 30 calls: 147-148, two-point slope: 143.5; tools_dev/vote_bench_method.py).  (Until round 4 the calls were enqueued eagerly back to back: the Python wrapper costs ~150 us of host time
+    per call, as much as the 32-frame sequence itself, so that figure measured the wrapper — 155 us where the launch loop
+    of tools_dev/vote_loop.py and the kernel trace say 146.  Eager enqueue stays as the fallback if capture fails.)"""
     import torch
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
     ms = []
-    cover = torch.empty(96 << 20, dtype=torch.float32, device=cat["mask"].device)      # see below
+    mode = "HIP-graph replay of the captured calls (device time)"
     with torch.no_grad():
-        for _ in range(reps):
-            aggs = [model_gpu.aggregate(cat) for _ in range(calls)]
-            if not use_bits:                                   # the stand-alone interface: f32 mask planes, no side channel
-                for agg in aggs:
-                    agg["instance_masks"]._fpc_mask_bits = None
-            # a ~100 us fill in front of the first event: the GPU is busy while the host enqueues the first call, so the
-            # region does not start with the device waiting for Python (that idle time was 5-9 us per call of a 10-call
-            # group); it also leaves the inputs cold
-            cover.fill_(0.0)
-            ev[0].record()
+        aggs = [model_gpu.aggregate(cat) for _ in range(calls)]
+        if not use_bits:                                       # the stand-alone interface: f32 mask planes, no side channel
             for agg in aggs:
-                model_gpu.hough_voting(agg)
+                agg["instance_masks"]._fpc_mask_bits = None
+        inputs = [(agg["instance_masks"], agg["xy"]) for agg in aggs]      # hough_voting replaces agg['xy']: keep the planes alive
+        graph = None
+        try:
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                model_gpu.hough_voting(dict(aggs[0]))                        # workspace and allocator pools warm
+                side.synchronize()
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph, stream=side):
+                    outs = [model_gpu.hough_voting(dict(agg)) for agg in aggs]
+            torch.cuda.current_stream().wait_stream(side)
+        except Exception as e:      # noqa: BLE001 - any capture problem: measure eagerly
+            print(f"vote_roofline: graph capture unavailable ({type(e).__name__}: {e}); eager timing", file=sys.stderr)
+            graph = None
+            mode = "eager back-to-back enqueues (host-bound above ~150 us per call)"
+        cover = torch.empty(256 << 20, dtype=torch.float32, device=cat["mask"].device)
+        for _ in range(reps):
+            # the device is busy (~0.4 ms of fills) while the host gets to the graph launch: the region does not start with
+            # the device waiting for it (a replay's launch latency was ~100 us of a 10-call group otherwise)
+            cover.fill_(0.0)
+            cover.fill_(1.0)
+            ev[0].record()
+            if graph is not None:
+                graph.replay()
+            else:
+                for agg in aggs:
+                    model_gpu.hough_voting(dict(agg))
             ev[1].record()
             ev[1].synchronize()
             ms.append(ev[0].elapsed_time(ev[1]) / calls)
-            del aggs
+        del aggs, inputs
     t = median(ms) * 1e-3
     alg = n_inst * 12 * H * W
     ach = alg / t / 1e9
@@ -246,7 +269,7 @@ def vote_roofline(model_gpu, cat, n_inst, reps, label, calls=10, use_bits=True):
                            "f32 mask planes through the reference's own interface (ransac_voting_layer_v3(mask, vertex, ...)): every "
                            "algorithmic byte is read",
             "workload": label, "algorithmic_bytes_per_launch": alg, "launch_ms": round(t * 1e3, 4),
-            "timing": f"HIP events around {calls} back-to-back calls on the launch stream / {calls}, median of {reps}"}
+            "timing": f"HIP events around {calls} calls on distinct cold inputs / {calls}, median of {reps}: {mode}"}
 
 
 def post_network_rates(model_gpu, cat1, n1, cat32, n32, reps=15, calls=6):
@@ -751,10 +774,10 @@ def main():
             cat32 = {k: v.to(dev) for k, v in cat32_cpu.items()}
             import aggregation_layer as al
             cat32["mask"] = al.attach_fg_bits(cat32["mask"].to(torch.int64).contiguous())
-            line["roofline_hn128"] = vote_roofline(ctx["model_gpu"], cat32, 6 * 32, 9, "batch 32, hn 128, 192 instances", calls=10)
+            line["roofline_hn128"] = vote_roofline(ctx["model_gpu"], cat32, 6 * 32, 9, "batch 32, hn 128, 192 instances")
             attach_profiled_counters(line["roofline_hn128"], "r04_vote_bits_traffic_b32_hn128.json")
             line["roofline_hn128_f32_masks"] = vote_roofline(ctx["model_gpu"], cat32, 6 * 32, 9, "batch 32, hn 128, 192 instances, f32 masks",
-                                                             calls=10, use_bits=False)
+                                                             use_bits=False)
             attach_profiled_counters(line["roofline_hn128_f32_masks"], "r04_vote_traffic_b32_hn128.json")
             line["post_network"] = post_network_rates(ctx["model_gpu"], ctx["cat"], ctx["n_inst"], cat32, 6 * 32)
             hp128.HV_NUM_OF_HYPOTHESES = args.hn
@@ -786,7 +809,7 @@ def main():
                              "ms_per_step_one_in_flight": r3["ms_per_frame_one_in_flight"]}}
             if "backbone" in r3:
                 c3["backbone"] = r3["backbone"]
-            c3["roofline"] = vote_roofline(ctx3["model_gpu"], ctx3["cat"], ctx3["n_inst"], 5, f"batch 32, hn {args.hn}, 192 instances", calls=10)
+            c3["roofline"] = vote_roofline(ctx3["model_gpu"], ctx3["cat"], ctx3["n_inst"], 5, f"batch 32, hn {args.hn}, 192 instances")
             attach_profiled_counters(c3["roofline"], "r04_vote_bits_traffic_b32_hn1000.json" if args.hn == 1000 else None)
             c3["roofline"]["bound_note"] = ("this configuration's count kernel is bound by vector-ALU issue, not HBM: 2 instructions per "
                                             "(entry, hypothesis) register pair behind 1/512 MFMA, ~3.0e9 pairs per call (`valu`); "
