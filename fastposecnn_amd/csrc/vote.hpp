@@ -69,7 +69,10 @@ struct Ws {
 
 // 8192: at B = 32 the 370 runs are one resident round of 512-thread workgroups (4096: two rounds, 38 us; whole instances:
 // the 35 000-pixel one alone takes 25 us; measured); a handful of instances are cut finer so that more CUs share them
-inline int run_entries_for(int n) { return n <= 16 ? 2048 : 8192; }
+#ifndef FPC_RUN_ENTRIES
+#define FPC_RUN_ENTRIES 8192
+#endif
+inline int run_entries_for(int n) { return n <= 16 ? 2048 : FPC_RUN_ENTRIES; }
 
 inline Ws carve(void* base, int n, int H, int W, int hn) {
     Ws w;

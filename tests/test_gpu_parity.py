@@ -319,6 +319,22 @@ def test_cc_label_from_bit_words(lib, oracle, dev, shape, kind):
     assert N2 == M and torch.equal(labels2, labels)
 
 
+@pytest.mark.parametrize("shape,p", [((2, 64, 64), 0.0), ((1, 1, 64), 1.0), ((1, 1, 128), 0.5), ((300, 16, 64), 0.35), ((3, 480, 640), 1.0),
+                                     ((2, 2, 4096), 0.5)])
+def test_cc_label_bit_word_path_edge_shapes(lib, oracle, dev, shape, p):
+    """The whole-image labelling on its edge cases: no foreground at all, a single row, more images than one sweep of the
+    per-image component counts (300 > 256 threads), frames that are one component, one long row of many words."""
+    import aggregation_layer as al
+    from fastposecnn_amd import _native as nat
+    assert nat.lib().fpc_cc_bits_supported(*shape) == 1
+    rng = np.random.default_rng(shape[0] + shape[2])
+    fg = rng.random(shape) < p if 0.0 < p < 1.0 else np.full(shape, p == 1.0)
+    cm = al.attach_fg_bits(T(fg.astype(np.int64), dev))
+    labels, N = al.AggregationLayer(None, 7).batchwise_break_segmentation_mask(cm)
+    want, M = oracle.cc_label(fg)
+    assert N == M and np.array_equal(labels.cpu().numpy(), want)
+
+
 def test_class_compression_writes_the_foreground_bit_words(lib, dev):
     import aggregation_layer as al
     import gpu_tensor_funcs as gtf
