@@ -1006,17 +1006,19 @@ __global__ __launch_bounds__(256) void k_up4_compress7(const Up4Args a) {
         if ((threadIdx.x & 63) == 0) a.fg_bits[(size_t)b * a.fg_stride + (p >> 6)] = fgm;
     }
     if (a.o_mask) {
+        // the 67 full-resolution logit planes (82 MB per frame) are the caller's output: nothing on this path reads them back,
+        // so they go out as streaming stores (the categorical planes below are read by the aggregation next: ordinary stores)
 #pragma unroll
-        for (int c = 0; c < C; ++c) a.o_mask[((size_t)b * C + c) * HW + p] = vm[c];
+        for (int c = 0; c < C; ++c) __builtin_nontemporal_store(vm[c], a.o_mask + ((size_t)b * C + c) * HW + p);
 #pragma unroll
-        for (int c = 0; c < 4 * G; ++c) a.o_quat[((size_t)b * 4 * G + c) * HW + p] = vq[c];
+        for (int c = 0; c < 4 * G; ++c) __builtin_nontemporal_store(vq[c], a.o_quat + ((size_t)b * 4 * G + c) * HW + p);
 #pragma unroll
-        for (int c = 0; c < 3 * G; ++c) a.o_scales[((size_t)b * 3 * G + c) * HW + p] = vs[c];
+        for (int c = 0; c < 3 * G; ++c) __builtin_nontemporal_store(vs[c], a.o_scales + ((size_t)b * 3 * G + c) * HW + p);
 #pragma unroll
         for (int k = 0; k < G; ++k) {
-            a.o_xy[((size_t)b * 2 * G + 2 * k) * HW + p] = vt[3 * k];
-            a.o_xy[((size_t)b * 2 * G + 2 * k + 1) * HW + p] = vt[3 * k + 1];
-            a.o_z[((size_t)b * G + k) * HW + p] = vt[3 * k + 2];
+            __builtin_nontemporal_store(vt[3 * k], a.o_xy + ((size_t)b * 2 * G + 2 * k) * HW + p);
+            __builtin_nontemporal_store(vt[3 * k + 1], a.o_xy + ((size_t)b * 2 * G + 2 * k + 1) * HW + p);
+            __builtin_nontemporal_store(vt[3 * k + 2], a.o_z + ((size_t)b * G + k) * HW + p);
         }
     }
     float q[4] = {0, 0, 0, 0}, sc[3] = {0, 0, 0}, vxy[2] = {0, 0}, zz = 0.f;
