@@ -38,6 +38,8 @@ Extra objects on the JSON line:
                     1/2.25) / device time per network, against the 157.3 TFLOP/s f32 matrix peak (and, second figure,
                     against the bf16 x 3 equivalent peak: config.matrix_products says which product form the plans use)
   configs.config3   BASELINE.json configs[2]: ResNet34, batch 32 per step, same pipeline (shorter timed region)
+  frames_per_launch  the headline stream (one frame per step) with FrameStreamer(coalesce=2 / 4): the runtime groups consecutive
+                    frames into one engine launch (dynamic batching; informational, never `value`)
   plain_f32_products  the headline measurement once more with split-precision products switched off (1-GPU runs)
   train             BASELINE.json configs[4] at batch 8 on this GPU (fastposecnn_amd/train_bench.py; 1-GPU runs)
   cpu_baseline      the same step on the host: torch-CPU backbone + the C oracle's post-network path (1 thread and the
@@ -77,6 +79,7 @@ def parse(argv=None):
     ap.add_argument("--batch", type=int, default=1, help="frames per GPU per step (1 = BASELINE.json configs[1]; 32 = configs[2]/[3])")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-config3", action="store_true", help="skip the ResNet34 batch-32 section (configs[2])")
+    ap.add_argument("--no-batch-scan", action="store_true", help="skip the 2 / 4 frames-per-launch section")
     ap.add_argument("--no-hn128", action="store_true", help="skip the hn=128 / 32-frame vote roofline")
     ap.add_argument("--no-plain-f32", action="store_true", help="skip the second streamed measurement with plain f32 matrix products")
     ap.add_argument("--no-train-line", action="store_true", help="skip the `train` object (configs[4] at B=8 on this GPU, 1-GPU runs only)")
@@ -408,7 +411,7 @@ def check_gather(model_gpu, gatherer, cat, Bq, world, rank, cap, dev):
     return bool(flag.item() > 0.5)
 
 
-def run_inference(args, encoder, Bq, hn, steps, warmup, world, rank, dev, want_backbone=True, split_precision=None):
+def run_inference(args, encoder, Bq, hn, steps, warmup, world, rank, dev, want_backbone=True, split_precision=None, coalesce=1):
     """The timed hot path for one (encoder, batch) configuration.  Returns a dict of measurements and the objects
     later sections reuse."""
     import torch
@@ -440,9 +443,11 @@ def run_inference(args, encoder, Bq, hn, steps, warmup, world, rank, dev, want_b
     cap = 64 * Bq
 
     streamer = FrameStreamer(model_gpu, net_streams=1 if args.no_pipeline else args.net_streams,
-                             post_inline=not args.post_stream)
+                             post_inline=not args.post_stream, coalesce=coalesce)
     s_net = streamer.net_streams[0]
     depth = 0 if args.no_pipeline else (args.frames_in_flight - 1 if args.frames_in_flight > 0 else len(streamer.models))
+    if coalesce > 1:                                          # a group per stream in flight, and one being filled
+        depth = coalesce * (len(streamer.models) + 1) - 1
     pending = []
     # pose records of `gather_every` frames per RCCL all-gather, issued on a side stream: no frame waits for it
     gatherer = parallel.PoseGatherer(cap, every=args.gather_every or max(1, depth + 1), device=dev) if world > 1 else None
@@ -466,6 +471,8 @@ def run_inference(args, encoder, Bq, hn, steps, warmup, world, rank, dev, want_b
         return None
 
     def drain():
+        if coalesce > 1:
+            streamer.flush()
         while pending:
             finish(pending.pop(0))
         if gatherer is not None and gatherer.pending:
@@ -817,6 +824,24 @@ def main():
                                           "note": "HPARAM.ENGINE_SPLIT_PRECISION = False: the engine's plans may only use "
                                                   "v_mfma_f32_32x32x2_f32 (a shorter timed region than `value`'s)"}
             del rp, ctxp
+        if not args.no_batch_scan and args.batch == 1 and not args.vote_only:
+            # the same one-frame-per-step stream with the runtime coalescing 2 / 4 consecutive frames per engine launch
+            # (FrameStreamer(coalesce=k)): how far the batch-1 rate is from the kernels' own throughput.  NOT `value`.
+            scan = {}
+            for k in (2, 4):
+                torch.cuda.empty_cache()
+                rb, ctxb = run_inference(args, args.encoder, 1, args.hn, 4 * max(15, args.steps // 8), 8, 1, 0, dev,
+                                         want_backbone=False, coalesce=k)           # steps and warm-up: whole groups
+                scan[f"coalesce_{k}"] = {"value": rb["value"], "unit": "img/s", "ms_per_step": rb["ms_per_step"], "steps": rb["steps"],
+                                         "frames_in_flight": rb["frames_in_flight"]}
+                del rb, ctxb
+            scan["note"] = ("the headline pipeline, ONE frame per step, with FrameStreamer(coalesce=k): the runtime groups k consecutive "
+                            "frames into one engine launch of batch k and one batched post-network enqueue (dynamic batching; every "
+                            "frame keeps its own ticket and result, its latency grows by the wait for its partners).  Informational, "
+                            "never `value`: configs[1] is one frame per launch.  It shows that the batch-1 headline is bound by kernel "
+                            "size (parallelism-bound encoder layers, ~60 launches per frame on four hardware queues), not by the "
+                            "kernels' arithmetic")
+            line["frames_per_launch"] = scan
         if not args.no_config3 and not (args.encoder == "resnet34" and args.batch == 32):
             del ctx
             torch.cuda.empty_cache()

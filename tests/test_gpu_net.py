@@ -597,3 +597,41 @@ def test_split_precision_error_is_at_the_plain_f32_level(lib, dev):
                           for k in ("mask", "quaternion", "scales", "xy", "z"))
     assert errs[True] <= 2.0 * errs[False] + 1e-7 and errs[False] <= 2.0 * errs[True] + 1e-7, errs
     assert errs[True] <= 2e-5, errs
+
+
+def test_frame_streamer_coalescing_returns_each_frames_own_result(lib, dev):
+    """FrameStreamer(coalesce=2): consecutive single frames run as one batch-2 engine launch + one batched post-network
+    enqueue; every ticket still yields ITS frame's forward() dict — logits / categorical equal to the frame's slice of the
+    batched forward, instances split by sample id (frame-local sample ids), an odd frame at the end flushed on its own."""
+    from fastposecnn_amd import config, synth
+    from fastposecnn_amd.streaming import FrameStreamer
+    import aggregation_layer as al
+    hp = config.INFERENCE()
+    hp.RUNTIME_TIMING = False
+    hp.HV_NUM_OF_HYPOTHESES = 64
+    torch.manual_seed(0)
+    m = lib.pose_regressor.MODELS['PoseRegressor'].load_from_ckpt(None, hp).to(dev).eval()
+    H, W = 96, 128
+    xs = [synth.make_image(i, H, W)[None].to(dev) for i in range(3)]
+    cats = []
+    for i in range(3):
+        c, _ = synth.make_vote_frame(i, K=2 + i, H=H, W=W, rmin=8, rmax=20)
+        cats.append({k: v.to(dev) for k, v in c.items()})          # [1, ...] tensors: one frame each
+    st = FrameStreamer(m, net_streams=2, coalesce=2)
+    tickets = [st.submit(xs[i], categorical_override=cats[i]) for i in range(3)]
+    st.flush()
+    outs = [st.collect(t) for t in tickets]
+    single = FrameStreamer(m, net_streams=1)
+    for i in range(3):
+        ref = single.collect(single.submit(xs[i], categorical_override=cats[i]))
+        o = outs[i]
+        assert tuple(o["logits"]["mask"].shape) == (1, 7, H, W) and tuple(o["categorical"]["mask"].shape) == (1, H, W)
+        for k in ref["logits"]:
+            err = (o["logits"][k] - ref["logits"][k]).abs().max().item()
+            assert err <= 1e-4 * max(1.0, ref["logits"][k].abs().max().item()), (i, k, err)      # batch-2 plans may tile differently
+        a, r = o["aggregated"], ref["aggregated"]
+        assert a["class_ids"].tolist() == r["class_ids"].tolist() and len(a["class_ids"]) == 2 + i
+        assert a["sample_ids"].tolist() == [0] * (2 + i)
+        assert torch.equal(a["instance_masks"], r["instance_masks"])
+        assert (a["quaternion"] - r["quaternion"]).abs().max().item() <= 1e-5
+        assert tuple(a["xy"].shape) == (2 + i, 2) and tuple(a["RT"].shape) == (2 + i, 4, 4)

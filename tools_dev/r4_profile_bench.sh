@@ -8,7 +8,7 @@ export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 D=$R/gpurun_out/prof_bench; rm -rf $D; mkdir -p $D
 cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $D/stream -- python3 $R/bench.py --no-train-line > $D/stream.json 2> $D/stream.err
-cd /tmp && timeout 300 rocprofv3 --kernel-trace --output-format csv -d $D/frame -- python3 $R/bench.py --steps 40 --warmup 10 --no-pipeline --no-train-line --no-config3 --no-hn128 --no-cpu-baseline --no-plain-f32 > $D/frame.json 2> $D/frame.err
+cd /tmp && timeout 300 rocprofv3 --kernel-trace --output-format csv -d $D/frame -- python3 $R/bench.py --steps 40 --warmup 10 --no-pipeline --no-batch-scan --no-train-line --no-config3 --no-hn128 --no-cpu-baseline --no-plain-f32 > $D/frame.json 2> $D/frame.err
 for f in 1 32; do
   cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $D/post$f -- python3 $R/tools_dev/post_loop.py --frames $f --iters 200 > $D/post$f.log 2>&1
 done
