@@ -1,4 +1,5 @@
 #!/bin/bash
+# (belongs to the archived experiment in this directory: needs its kernels and fpc_vote_set_fuse_min_instances)
 cd $GRAFT_REPO_ROOT
 python -c "from fastposecnn_amd import build; build.build(extra=['-DFPC_STAMP_VOTE'])" > gpurun_out/tb.log 2>&1 || { tail gpurun_out/tb.log; exit 1; }
 python tools_dev/vote_stamps.py --hn 1000 --frames 1 2>&1 | tail -14
