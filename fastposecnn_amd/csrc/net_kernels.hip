@@ -68,6 +68,28 @@ __device__ __forceinline__ f32x4 sub_pk(f32x4 a, f32x4 b) {
     return __builtin_shufflevector(rl, rh, 0, 1, 2, 3);
 }
 
+// Scalar forms for code that runs between bf16 matrix instructions: there a packed f32 instruction costs more than the two
+// scalar ones it replaces (MI355X_MICROARCH.md, "price of one filler beside MFMAs"), and the SLP vectorizer would pack
+// plain C++ arithmetic again — hence inline asm, one instruction per element.  Same IEEE results as the packed forms.
+__device__ __forceinline__ f32x4 sub_s4(f32x4 a, f32x4 b) {
+    f32x4 r;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { float x = a[k], y = b[k], z; asm("v_sub_f32 %0, %1, %2" : "=v"(z) : "v"(x), "v"(y)); r[k] = z; }
+    return r;
+}
+__device__ __forceinline__ f32x4 add_s4(f32x4 a, f32x4 b) {
+    f32x4 r;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { float x = a[k], y = b[k], z; asm("v_add_f32 %0, %1, %2" : "=v"(z) : "v"(x), "v"(y)); r[k] = z; }
+    return r;
+}
+__device__ __forceinline__ f32x4 fma_s4(float s, f32x4 b, f32x4 a) {      // s * b + a, fused
+    f32x4 r;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { float x = b[k], y = a[k], z; asm("v_fma_f32 %0, %1, %2, %3" : "=v"(z) : "v"(s), "v"(x), "v"(y)); r[k] = z; }
+    return r;
+}
+
 // LDS operand rows are 32 floats (128 B) with NO padding: the 16-byte chunk c of row r lives in slot c ^ (r & 7), which
 // keeps both the staging writes and the fragment reads conflict-free (8 consecutive rows hit 8 distinct slots of
 // each half of the 64-bank window).  32 KB for the 64x64 tiling, 48 KB for 64x128 / 128x64 (36-float padded rows:
@@ -635,14 +657,18 @@ __global__ __launch_bounds__(256) void k_maxpool3x3s2(const float* __restrict__ 
 
 // ------------------------------------------------------------------------------------------
 // GroupNorm statistics: partial sums -> per (image, channel) affine  y = x*a + b
-// grid (groups, B, G), 64 threads; fp64 combine in fixed order.
+// grid (groups, B, sites * kMaxGroup), 64 threads; fp64 combine in fixed order.  One launch serves every site whose
+// statistics are complete (the four first segmentation blocks of a frame: one launch instead of four).
 
 __global__ __launch_bounds__(64) void k_gn_finalize(const GnFinArgs a) {
     const int g = blockIdx.x, b = blockIdx.y, z = blockIdx.z;
     const int cpg = a.C / a.groups;
-    const float* part = a.gn_part[z] + (size_t)b * a.P * a.C * 2;
+    const int site = z / kMaxGroup;
+    const int P = a.P[site];
+    const long long count = a.count[site];
+    const float* part = a.gn_part[z] + (size_t)b * P * a.C * 2;
     double s1 = 0.0, s2 = 0.0;
-    for (int i = threadIdx.x; i < a.P * cpg; i += 64) {
+    for (int i = threadIdx.x; i < P * cpg; i += 64) {
         int tile = i / cpg, c = g * cpg + (i - tile * cpg);
         const float* q = part + ((size_t)tile * a.C + c) * 2;
         s1 += (double)q[0]; s2 += (double)q[1];
@@ -650,8 +676,8 @@ __global__ __launch_bounds__(64) void k_gn_finalize(const GnFinArgs a) {
     s1 = wave_reduce_add(s1);
     s2 = wave_reduce_add(s2);
     s1 = __shfl(s1, 0, 64); s2 = __shfl(s2, 0, 64);
-    double mean = s1 / (double)a.count;
-    double var = s2 / (double)a.count - mean * mean;
+    double mean = s1 / (double)count;
+    double var = s2 / (double)count - mean * mean;
     if (var < 0.0) var = 0.0;
     float rstd = (float)(1.0 / sqrt(var + (double)a.eps));
     float fmean = (float)mean;
@@ -713,13 +739,15 @@ __device__ __forceinline__ void load_affine4(const float* aff, float4& sa, float
     sb = make_float4(u.y, u.w, v.y, v.w);
 }
 
-// GN + ReLU + x2 bilinear upsample (Conv3x3GNReLU with upsample=True), grid-stride, grid.y = group
+// GN + ReLU + x2 bilinear upsample (Conv3x3GNReLU with upsample=True), grid-stride, grid.y = job * kMaxGroup + group
 __global__ __launch_bounds__(256) void k_gn_relu_up2(const GnUpArgs a) {
     const int z = blockIdx.y;
     const float* in = a.in[z];
     const float* aff = a.affine[z];
     float* out = a.out[z];
-    const int C4 = a.C >> 2, H2 = 2 * a.h, W2 = 2 * a.w;
+    const int job = z / kMaxGroup;
+    const int ah = a.h[job], aw = a.w[job];
+    const int C4 = a.C >> 2, H2 = 2 * ah, W2 = 2 * aw;
     long long total = (long long)a.B * H2 * W2 * C4;
     for (long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (long long)gridDim.x * blockDim.x) {
         int c4 = (int)(g % C4);
@@ -727,14 +755,14 @@ __global__ __launch_bounds__(256) void k_gn_relu_up2(const GnUpArgs a) {
         int x = (int)(r % W2); r /= W2;
         int y = (int)(r % H2);
         int b = (int)(r / H2);
-        Lerp ly = lerp_coord(y, a.h, H2), lx = lerp_coord(x, a.w, W2);
+        Lerp ly = lerp_coord(y, ah, H2), lx = lerp_coord(x, aw, W2);
         float4 sa, sb;
         load_affine4(aff + ((size_t)b * a.C + 4 * c4) * 2, sa, sb);
-        const float* base = in + (size_t)b * a.h * a.w * a.C + 4 * c4;
-        float4 v00 = gn_relu4(base + ((size_t)ly.i0 * a.w + lx.i0) * a.C, sa, sb);
-        float4 v01 = gn_relu4(base + ((size_t)ly.i0 * a.w + lx.i1) * a.C, sa, sb);
-        float4 v10 = gn_relu4(base + ((size_t)ly.i1 * a.w + lx.i0) * a.C, sa, sb);
-        float4 v11 = gn_relu4(base + ((size_t)ly.i1 * a.w + lx.i1) * a.C, sa, sb);
+        const float* base = in + (size_t)b * ah * aw * a.C + 4 * c4;
+        float4 v00 = gn_relu4(base + ((size_t)ly.i0 * aw + lx.i0) * a.C, sa, sb);
+        float4 v01 = gn_relu4(base + ((size_t)ly.i0 * aw + lx.i1) * a.C, sa, sb);
+        float4 v10 = gn_relu4(base + ((size_t)ly.i1 * aw + lx.i0) * a.C, sa, sb);
+        float4 v11 = gn_relu4(base + ((size_t)ly.i1 * aw + lx.i1) * a.C, sa, sb);
         *reinterpret_cast<float4*>(out + (size_t)g * 4) = bilerp4(v00, v01, v10, v11, ly, lx);
     }
 }
@@ -1144,14 +1172,17 @@ int launch_maxpool3x3s2(const float* in, float* out, int B, int Hi, int Wi, int 
 
 int launch_gn_finalize(const GnFinArgs& a, int groups, hipStream_t s) {
     if (a.C % a.groups != 0 || a.C / a.groups > 64) return FPC_EINVAL;
-    hipLaunchKernelGGL(k_gn_finalize, dim3(a.groups, a.B, groups), dim3(64), 0, s, a);
+    if (a.sites < 1 || a.sites > kMaxGnSites || groups != kMaxGroup) return FPC_EINVAL;
+    hipLaunchKernelGGL(k_gn_finalize, dim3(a.groups, a.B, a.sites * kMaxGroup), dim3(64), 0, s, a);
     return check_launch();
 }
 
 int launch_gn_relu_up2(const GnUpArgs& a, int groups, hipStream_t s) {
     if (a.C % 4 != 0) return FPC_EINVAL;
-    hipLaunchKernelGGL(k_gn_relu_up2, dim3(stream_grid((long long)a.B * 4 * a.h * a.w * (a.C / 4)), groups), dim3(256), 0,
-                       s, a);
+    if (a.jobs < 1 || a.jobs > kMaxUpJobs || groups != kMaxGroup) return FPC_EINVAL;
+    long long most = 0;
+    for (int j = 0; j < a.jobs; ++j) most = std::max(most, (long long)a.B * 4 * a.h[j] * a.w[j] * (a.C / 4));
+    hipLaunchKernelGGL(k_gn_relu_up2, dim3(stream_grid(most), a.jobs * kMaxGroup), dim3(256), 0, s, a);
     return check_launch();
 }
 
@@ -1589,6 +1620,7 @@ __global__ __launch_bounds__(64 * NW, BF3 ? 1 : 2) void k_conv_wino(const WinoAr
     // BF3: the three bf16 pieces of the transformed fragments (four channels per piece and xi), and the {b3} fragment offsets
     u32x2 pa[4][3];
     int w3_frag[2];
+    int w_fragh[2] = {w_frag[0], w_frag[1]};      // BF3: the same offsets, opaque (see the operand tuples in the K loop)
     if constexpr (BF3) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) split_bf3(v[j], pa[j][0], pa[j][1], pa[j][2]);
@@ -1597,6 +1629,9 @@ __global__ __launch_bounds__(64 * NW, BF3 ? 1 : 2) void k_conv_wino(const WinoAr
             int co = nt * 32 + li;
             w3_frag[nt] = 8192 + ((4 * wi) * kWinoBN + co) * 4 + 2 * (lh ^ ((co >> 4) & 1));      // halves swapped per 16 channels (k_wino_pack_bf3)
         }
+        // opaque copies: no forwarding from the 16-byte reads, and no pairing of the two {b3} reads into one
+        // ds_read2 (its results would sit in adjacent registers and have to be moved into their operand tuples)
+        asm volatile("" : "+v"(w_fragh[0]), "+v"(w_fragh[1]), "+v"(w3_frag[1]));
     }
     __syncthreads();       // I[0] is refilled by step 0's DMA
     long long stamp[6] = {0, 0, 0, 0, 0, 0};
@@ -1618,8 +1653,14 @@ __global__ __launch_bounds__(64 * NW, BF3 ? 1 : 2) void k_conv_wino(const WinoAr
         f32x4 da[4], db[4], e[4], vn[4];
         __builtin_amdgcn_s_setprio(1);      // MFMA issue ahead of the co-resident workgroup's staging
         if constexpr (BF3) {
+            // Operand tuples without register moves: {b1, b2} is one 16-byte read; {b3, b1} is built from two 8-byte reads
+            // that land in the two halves of one register tuple (the b1 half read again through an offset the compiler cannot
+            // see through, or it would forward the 16-byte read and copy) — 8 LDS instructions more, 32 vector instructions fewer per K-step
+            // of a wave, in a block that is bound by vector issue (190 vector instructions beside 24 matrix instructions).
             u32x4 u0 = *reinterpret_cast<const u32x4*>(Wb + w_frag[0]), u1 = *reinterpret_cast<const u32x4*>(Wb + w_frag[1]);
             u32x2 t0 = *reinterpret_cast<const u32x2*>(Wb + w3_frag[0]), t1 = *reinterpret_cast<const u32x2*>(Wb + w3_frag[1]);
+            u32x2 h0 = *reinterpret_cast<const u32x2*>(Wb + w_fragh[0]), h1 = *reinterpret_cast<const u32x2*>(Wb + w_fragh[1]);
+            asm volatile("" ::: "memory");      // keeps these reads from being paired (ds_read2) with xi 1's: paired results sit in adjacent registers
             u32x2 pn[4][3];
 #define FPC_WINO_BF3_MFMA(A, B0, B1)                                                                               \
     do {                                                                                                      \
@@ -1629,12 +1670,14 @@ __global__ __launch_bounds__(64 * NW, BF3 ? 1 : 2) void k_conv_wino(const WinoAr
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 u32x4 n0 = u0, n1 = u1;
-                u32x2 m0 = t0, m1 = t1;
+                u32x2 m0 = t0, m1 = t1, g0 = h0, g1 = h1;
                 if (j < 3) {
                     n0 = *reinterpret_cast<const u32x4*>(Wb + w_frag[0] + (j + 1) * kWinoBN * 8);
                     n1 = *reinterpret_cast<const u32x4*>(Wb + w_frag[1] + (j + 1) * kWinoBN * 8);
                     m0 = *reinterpret_cast<const u32x2*>(Wb + w3_frag[0] + (j + 1) * kWinoBN * 4);
                     m1 = *reinterpret_cast<const u32x2*>(Wb + w3_frag[1] + (j + 1) * kWinoBN * 4);
+                    g0 = *reinterpret_cast<const u32x2*>(Wb + w_fragh[0] + (j + 1) * kWinoBN * 8);
+                    g1 = *reinterpret_cast<const u32x2*>(Wb + w_fragh[1] + (j + 1) * kWinoBN * 8);
                 }
                 if (j < 2) {
 #pragma unroll
@@ -1647,23 +1690,23 @@ __global__ __launch_bounds__(64 * NW, BF3 ? 1 : 2) void k_conv_wino(const WinoAr
                 const u32x4 A0 = {pa[j][0][0], pa[j][0][1], pa[j][0][0], pa[j][0][1]};
                 const u32x4 A1 = {pa[j][1][0], pa[j][1][1], pa[j][1][0], pa[j][1][1]};
                 const u32x4 A2 = {pa[j][0][0], pa[j][0][1], pa[j][2][0], pa[j][2][1]};
-                const u32x4 C0 = {t0[0], t0[1], u0[0], u0[1]}, C1 = {t1[0], t1[1], u1[0], u1[1]};
+                const u32x4 C0 = {t0[0], t0[1], h0[0], h0[1]}, C1 = {t1[0], t1[1], h1[0], h1[1]};
                 FPC_WINO_BF3_MFMA(A0, u0, u1);      // a1 b1 + a1 b2
                 // the next step's fragments in the shadow of this wave's own MFMAs: transform at xi 0 / 1, split at xi 2 / 3
-                if (j == 0) { e[0] = __builtin_elementwise_fma(sg4, db[0], da[0]); e[1] = __builtin_elementwise_fma(sg4, db[1], da[1]); }
-                if (j == 1) { e[2] = __builtin_elementwise_fma(sg4, db[2], da[2]); e[3] = __builtin_elementwise_fma(sg4, db[3], da[3]); }
+                if (j == 0) { e[0] = fma_s4(sgn, db[0], da[0]); e[1] = fma_s4(sgn, db[1], da[1]); }
+                if (j == 1) { e[2] = fma_s4(sgn, db[2], da[2]); e[3] = fma_s4(sgn, db[3], da[3]); }
                 if (j == 2) split_bf3(vn[0], pn[0][0], pn[0][1], pn[0][2]);
                 if (j == 3) split_bf3(vn[2], pn[2][0], pn[2][1], pn[2][2]);
                 __builtin_amdgcn_sched_barrier(0);
                 FPC_WINO_BF3_MFMA(A1, u0, u1);      // a2 b1 + a2 b2
-                if (j == 1) { vn[0] = sub_pk(e[0], e[2]); vn[1] = e[1] + e[2]; }
+                if (j == 1) { vn[0] = sub_s4(e[0], e[2]); vn[1] = add_s4(e[1], e[2]); }
                 if (j == 2) split_bf3(vn[1], pn[1][0], pn[1][1], pn[1][2]);
                 if (j == 3) split_bf3(vn[3], pn[3][0], pn[3][1], pn[3][2]);
                 __builtin_amdgcn_sched_barrier(0);
                 FPC_WINO_BF3_MFMA(A2, C0, C1);      // a1 b3 + a3 b1
-                if (j == 1) { vn[2] = sub_pk(e[2], e[1]); vn[3] = sub_pk(e[1], e[3]); }
+                if (j == 1) { vn[2] = sub_s4(e[2], e[1]); vn[3] = sub_s4(e[1], e[3]); }
                 __builtin_amdgcn_sched_barrier(0);
-                u0 = n0; u1 = n1; t0 = m0; t1 = m1;
+                u0 = n0; u1 = n1; t0 = m0; t1 = m1; h0 = g0; h1 = g1;
             }
 #undef FPC_WINO_BF3_MFMA
             __builtin_amdgcn_s_setprio(0);

@@ -38,21 +38,25 @@ struct ConvArgs {
     void* dbg;                        // host side only: diagnostic stamp buffer for k_conv_wino (or null)
 };
 
+constexpr int kMaxGnSites = 4;    // segmentation sites finalized by one launch (x kMaxGroup decoders each)
 struct GnFinArgs {
-    const float* gn_part[kMaxGroup];   // [B][P][C][2]
-    const float* gamma[kMaxGroup];
-    const float* beta[kMaxGroup];
-    float* affine[kMaxGroup];          // [B][C][2]: y = x*a + b
-    int B, P, C, groups;
-    long long count;                   // elements per (image, group) = Ho*Wo*C/groups
+    const float* gn_part[kMaxGnSites * kMaxGroup];   // [site * kMaxGroup + decoder]: [B][P][C][2]
+    const float* gamma[kMaxGnSites * kMaxGroup];
+    const float* beta[kMaxGnSites * kMaxGroup];
+    float* affine[kMaxGnSites * kMaxGroup];          // [B][C][2]: y = x*a + b
+    int P[kMaxGnSites];                // partial rows per image of the site's convolution plan
+    long long count[kMaxGnSites];      // elements per (image, group) = Ho*Wo*C/groups
+    int B, C, groups, sites;
     float eps;
 };
 
+constexpr int kMaxUpJobs = 2;     // upsample jobs (different map sizes) of one launch (x kMaxGroup decoders each)
 struct GnUpArgs {
-    const float* in[kMaxGroup];        // [B,h,w,C]
-    const float* affine[kMaxGroup];    // [B][C][2]
-    float* out[kMaxGroup];             // [B,2h,2w,C]
-    int B, h, w, C;
+    const float* in[kMaxUpJobs * kMaxGroup];        // [job * kMaxGroup + decoder]: [B,h,w,C]
+    const float* affine[kMaxUpJobs * kMaxGroup];    // [B][C][2]
+    float* out[kMaxUpJobs * kMaxGroup];             // [B,2h,2w,C]
+    int h[kMaxUpJobs], w[kMaxUpJobs];
+    int B, C, jobs;
 };
 
 struct MergeHeadArgs {

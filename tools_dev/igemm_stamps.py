@@ -9,9 +9,9 @@ from fastposecnn_amd import _native as nat
 dev = torch.device("cuda:0"); L = nat.lib()
 CASES = [("stem 7x7/2 on NHWC4 M=76800 N=64 K=196 (MODE 2 form)", 1, 4, 480, 640, 64, 7, [(64, 64, 1)]),
          ("stem-like 3x3 Cin=32 M=76800 N=64 K=288", 1, 32, 240, 320, 64, 3, [(64, 64, 1)]),
-         ("l3 3x3 M=1200 N=256 K=2304", 1, 256, 30, 40, 256, 3, [(64, 128, 6), (64, 64, 3), (64, 64, 8), (64, 64, 12)]),
-         ("l2 3x3 M=4800 N=128 K=1152", 1, 128, 60, 80, 128, 3, [(64, 128, 3), (64, 64, 1), (64, 64, 4)]),
-         ("l4 3x3 M=300 N=512 K=4608", 1, 512, 15, 20, 512, 3, [(64, 64, 8), (64, 64, 16), (64, 128, 12)]),
+         ("l3 3x3 M=1200 N=256 K=2304", 1, 256, 30, 40, 256, 3, [(64, 128, 6), (64, 64, 3), (64, 64, 8), (64, 64, 12), (64, 64, 1006), (64, 64, 1012)]),
+         ("l2 3x3 M=4800 N=128 K=1152", 1, 128, 60, 80, 128, 3, [(64, 128, 3), (64, 64, 1), (64, 64, 4), (64, 64, 1003), (64, 64, 1001), (64, 64, 1006)]),
+         ("l4 3x3 M=300 N=512 K=4608", 1, 512, 15, 20, 512, 3, [(64, 64, 8), (64, 64, 16), (64, 128, 12), (64, 64, 1012), (64, 64, 1024)]),
          ("p2 lateral x4 M=76800 N=256 K=64", 4, 64, 120, 160, 256, 1, [(64, 64, 1), (128, 128, 1)])]
 for name, B, Cin, Hi, Wi, Cout, k, plans in CASES:
     x = torch.randn((B, Hi, Wi, Cin), device=dev); w = torch.randn((Cout, Cin, k, k), device=dev) * 0.05
