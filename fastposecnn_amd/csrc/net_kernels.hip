@@ -1218,6 +1218,12 @@ int launch_up4_compress(const Up4Args& a, hipStream_t s) {
 // its four V_xi fragments from 8 LDS reads + 8 vector adds, so the transformed input never exists in
 // memory.  The output transform runs through LDS (wave i holds row i of M) and feeds the same
 // epilogue as the direct kernel (BatchNorm / bias, residual, ReLU, GroupNorm partial sums).
+#ifndef FPC_WINO_PRIO_HI
+#define FPC_WINO_PRIO_HI 1
+#endif
+#ifndef FPC_WINO_STAGGER
+#define FPC_WINO_STAGGER 1
+#endif
 constexpr int kWinoTX = 8;                              // tile patch per workgroup: 8 wide, NW tall (NW = 4 or 8 waves)
 constexpr int kWinoRW = 2 * kWinoTX + 2;                // input region width 18
 constexpr int kWinoIS = 8;                              // floats per staged position (one 32-byte K-step slice)
@@ -1251,7 +1257,17 @@ __global__ __launch_bounds__(64 * NW, BF3 ? 1 : 2) void k_conv_wino(const WinoAr
     constexpr int NT = 8 * NW;                              // tiles per workgroup
     constexpr int WPI = 8 * kWinoRW * kWinoIS;              // WP: floats of a wave's private input patch (8 rows)
     constexpr int IP3 = 512 * kWinoIS;                      // P3: floats per input stage (16 pieces of 1 KB, 324 positions used)
-    constexpr int NPI = (POS + 31) / 32, LINP = NPI * 256;   // barrier form: 1 KB input pieces per stage, floats per input buffer
+    // barrier form: 1 KB input pieces per stage, floats per input buffer.  PERM (the BF3 form): the 16-byte units of the region
+    // are PERMUTED in LDS so that the fragment reads are conflict-free — position (ry, rx), channel half hf lives in unit
+    //   (((a >> 2) * 3 + (q >> 2)) * 8 + (ry & 1) * 4 + (rx & 1) * 2 + hf) * 16 + 4 * (q & 3) + (a & 3),   a = ry >> 1, q = rx >> 1:
+    // the 16 lanes of a ds_read_b128 group are 4 tile rows x 4 tile columns at fixed row / column parity, i.e. 16 different
+    // (a & 3, q & 3) = 16 different 16-byte bank slots (the row-major image put them on 4: every read 4-way, 1024 of the
+    // ~2300 LDS cycles of a K-step).  The DMA lands lane-linear pieces, so the permutation is only the choice of the global
+    // address each lane fetches; 72 x 16 units = 18 pieces with 648 of 1152 lanes active.
+    constexpr bool PERM = BF3;
+    constexpr int NPI = PERM ? 18 : (POS + 31) / 32, LINP = NPI * 256;
+    constexpr int NIN = PERM ? 3 : 2;                        // input pieces per wave and K-step (NW = 8: 18 / 11 pieces over 8 waves)
+    static_assert(!PERM || NW == 8, "permuted input image is laid out for the 18 x 18 region");
     constexpr int kWB = BF3 ? 12288 : kWinoLdsW;            // floats per weight buffer (BF3: 32 KB {b1, b2} + 16 KB {b3})
     constexpr int kLdsFloats = WP ? (kWinoLdsW + 4 * WPI) : P3 ? (3 * IP3 + 3 * kWinoLdsW) : (2 * LINP + 2 * kWB);
     static_assert(!BF3 || (NW == 8 && !WP && !P3), "split precision rides on the 8-wave barrier form");
@@ -1532,14 +1548,27 @@ __global__ __launch_bounds__(64 * NW, BF3 ? 1 : 2) void k_conv_wino(const WinoAr
     const float* wsb3 = P.w + (size_t)nb * nkb * kWB + 8192 + swv * 512;            // BF3: its two pieces of the {b3} image
     const float* isb = P.in + (size_t)b * HW * Cin;                                // image base, + 8 floats per step
     const unsigned wvo = 16u * lane;                                               // bytes
-    unsigned ivo[2];
-    bool iok[2];
+    unsigned ivo[NIN];
+    bool iok[NIN];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        int q = (swv + NW * i) * 32 + (lane >> 1), hf = lane & 1;     // LDS position of this lane's 16 bytes
-        int ry = q / kWinoRW, rx = q - ry * kWinoRW;
+    for (int i = 0; i < NIN; ++i) {
+        int ry, rx, hf;
+        bool inreg;
+        if constexpr (PERM) {
+            const int slot = (swv + NW * i) * 64 + lane;              // 16-byte unit this lane's DMA data lands in
+            const int blk = slot >> 4, res = slot & 15, g = blk >> 3;
+            const int ah = (g / 3) * 4 + (res & 3), qh = (g % 3) * 4 + (res >> 2);
+            hf = blk & 1;
+            ry = 2 * ah + ((blk >> 2) & 1); rx = 2 * qh + ((blk >> 1) & 1);
+            inreg = swv + NW * i < NPI && ah <= 8 && qh <= 8;
+        } else {
+            const int q = (swv + NW * i) * 32 + (lane >> 1);          // LDS position of this lane's 16 bytes
+            hf = lane & 1;
+            ry = q / kWinoRW; rx = q - ry * kWinoRW;
+            inreg = q < POS && (i == 0 || swv + NW < NPI);
+        }
         int y = y_in0 + ry, x = x_in0 + rx;
-        iok[i] = q < POS && y >= 0 && y < H && x >= 0 && x < W && (i == 0 || swv + NW < NPI);
+        iok[i] = inreg && y >= 0 && y < H && x >= 0 && x < W;
         ivo[i] = iok[i] ? (unsigned)((((size_t)y * W + x) * Cin + 4 * hf) * sizeof(float)) : 0u;
     }
     // out-of-image positions are never written by the DMA (inactive lanes): zero both input buffers once
@@ -1571,6 +1600,9 @@ __global__ __launch_bounds__(64 * NW, BF3 ? 1 : 2) void k_conv_wino(const WinoAr
                                  :: "s"(FPC_LDS_ADDR(lds + (BUF) * LINP + swv * 256)), "v"(ivo[0]), "s"(isb) : "memory", "m0"); \
         if (iok[1]) asm volatile("s_mov_b32 m0, %0\n s_nop 0\n global_load_lds_dwordx4 %1, %2\n"              \
                                  :: "s"(FPC_LDS_ADDR(lds + (BUF) * LINP + (swv + NW) * 256)), "v"(ivo[1]), "s"(isb) : "memory", "m0"); \
+        if constexpr (NIN > 2)                                                                                \
+            if (iok[NIN - 1]) asm volatile("s_mov_b32 m0, %0\n s_nop 0\n global_load_lds_dwordx4 %1, %2\n"     \
+                                 :: "s"(FPC_LDS_ADDR(lds + (BUF) * LINP + (swv + 2 * NW) * 256)), "v"(ivo[NIN - 1]), "s"(isb) : "memory", "m0"); \
     } while (0)
 
     // ---- fragment addressing
@@ -1578,8 +1610,19 @@ __global__ __launch_bounds__(64 * NW, BF3 ? 1 : 2) void k_conv_wino(const WinoAr
     // row pair (ra, rb) and sign of B^T row wi:  0: d0-d2   1: d1+d2   2: d2-d1   3: d1-d3
     const int ra = (wi == 0) ? 0 : (wi == 2 ? 2 : 1);
     const int rb = (wi == 0) ? 2 : (wi == 1 ? 2 : (wi == 2 ? 1 : 3));
-    const int in_a = ((2 * tyl + ra) * kWinoRW + 2 * txl) * kWinoIS + 4 * lh;
-    const int in_b = ((2 * tyl + rb) * kWinoRW + 2 * txl) * kWinoIS + 4 * lh;
+    // float offsets of the four positions (2 * txl + c, c = 0..3) of region rows 2 * tyl + ra / rb: [c >> 1] + (c & 1) * in_cs
+    int in_a[2], in_b[2];
+    constexpr int in_cs = PERM ? 2 * 16 * 4 : kWinoIS;
+    if constexpr (PERM) {
+        auto unit = [&](int r, int ch) {      // row 2 * tyl + r, column 2 * (txl + ch)
+            const int ah = tyl + (r >> 1), qh = txl + ch;
+            return ((((ah >> 2) * 3 + (qh >> 2)) * 8 + (r & 1) * 4 + lh) * 16 + 4 * (qh & 3) + (ah & 3)) * 4;
+        };
+        in_a[0] = unit(ra, 0); in_a[1] = unit(ra, 1); in_b[0] = unit(rb, 0); in_b[1] = unit(rb, 1);
+    } else {
+        in_a[0] = ((2 * tyl + ra) * kWinoRW + 2 * txl) * kWinoIS + 4 * lh; in_a[1] = in_a[0] + 2 * kWinoIS;
+        in_b[0] = ((2 * tyl + rb) * kWinoRW + 2 * txl) * kWinoIS + 4 * lh; in_b[1] = in_b[0] + 2 * kWinoIS;
+    }
     int w_frag[2];
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt) {
@@ -1613,8 +1656,8 @@ __global__ __launch_bounds__(64 * NW, BF3 ? 1 : 2) void k_conv_wino(const WinoAr
         f32x4 e[4];
 #pragma unroll
         for (int c = 0; c < 4; ++c)
-            e[c] = __builtin_elementwise_fma(sg4, *reinterpret_cast<const f32x4*>(lds + in_b + c * kWinoIS),
-                                             *reinterpret_cast<const f32x4*>(lds + in_a + c * kWinoIS));
+            e[c] = __builtin_elementwise_fma(sg4, *reinterpret_cast<const f32x4*>(lds + in_b[c >> 1] + (c & 1) * in_cs),
+                                             *reinterpret_cast<const f32x4*>(lds + in_a[c >> 1] + (c & 1) * in_cs));
         v[0] = sub_pk(e[0], e[2]); v[1] = e[1] + e[2]; v[2] = sub_pk(e[2], e[1]); v[3] = sub_pk(e[1], e[3]);
     }
     // BF3: the three bf16 pieces of the transformed fragments (four channels per piece and xi), and the {b3} fragment offsets
@@ -1642,16 +1685,25 @@ __global__ __launch_bounds__(64 * NW, BF3 ? 1 : 2) void k_conv_wino(const WinoAr
     int cur = 0;
 #pragma unroll 1
     for (int kb = 0; kb < nkb; ++kb) {
-        FPC_WB_ISSUE_W(cur ^ 1);
-        FPC_WB_ISSUE_IN(cur);
-        wsb += kb + 2 < nkb ? kWB : 0;
-        wsb3 += kb + 2 < nkb ? kWB : 0;
-        isb += kb + 3 < nkb ? 8 : 0;
+        // BF3, stagger (FPC_WINO_STAGGER): SIMD partners are waves w and w + 4.  The younger half stages first and computes
+        // second, the older half computes first and stages afterwards, so that on every SIMD one wave's matrix block runs
+        // beside the other's staging burst instead of both doing the same phase in lockstep.  Same buffers, same hazards:
+        // W[cur ^ 1] and I[cur] were last read in step kb - 1, whichever half writes them in step kb.
+        const bool stage_first = !(BF3 && FPC_WINO_STAGGER) || swv >= 4;
+        if (stage_first) {
+            FPC_WB_ISSUE_W(cur ^ 1);
+            FPC_WB_ISSUE_IN(cur);
+        }
         FPC_STAMP(0);      // issue of the staging loads
         const float* In = lds + (cur ^ 1) * LINP;
         const float* Wb = lds_w + cur * kWB;
         f32x4 da[4], db[4], e[4], vn[4];
-        __builtin_amdgcn_s_setprio(1);      // MFMA issue ahead of the co-resident workgroup's staging
+        // MFMA issue ahead of the co-resident workgroup's staging.  BF3 (one workgroup per CU): the SIMD partners are waves w
+        // and w + 4 of this workgroup, and the younger one (w + 4) loses the arbitration in the staging phase AND here
+        // (stamps: 1520 + 1900 cycles per K-step against 1000 + 1500, the older waves then wait 1200 at the barrier) —
+        // FPC_WINO_PRIO_HI for the younger half in this block evens the two out.
+        if (BF3 && swv >= 4) __builtin_amdgcn_s_setprio(FPC_WINO_PRIO_HI);
+        else __builtin_amdgcn_s_setprio(1);
         if constexpr (BF3) {
             // Operand tuples without register moves: {b1, b2} is one 16-byte read; {b3, b1} is built from two 8-byte reads
             // that land in the two halves of one register tuple (the b1 half read again through an offset the compiler cannot
@@ -1682,8 +1734,8 @@ __global__ __launch_bounds__(64 * NW, BF3 ? 1 : 2) void k_conv_wino(const WinoAr
                 if (j < 2) {
 #pragma unroll
                     for (int c = 2 * j; c < 2 * j + 2; ++c) {
-                        da[c] = *reinterpret_cast<const f32x4*>(In + in_a + c * kWinoIS);
-                        db[c] = *reinterpret_cast<const f32x4*>(In + in_b + c * kWinoIS);
+                        da[c] = *reinterpret_cast<const f32x4*>(In + in_a[c >> 1] + (c & 1) * in_cs);
+                        db[c] = *reinterpret_cast<const f32x4*>(In + in_b[c >> 1] + (c & 1) * in_cs);
                     }
                 }
                 __builtin_amdgcn_sched_barrier(0);
@@ -1726,8 +1778,8 @@ __global__ __launch_bounds__(64 * NW, BF3 ? 1 : 2) void k_conv_wino(const WinoAr
             if (j < 2) {                    // raw fragments of the next step, two channel pairs per xi block
 #pragma unroll
                 for (int c = 2 * j; c < 2 * j + 2; ++c) {
-                    da[c] = *reinterpret_cast<const f32x4*>(In + in_a + c * kWinoIS);
-                    db[c] = *reinterpret_cast<const f32x4*>(In + in_b + c * kWinoIS);
+                    da[c] = *reinterpret_cast<const f32x4*>(In + in_a[c >> 1] + (c & 1) * in_cs);
+                    db[c] = *reinterpret_cast<const f32x4*>(In + in_b[c >> 1] + (c & 1) * in_cs);
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
@@ -1749,6 +1801,13 @@ __global__ __launch_bounds__(64 * NW, BF3 ? 1 : 2) void k_conv_wino(const WinoAr
         v[0] = vn[0]; v[1] = vn[1]; v[2] = vn[2]; v[3] = vn[3];
         }
         FPC_STAMP(2);      // MFMA issue + the next step's fragments (not completion)
+        if (!stage_first) {
+            FPC_WB_ISSUE_W(cur ^ 1);
+            FPC_WB_ISSUE_IN(cur);
+        }
+        wsb += kb + 2 < nkb ? kWB : 0;
+        wsb3 += kb + 2 < nkb ? kWB : 0;
+        isb += kb + 3 < nkb ? 8 : 0;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's DMA pieces have landed
         FPC_STAMP(3);
         __syncthreads();                                      // everybody's have; this step's reads are done

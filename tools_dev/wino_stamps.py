@@ -31,3 +31,6 @@ print("  total            %8.0f" % per.sum(-1).mean())
 print("  whole K loop per step: %.0f" % (d[:, :, 3] / d[:, :, 5]).mean())
 print("kernel entry -> K loop: %.0f ticks; K loop end -> last store acknowledged: %.0f ticks (mean over waves; p90 %.0f)" %
       (d[:, :, 6].mean(), d[:, :, 7].mean(), d[:, :, 7].flatten().quantile(0.9)))
+print("per wave (mean over workgroups): issue | wait + barrier | MFMA block")
+for w in range(NWAVE):
+    print("  wave %d: %6.0f %6.0f %6.0f" % (w, per[:, w, 0].mean(), per[:, w, 1].mean(), per[:, w, 2].mean()))
