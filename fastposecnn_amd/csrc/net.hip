@@ -168,7 +168,7 @@ struct fpc_net {
             add_param(p + ".running_var", Cout);
         }
         if (bias_name) c.p_bias = add_param(bias_name, Cout);
-        c.w_off = alloc((size_t)c.Npad * c.Kpad);
+        c.w_off = alloc(conv_packed_floats(c.Npad, c.Kpad));      // f32 image + its three bf16 planes
         if (bn_prefix) { c.scale_off = alloc(Cout); c.shift_off = alloc(Cout); }
         c.wino_ok = (k == 3 && stride == 1 && pad == 1 && c.Cinp == Cin && Cin % 8 == 0 && Cout % 64 == 0);
         if (c.wino_ok) c.wino_off = alloc((size_t)40 * Cout * Cin);      // f32 image (16 x) + split-precision image (24 x)
@@ -363,6 +363,8 @@ extern "C" int fpc_net_load_params(fpc_net_t* n, const float* const* params, int
     if (hipMemsetAsync(n->ws + n->tickets_off, 0, kConvTickets * sizeof(int), s) != hipSuccess) return FPC_ELAUNCH;
     for (const PackedConv& c : n->convs) {
         int rc = launch_pack_weight(n->pptr[c.p_w], n->ws + c.w_off, c.Cout, c.Cin, c.Cinp, c.Kh, c.Kw, c.Kwp, c.Npad, c.Kpad, s);
+        if (rc) return rc;
+        rc = launch_pack_weight_bf3(n->pptr[c.p_w], n->ws + c.w_off, c.Cout, c.Cin, c.Cinp, c.Kh, c.Kw, c.Kwp, c.Npad, c.Kpad, s);
         if (rc) return rc;
         if (c.wino_ok) {
             rc = launch_wino_pack(n->pptr[c.p_w], n->ws + c.wino_off, c.Cout, c.Cin, s);
@@ -782,7 +784,7 @@ extern "C" int fpc_net_tensor(const fpc_net_t* n, const char* name, const float*
 // ---- stand-alone convolution (unit tests / micro-benchmarks of k_conv_igemm) -----------------
 extern "C" size_t fpc_conv2d_workspace_bytes(int B, int Ho, int Wo, int Cin, int Cout, int Kh, int Kw) {
     int K = Cin * Kh * Kw, Kpad = cdiv(K, kConvBK) * kConvBK, Npad = cdiv(Cout, kConvNAlign) * kConvNAlign;
-    size_t packed = ((size_t)Npad * Kpad + 63) / 64 * 64;
+    size_t packed = conv_packed_floats(Npad, Kpad);
     size_t splitk = (size_t)32 * B * (cdiv(Ho * Wo, 128) * 128) * Npad;
     size_t wino = (size_t)40 * Cout * Cin + 64;      // f32 + split-precision Winograd images + a zero page for the all-DMA form
     return (packed + splitk + wino + kConvTickets) * sizeof(float);
@@ -816,7 +818,7 @@ struct Conv2dLayout { size_t packed, splitk, wino, tickets, total; };
 Conv2dLayout conv2d_layout(int B, int Cin, int Cout, int Kh, int Kw, const ConvPlan& p, const Conv2dRequest& r) {
     const int K = Cin * Kh * Kw, Kpad = cdiv(K, kConvBK) * kConvBK, Npad = cdiv(Cout, kConvNAlign) * kConvNAlign;
     Conv2dLayout L;
-    L.packed = r.wino ? 0 : ((size_t)Npad * Kpad + 63) / 64 * 64;
+    L.packed = r.wino ? 0 : conv_packed_floats(Npad, Kpad);
     L.splitk = r.wino ? 0 : (splitk_floats_for(p, 1, B, Npad) + 63) / 64 * 64;
     L.wino = r.wino ? (size_t)(r.nsplit == -5 ? 40 : 16) * Cout * Cin + 64 : 0;
     L.tickets = (!r.wino && p.fused && p.nsplit > 1) ? kConvTickets : 0;
@@ -861,6 +863,7 @@ extern "C" int fpc_conv2d(const float* in, int64_t sb, int64_t sh, int64_t sw, i
     hipStream_t s = (hipStream_t)stream;
     float* packed = (float*)ws;
     if (!wino) FPC_TRY(launch_pack_weight(w_oihw, packed, Cout, Cin, Cin, Kh, Kw, Kw, c.Npad, c.Kpad, s));
+    if (!wino && p.bf3) FPC_TRY(launch_pack_weight_bf3(w_oihw, packed, Cout, Cin, Cin, Kh, Kw, Kw, c.Npad, c.Kpad, s));
     int mode = (sc == 1 && Cin % kConvBK == 0 && Kh * Kw <= 32 && ((int64_t)Hi + 2 * pad) * sh * 4 < ((int64_t)1 << 31)) ? 0
                : (sc == 1 && Cin % 4 == 0 && sw % 4 == 0 && sh % 4 == 0 && sb % 4 == 0 && ((uintptr_t)in & 15) == 0) ? 2 : 1;
     fpc_net tmp;

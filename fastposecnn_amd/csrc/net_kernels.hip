@@ -100,6 +100,9 @@ constexpr int kLdsRow = kConvBK;
 
 // ------------------------------------------------------------------------------------------
 // implicit-GEMM convolution
+#ifndef FPC_IGEMM_DMA_B
+#define FPC_IGEMM_DMA_B 1
+#endif
 
 // One K-step of operands, global -> registers.  Thread (sr, sq) owns rows sr + 32*i and the float4 at
 // column 4*sq of the 32-wide K-step.  (Macros, not functions: hipcc keeps by-reference register
@@ -116,7 +119,7 @@ constexpr int kLdsRow = kConvBK;
 #define FPC_CONV_LOAD(KS, ra, rb)                                                                                     \
     do {                                                                                                      \
         const int ks_ = (KS);                                                                                 \
-        _Pragma("unroll") for (int i = 0; i < BR; ++i) rb[i] = buf_load4(rs_w, wvo[i], ks_ * (kConvBK * 4)); \
+        if (!DMAB) { _Pragma("unroll") for (int i = 0; i < BR; ++i) rb[i] = buf_load4(rs_w, wvo[i], ks_ * (kConvBK * 4)); } \
         if (MODE == 0) {                                                                                      \
             _Pragma("unroll") for (int i = 0; i < AR; ++i)                                                    \
                 ra[i] = buf_load4(rs_in, ((anm[i] >> ld_tap) << 31) | avo[i], ld_soff);                       \
@@ -172,13 +175,15 @@ constexpr int kLdsRow = kConvBK;
             *reinterpret_cast<f32x4*>(Bs_ + (sr + 32 * i) * kLdsRow + swz_w) = rb[i];                        \
     } while (0)
 
-// Split-precision staging: the f32 registers of one K-step -> three bf16 planes per operand in LDS.  Plane rows are
-// 32 bf16 = 64 bytes = four 16-byte chunks (one MFMA operand each); chunk c of row r sits in slot c ^ ((r >> 2) & 1)
-// so that the eight rows a ds_read_b128 group touches hit eight different 16-byte positions of the bank window.
+// Split-precision staging: three bf16 planes per operand in LDS.  Plane rows are 32 bf16 = 64 bytes = four 16-byte chunks
+// (one MFMA operand each); chunk c of row r sits in slot c ^ ((r >> 2) & 1) so that the eight rows a ds_read_b128 group
+// touches hit eight different 16-byte positions of the bank window.  The ACTIVATION rows are split here, on the way from
+// the f32 registers of one K-step; the WEIGHT rows arrive already split (k_pack_weight_bf3: three bf16 planes behind the
+// f32 image) and go global -> LDS by LDS-DMA, FPC_CONV_DMA_B — no registers, no vector instructions, no ds_write.
 #define FPC_CONV_STORE_BF3(BUF, ra, rb)                                                                       \
     do {                                                                                                      \
         char* st_ = reinterpret_cast<char*>(lds) + (BUF) * (BM + BN) * 192;                                   \
-        _Pragma("unroll") for (int i = 0; i < AR + BR; ++i) {                                                 \
+        _Pragma("unroll") for (int i = 0; i < AR + (DMAB ? 0 : BR); ++i) {                                    \
             const int row_ = (i < AR ? 0 : BM) + sr + 32 * (i < AR ? i : i - AR);                             \
             u32x2 p1_, p2_, p3_;                                                                              \
             split_bf3(i < AR ? ra[i < AR ? i : 0] : rb[i < AR ? 0 : i - AR], p1_, p2_, p3_);                  \
@@ -269,6 +274,7 @@ template <int BM, int BN, int MODE, bool BF3 = false>
 __global__ __launch_bounds__(256, (BM * BN >= 128 * 128) ? 1 : 2) void k_conv_igemm(const ConvArgs a) {
     constexpr int TM = BM / 64, TN = BN / 64;     // 32x32 tiles per wave
     constexpr int AR = BM / 32, BR = BN / 32;     // float4 rows staged per thread
+    constexpr bool DMAB = BF3 && FPC_IGEMM_DMA_B; // split precision: weight planes pre-split, staged by LDS-DMA
     // f32 operands: 2 stages x (BM + BN) rows x 128 B;  split precision: 2 stages x 3 planes x (BM + BN) rows x 64 B
     __shared__ __attribute__((aligned(16))) float lds[BF3 ? 2 * (BM + BN) * 48 : 2 * (BM + BN) * kLdsRow];
     __shared__ int s_last;
@@ -346,6 +352,43 @@ __global__ __launch_bounds__(256, (BM * BN >= 128 * 128) ? 1 : 2) void k_conv_ig
     unsigned wvo[BR];
 #pragma unroll
     for (int i = 0; i < BR; ++i) wvo[i] = (unsigned)(((n0 + sr + 32 * i) * Kpad + 4 * sq) * 4);
+    // split precision: this wave's LDS-DMA pieces of a K-step's weight planes.  A piece = 16 rows x 64 B of one plane (1 KB,
+    // lane l -> row l >> 2, slot l & 3); 3 * BN / 16 pieces per K-step, piece q = wave + 4 i is plane q / (BN / 16), row
+    // group q % (BN / 16).  The swizzle is the choice of the chunk each lane fetches.  SGPR base + 32-bit lane offset, the
+    // base advances 64 B per K-step (see the Winograd kernel for why not a 64-bit lane address).
+    constexpr int kRG = BN / 16, kNPB = 3 * kRG / 4;
+    const int swave = __builtin_amdgcn_readfirstlane(wave);
+    unsigned bvo[kNPB];
+    const char* w3b = nullptr;
+    if constexpr (DMAB) {
+#pragma unroll
+        for (int i = 0; i < kNPB; ++i) {
+            const int q = swave + 4 * i, pl = q / kRG, rg = q - pl * kRG;
+            const int r = rg * 16 + (lane >> 2), c = (lane & 3) ^ ((r >> 2) & 1);
+            bvo[i] = (unsigned)((((size_t)pl * Npad + n0 + r) * Kpad + c * 8) * 2);
+        }
+        w3b = reinterpret_cast<const char*>(P.w + (size_t)Npad * Kpad) + (size_t)ks0 * (kConvBK * 2);
+    }
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"
+#define FPC_CONV_DMA_B(BUF)                                                                                   \
+    do {                                                                                                      \
+        _Pragma("unroll") for (int i = 0; i < kNPB; ++i) {                                                    \
+            const int q_ = swave + 4 * i, pl_ = q_ / kRG, rg_ = q_ - pl_ * kRG;                               \
+            asm volatile("s_mov_b32 m0, %0\n s_nop 0\n global_load_lds_dwordx4 %1, %2\n"                      \
+                         :: "s"((unsigned)(size_t)(__attribute__((address_space(3))) void*)(reinterpret_cast<char*>(lds) + \
+                                 (BUF) * (BM + BN) * 192 + pl_ * (BM + BN) * 64 + (BM + rg_ * 16) * 64)),       \
+                            "v"(bvo[i]), "s"(w3b) : "memory", "m0");                                          \
+        }                                                                                                     \
+        w3b += kConvBK * 2;                                                                                   \
+    } while (0)
+    // the pieces above have landed; the NYOUNG vector-memory operations issued after them may stay in flight
+#define FPC_CONV_DMA_WAIT(YOUNGER)                                                                            \
+    do {                                                                                                      \
+        if (YOUNGER) { if constexpr (AR == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); } \
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                 \
+    } while (0)
+    static_assert(AR == 2 || AR == 4, "FPC_CONV_DMA_WAIT counts AR activation loads");
     // tap walk of the NEXT K-step to load (scalar): channel offset, tap index and coordinates, byte offset of the tap
     int ld_c0, ld_tap, ld_kh, ld_kw, ld_soff;
     {
@@ -445,28 +488,38 @@ __global__ __launch_bounds__(256, (BM * BN >= 128 * 128) ? 1 : 2) void k_conv_ig
 #define FPC_STORE_ANY(BUF, ra, rb) do { if (BF3) FPC_CONV_STORE_BF3(BUF, ra, rb); else FPC_CONV_STORE(BUF, ra, rb); } while (0)
 #define FPC_COMPUTE_ANY(BUF) do { if (BF3) FPC_CONV_COMPUTE_BF3(BUF); else FPC_CONV_COMPUTE(BUF); } while (0)
 
+    // Split precision: the weight planes of step k + 1 are DMA'd into the other LDS buffer at the start of step k (that buffer
+    // was last read in step k - 1) and must have landed at the barrier that ends step k; the activation loads issued after
+    // them (step k + 2) stay in flight across the barrier (counted vmcnt).
     if (ks0 < ks1) {
+        if constexpr (DMAB) FPC_CONV_DMA_B(0);
         FPC_CONV_LOAD(ks0, ra0, rb0);
         FPC_STORE_ANY(0, ra0, rb0);
     }
     if (ks0 + 1 < ks1) FPC_CONV_LOAD(ks0 + 1, ra0, rb0);
+    if constexpr (DMAB) FPC_CONV_DMA_WAIT(ks0 + 1 < ks1);
     __syncthreads();
 #ifdef FPC_STAMP_IGEMM
     const long long st1 = clock64();
 #endif
     for (int ks = ks0; ks < ks1; ks += 2) {
         // even phase: LDS buffer 0 holds step ks, set 0 holds ks+1
+        if constexpr (DMAB) { if (ks + 1 < ks1) FPC_CONV_DMA_B(1); }
         if (ks + 2 < ks1) FPC_CONV_LOAD(ks + 2, ra1, rb1);
         FPC_COMPUTE_ANY(0);
         if (ks + 1 < ks1) FPC_STORE_ANY(1, ra0, rb0);
+        if constexpr (DMAB) FPC_CONV_DMA_WAIT(ks + 2 < ks1);
         __syncthreads();
         if (ks + 1 >= ks1) break;
         // odd phase: LDS buffer 1 holds step ks+1, set 1 holds ks+2
+        if constexpr (DMAB) { if (ks + 2 < ks1) FPC_CONV_DMA_B(0); }
         if (ks + 3 < ks1) FPC_CONV_LOAD(ks + 3, ra0, rb0);
         FPC_COMPUTE_ANY(1);
         if (ks + 2 < ks1) FPC_STORE_ANY(0, ra1, rb1);
+        if constexpr (DMAB) FPC_CONV_DMA_WAIT(ks + 3 < ks1);
         __syncthreads();
     }
+#pragma clang diagnostic pop
 
 #ifdef FPC_STAMP_IGEMM
     const long long st2 = clock64();
@@ -1089,6 +1142,30 @@ __global__ __launch_bounds__(256) void k_pack_weight(const float* __restrict__ w
             if (ci < Cin && kw < Kw) v = w[(((size_t)n * Cin + ci) * Kh + kh) * Kw + kw];
         }
         out[g] = v;
+    }
+}
+
+// The same [Npad][Kpad] image split EXACTLY into three bf16 planes (x = b1 + b2 + b3 by truncation, as split_bf3):
+// out[(plane * Npad + n) * Kpad + k] — the weight operand of the split-precision direct convolution, staged by LDS-DMA.
+__global__ __launch_bounds__(256) void k_pack_weight_bf3(const float* __restrict__ w, unsigned short* __restrict__ out, int Cout,
+                                                       int Cin, int Cinp, int Kh, int Kw, int Kwp, int Npad, int Kpad) {
+    const int K = Cinp * Kh * Kwp;
+    long long total = (long long)Npad * Kpad;
+    for (long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (long long)gridDim.x * blockDim.x) {
+        int n = (int)(g / Kpad), k = (int)(g - (long long)n * Kpad);
+        float v = 0.f;
+        if (n < Cout && k < K) {
+            int tap = k / Cinp, ci = k - tap * Cinp;
+            int kh = tap / Kwp, kw = tap - kh * Kwp;
+            if (ci < Cin && kw < Kw) v = w[(((size_t)n * Cin + ci) * Kh + kh) * Kw + kw];
+        }
+        const unsigned b1 = __builtin_bit_cast(unsigned, v) & 0xFFFF0000u;
+        const float r = v - __builtin_bit_cast(float, b1);
+        const unsigned b2 = __builtin_bit_cast(unsigned, r) & 0xFFFF0000u;
+        const float q = r - __builtin_bit_cast(float, b2);
+        out[g] = (unsigned short)(b1 >> 16);
+        out[total + g] = (unsigned short)(b2 >> 16);
+        out[2 * total + g] = (unsigned short)(__builtin_bit_cast(unsigned, q) >> 16);
     }
 }
 
@@ -2015,6 +2092,14 @@ int launch_pack_weight(const float* w, float* packed, int Cout, int Cin, int Cin
     if (Kwp < Kw || Cinp < Cin) return FPC_EINVAL;
     hipLaunchKernelGGL(k_pack_weight, dim3(stream_grid((long long)Npad * Kpad)), dim3(256), 0, s, w, packed, Cout, Cin,
                        Cinp, Kh, Kw, Kwp, Npad, Kpad);
+    return check_launch();
+}
+
+int launch_pack_weight_bf3(const float* w, float* packed, int Cout, int Cin, int Cinp, int Kh, int Kw, int Kwp, int Npad,
+                           int Kpad, hipStream_t s) {
+    if (Kwp < Kw || Cinp < Cin) return FPC_EINVAL;
+    hipLaunchKernelGGL(k_pack_weight_bf3, dim3(stream_grid((long long)Npad * Kpad)), dim3(256), 0, s, w,
+                       reinterpret_cast<unsigned short*>(packed + (size_t)Npad * Kpad), Cout, Cin, Cinp, Kh, Kw, Kwp, Npad, Kpad);
     return check_launch();
 }
 

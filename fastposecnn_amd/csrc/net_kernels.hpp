@@ -104,6 +104,11 @@ int launch_merge_head(const MergeHeadArgs& a, int groups, hipStream_t s);
 int launch_up4_compress(const Up4Args& a, hipStream_t s);
 int launch_pack_weight(const float* w_oihw, float* packed, int Cout, int Cin, int Cinp, int Kh, int Kw, int Kwp, int Npad,
                        int Kpad, hipStream_t s);
+// + the three bf16 planes of the same image behind it (packed + Npad * Kpad floats; 1.5 x Npad * Kpad floats more):
+// the weight operand of the split-precision direct convolution.  conv_packed_floats() = the room both need.
+int launch_pack_weight_bf3(const float* w_oihw, float* packed, int Cout, int Cin, int Cinp, int Kh, int Kw, int Kwp, int Npad,
+                           int Kpad, hipStream_t s);
+inline size_t conv_packed_floats(int Npad, int Kpad) { return ((size_t)Npad * Kpad * 5 / 2 + 63) / 64 * 64; }
 int launch_nchw3_to_nhwc4(const float* x, float* out, int B, int HW, hipStream_t s);
 int launch_fold_bn(const float* gamma, const float* beta, const float* mean, const float* var, float eps, int C,
                    float* scale, float* shift, hipStream_t s);
