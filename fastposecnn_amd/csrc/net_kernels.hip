@@ -1301,6 +1301,9 @@ int launch_up4_compress(const Up4Args& a, hipStream_t s) {
 #ifndef FPC_WINO_STAGGER
 #define FPC_WINO_STAGGER 1
 #endif
+#ifndef FPC_WINO_LATE_AT
+#define FPC_WINO_LATE_AT 1
+#endif
 constexpr int kWinoTX = 8;                              // tile patch per workgroup: 8 wide, NW tall (NW = 4 or 8 waves)
 constexpr int kWinoRW = 2 * kWinoTX + 2;                // input region width 18
 constexpr int kWinoIS = 8;                              // floats per staged position (one 32-byte K-step slice)
@@ -1836,6 +1839,12 @@ __global__ __launch_bounds__(64 * NW, BF3 ? 1 : 2) void k_conv_wino(const WinoAr
                 if (j == 1) { vn[2] = sub_s4(e[2], e[1]); vn[3] = sub_s4(e[1], e[3]); }
                 __builtin_amdgcn_sched_barrier(0);
                 u0 = n0; u1 = n1; t0 = m0; t1 = m1; h0 = g0; h1 = g1;
+                // stagger: the compute-first half stages after xi FPC_WINO_LATE_AT of its matrix block (3 = after the block)
+                if (j == FPC_WINO_LATE_AT && FPC_WINO_LATE_AT < 3 && !stage_first) {
+                    FPC_WB_ISSUE_W(cur ^ 1);
+                    FPC_WB_ISSUE_IN(cur);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
             }
 #undef FPC_WINO_BF3_MFMA
             __builtin_amdgcn_s_setprio(0);
@@ -1878,7 +1887,7 @@ __global__ __launch_bounds__(64 * NW, BF3 ? 1 : 2) void k_conv_wino(const WinoAr
         v[0] = vn[0]; v[1] = vn[1]; v[2] = vn[2]; v[3] = vn[3];
         }
         FPC_STAMP(2);      // MFMA issue + the next step's fragments (not completion)
-        if (!stage_first) {
+        if (!stage_first && !(BF3 && FPC_WINO_LATE_AT < 3)) {
             FPC_WB_ISSUE_W(cur ^ 1);
             FPC_WB_ISSUE_IN(cur);
         }
