@@ -16,4 +16,5 @@ cd $R
 python tools_dev/kstats.py $(ls $D/stream/*/*kernel_stats.csv | tail -1) --top 60 --out gpurun_out/r04_stream_kernel_stats.csv | head -24
 python tools_dev/frame_timeline.py $(ls $D/frame/*/*kernel_trace.csv | tail -1) --all > gpurun_out/r04_frame_timeline_b1.txt; tail -16 gpurun_out/r04_frame_timeline_b1.txt
 for f in 1 32; do echo "post-network kernels, $f frame(s)"; python tools_dev/kstats.py $(ls $D/post$f/*/*kernel_stats.csv | tail -1) --top 12 --out gpurun_out/r04_post_b${f}_kernel_stats.csv | head -12; done
+rm -rf $D      # raw traces stay on the box: gpurun copies back 64 MiB at most
 timeout 900 python bench.py > gpurun_out/r04_bench.json 2> gpurun_out/r04_bench.err; python tools_dev/bench_summary.py gpurun_out/r04_bench.json
