@@ -1301,6 +1301,9 @@ int launch_up4_compress(const Up4Args& a, hipStream_t s) {
 #ifndef FPC_WINO_STAGGER
 #define FPC_WINO_STAGGER 1
 #endif
+#ifndef FPC_WINO_B3_OLDER
+#define FPC_WINO_B3_OLDER 1
+#endif
 #ifndef FPC_WINO_LATE_AT
 #define FPC_WINO_LATE_AT 1
 #endif
@@ -1625,7 +1628,10 @@ __global__ __launch_bounds__(64 * NW, BF3 ? 1 : 2) void k_conv_wino(const WinoAr
     // MFMA partner starves it: 1550 cycles against 12 for the SGPR-base form — tools_dev/dma_vs_mfma.hip).
     // The bases advance on the scalar unit, the lane offsets never change: no vector instruction per K-step.
     const float* wsb = P.w + (size_t)nb * nkb * kWB + swv * NPIECE * 256;           // wave-uniform: this wave's pieces of step 0
-    const float* wsb3 = P.w + (size_t)nb * nkb * kWB + 8192 + swv * 512;            // BF3: its two pieces of the {b3} image
+    // BF3: the {b3} image's 16 pieces.  FPC_WINO_B3_OLDER: all of them go to the older half (waves 0-3, four each) — in the
+    // staggered loop the younger half's staging burst + matrix block is the longer chain (stamps: 1093 + 1797 cycles against
+    // 659 + 1668), so the older half takes 10-11 of a step's pieces and the younger 6-7 instead of 8-9 each.
+    const float* wsb3 = P.w + (size_t)nb * nkb * kWB + 8192 + (FPC_WINO_B3_OLDER ? (swv & 3) * 1024 : swv * 512);
     const float* isb = P.in + (size_t)b * HW * Cin;                                // image base, + 8 floats per step
     const unsigned wvo = 16u * lane;                                               // bytes
     unsigned ivo[NIN];
@@ -1668,10 +1674,16 @@ __global__ __launch_bounds__(64 * NW, BF3 ? 1 : 2) void k_conv_wino(const WinoAr
                          "global_load_lds_dwordx4 %1, %2 offset:2048\n global_load_lds_dwordx4 %1, %2 offset:3072\n" \
                          :: "s"(FPC_LDS_ADDR(lds_w + (BUF) * kWB + (swv * NPIECE + 4 * g) * 256)), "v"(wvo),       \
                             "s"(wsb + 1024 * g) : "memory", "m0");                                            \
-        if constexpr (BF3)                                                                                    \
+        if constexpr (BF3 && !FPC_WINO_B3_OLDER)                                                              \
             asm volatile("s_mov_b32 m0, %0\n s_nop 0\n"                                                       \
                          "global_load_lds_dwordx4 %1, %2\n global_load_lds_dwordx4 %1, %2 offset:1024\n"      \
                          :: "s"(FPC_LDS_ADDR(lds_w + (BUF) * kWB + 8192 + swv * 512)), "v"(wvo), "s"(wsb3) : "memory", "m0"); \
+        if constexpr (BF3 && FPC_WINO_B3_OLDER)                                                               \
+            if (swv < 4)                                                                                      \
+                asm volatile("s_mov_b32 m0, %0\n s_nop 0\n"                                                   \
+                             "global_load_lds_dwordx4 %1, %2\n global_load_lds_dwordx4 %1, %2 offset:1024\n"  \
+                             "global_load_lds_dwordx4 %1, %2 offset:2048\n global_load_lds_dwordx4 %1, %2 offset:3072\n" \
+                             :: "s"(FPC_LDS_ADDR(lds_w + (BUF) * kWB + 8192 + swv * 1024)), "v"(wvo), "s"(wsb3) : "memory", "m0"); \
     } while (0)
     // input region of one K-step -> input buffer BUF (in-image lanes only)
 #define FPC_WB_ISSUE_IN(BUF)                                                                                  \
@@ -1839,7 +1851,9 @@ __global__ __launch_bounds__(64 * NW, BF3 ? 1 : 2) void k_conv_wino(const WinoAr
                 if (j == 1) { vn[2] = sub_s4(e[2], e[1]); vn[3] = sub_s4(e[1], e[3]); }
                 __builtin_amdgcn_sched_barrier(0);
                 u0 = n0; u1 = n1; t0 = m0; t1 = m1; h0 = g0; h1 = g1;
-                // stagger: the compute-first half stages after xi FPC_WINO_LATE_AT of its matrix block (3 = after the block)
+                // stagger: the compute-first half stages after xi FPC_WINO_LATE_AT of its matrix block (3 = after the block): the
+                // pieces land while the rest of the block runs (3415 -> 3170 cycles per K-step against staging after the block;
+                // the stage-first half staging inside its block as well: 3500-4100)
                 if (j == FPC_WINO_LATE_AT && FPC_WINO_LATE_AT < 3 && !stage_first) {
                     FPC_WB_ISSUE_W(cur ^ 1);
                     FPC_WB_ISSUE_IN(cur);
