@@ -103,6 +103,9 @@ constexpr int kLdsRow = kConvBK;
 #ifndef FPC_IGEMM_DMA_B
 #define FPC_IGEMM_DMA_B 1
 #endif
+#ifndef FPC_IGEMM_INTERLEAVE
+#define FPC_IGEMM_INTERLEAVE 1
+#endif
 
 // One K-step of operands, global -> registers.  Thread (sr, sq) owns rows sr + 32*i and the float4 at
 // column 4*sq of the 32-wide K-step.  (Macros, not functions: hipcc keeps by-reference register
@@ -485,6 +488,54 @@ __global__ __launch_bounds__(256, (BM * BN >= 128 * 128) ? 1 : 2) void k_conv_ig
         FPC_BF3_MFMA(ga1, gb1);                                                                               \
         __builtin_amdgcn_s_setprio(0);                                                                        \
     } while (0)
+    // Split precision with DMA-staged weights: the matrix block of LDS buffer BUF with the split of the NEXT step's
+    // activation registers (ra -> the three planes of buffer BUF ^ 1) cut into 6 micro-steps per row — and, and-subtract,
+    // and, subtract, pack, three 8-byte LDS stores — that are issued one after each MFMA (or every second one), in the matrix
+    // instructions' shadow instead of as a block of 44 vector instructions + 6 ds_write_b64 behind them.  Runs unconditionally:
+    // past the last step it splits stale registers into a buffer nobody reads (the epilogue's patches come after a barrier).
+    // Not for the 128 x 128 tile: fully unrolled there the block needs more than 512 registers.
+#define FPC_CONV_COMPUTE_STORE_BF3(BUF, ra)                                                                   \
+    do {                                                                                                      \
+        const char* Ab = reinterpret_cast<const char*>(lds) + (BUF) * (BM + BN) * 192 + (wm * (BM / 2) + li) * 64;        \
+        const char* Bb = reinterpret_cast<const char*>(lds) + (BUF) * (BM + BN) * 192 + (BM + wn * (BN / 2) + li) * 64;   \
+        char* st_ = reinterpret_cast<char*>(lds) + ((BUF) ^ 1) * (BM + BN) * 192;                             \
+        bf16x8 ga[2][3][TM], gb[2][3][TN];                                                                    \
+        FPC_BF3_FRAG(0, ga[0], gb[0]);                                                                        \
+        FPC_BF3_FRAG(1, ga[1], gb[1]);                                                                        \
+        __builtin_amdgcn_sched_barrier(0);                                                                    \
+        __builtin_amdgcn_s_setprio(1);                                                                        \
+        constexpr int kNM = 12 * TM * TN, kNS = 6 * AR;      /* MFMAs, split micro-steps */                    \
+        constexpr int kPa[6] = {2, 0, 1, 1, 0, 0}, kPb[6] = {0, 2, 1, 0, 1, 0};                               \
+        unsigned sb1_[AR][4], sb2_[AR][4];                                                                    \
+        float sr_[AR][4], sq_[AR][4];                                                                         \
+        u32x2 sp1_[AR], sp2_[AR], sp3_[AR];                                                                   \
+        _Pragma("unroll") for (int m_ = 0; m_ < kNM; ++m_) {                                                  \
+            const int kk_ = m_ / (6 * TM * TN), t_ = (m_ / 6) % (TM * TN), c_ = m_ % 6;                       \
+            const int i_ = t_ / TN, j_ = t_ % TN;                                                             \
+            acc[i_][j_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ga[kk_][kPa[c_]][i_], gb[kk_][kPb[c_]][j_], acc[i_][j_], 0, 0, 0); \
+            _Pragma("unroll") for (int ns_ = m_ * kNS / kNM; ns_ < (m_ + 1) * kNS / kNM; ++ns_) {             \
+                const int r_ = ns_ / 6, ph_ = ns_ % 6;                                                        \
+                if (ph_ == 0) { _Pragma("unroll") for (int e = 0; e < 4; ++e) { const float x_ = ra[r_][e]; sb1_[r_][e] = __builtin_bit_cast(unsigned, x_) & 0xFFFF0000u; } } \
+                if (ph_ == 1) { _Pragma("unroll") for (int e = 0; e < 4; ++e) { const float x_ = ra[r_][e]; sr_[r_][e] = x_ - __builtin_bit_cast(float, sb1_[r_][e]); } } \
+                if (ph_ == 2) { _Pragma("unroll") for (int e = 0; e < 4; ++e) sb2_[r_][e] = __builtin_bit_cast(unsigned, sr_[r_][e]) & 0xFFFF0000u; } \
+                if (ph_ == 3) { _Pragma("unroll") for (int e = 0; e < 4; ++e) sq_[r_][e] = sr_[r_][e] - __builtin_bit_cast(float, sb2_[r_][e]); } \
+                if (ph_ == 4) {                                                                               \
+                    const float x0_ = ra[r_][0], x1_ = ra[r_][1], x2_ = ra[r_][2], x3_ = ra[r_][3];           \
+                    sp1_[r_] = u32x2{pack_hi16(x0_, x1_), pack_hi16(x2_, x3_)};                               \
+                    sp2_[r_] = u32x2{pack_hi16(sr_[r_][0], sr_[r_][1]), pack_hi16(sr_[r_][2], sr_[r_][3])};   \
+                    sp3_[r_] = u32x2{pack_hi16(sq_[r_][0], sq_[r_][1]), pack_hi16(sq_[r_][2], sq_[r_][3])};   \
+                }                                                                                             \
+                if (ph_ == 5) {                                                                               \
+                    char* d_ = st_ + (sr + 32 * r_) * 64 + bf3_w;                                             \
+                    *reinterpret_cast<u32x2*>(d_) = sp1_[r_];                                                 \
+                    *reinterpret_cast<u32x2*>(d_ + (BM + BN) * 64) = sp2_[r_];                                \
+                    *reinterpret_cast<u32x2*>(d_ + 2 * (BM + BN) * 64) = sp3_[r_];                            \
+                }                                                                                             \
+            }                                                                                                 \
+            __builtin_amdgcn_sched_barrier(0);                                                                \
+        }                                                                                                     \
+        __builtin_amdgcn_s_setprio(0);                                                                        \
+    } while (0)
 #define FPC_STORE_ANY(BUF, ra, rb) do { if (BF3) FPC_CONV_STORE_BF3(BUF, ra, rb); else FPC_CONV_STORE(BUF, ra, rb); } while (0)
 #define FPC_COMPUTE_ANY(BUF) do { if (BF3) FPC_CONV_COMPUTE_BF3(BUF); else FPC_CONV_COMPUTE(BUF); } while (0)
 
@@ -506,16 +557,22 @@ __global__ __launch_bounds__(256, (BM * BN >= 128 * 128) ? 1 : 2) void k_conv_ig
         // even phase: LDS buffer 0 holds step ks, set 0 holds ks+1
         if constexpr (DMAB) { if (ks + 1 < ks1) FPC_CONV_DMA_B(1); }
         if (ks + 2 < ks1) FPC_CONV_LOAD(ks + 2, ra1, rb1);
-        FPC_COMPUTE_ANY(0);
-        if (ks + 1 < ks1) FPC_STORE_ANY(1, ra0, rb0);
+        if constexpr (DMAB && FPC_IGEMM_INTERLEAVE && BM * BN < 128 * 128) FPC_CONV_COMPUTE_STORE_BF3(0, ra0);
+        else {
+            FPC_COMPUTE_ANY(0);
+            if (ks + 1 < ks1) FPC_STORE_ANY(1, ra0, rb0);
+        }
         if constexpr (DMAB) FPC_CONV_DMA_WAIT(ks + 2 < ks1);
         __syncthreads();
         if (ks + 1 >= ks1) break;
         // odd phase: LDS buffer 1 holds step ks+1, set 1 holds ks+2
         if constexpr (DMAB) { if (ks + 2 < ks1) FPC_CONV_DMA_B(0); }
         if (ks + 3 < ks1) FPC_CONV_LOAD(ks + 3, ra0, rb0);
-        FPC_COMPUTE_ANY(1);
-        if (ks + 2 < ks1) FPC_STORE_ANY(0, ra1, rb1);
+        if constexpr (DMAB && FPC_IGEMM_INTERLEAVE && BM * BN < 128 * 128) FPC_CONV_COMPUTE_STORE_BF3(1, ra1);
+        else {
+            FPC_COMPUTE_ANY(1);
+            if (ks + 2 < ks1) FPC_STORE_ANY(0, ra1, rb1);
+        }
         if constexpr (DMAB) FPC_CONV_DMA_WAIT(ks + 3 < ks1);
         __syncthreads();
     }
