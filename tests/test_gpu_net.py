@@ -118,6 +118,9 @@ CONV_CASES = [
     (1, 128, 16, 24, 128, 3, 1, 1, (64, 128, 1001), "gn"),
     (2, 64, 24, 32, 256, 1, 1, 0, (64, 64, 1001), "bias_up"),     # FPN lateral
     (1, 64, 24, 32, 128, 1, 2, 0, (128, 64, 1001), "bn"),         # 1x1 stride 2
+    (1, 96, 20, 24, 64, 3, 1, 1, (64, 64, 1002), "bias_relu"),    # 27 K-steps in slices of 14 + 13: both phase parities end a slice (DMA-staged weight planes)
+    (1, 32, 12, 16, 64, 3, 1, 1, (64, 64, 1001), "bias_relu"),    # 9 K-steps, one slice
+    (1, 32, 12, 16, 64, 1, 1, 0, (64, 64, 1001), "bias"),         # a single K-step: prologue only
     # split-precision Winograd (nsplit = -5): transformed tiles split into three bf16 pieces, three bf16 MFMAs per K-step, 8 waves
     (1, 64, 30, 40, 64, 3, 1, 1, (0, 0, -5), "bn_relu_res"),
     (2, 256, 15, 20, 128, 3, 1, 1, (0, 0, -5), "gn"),
