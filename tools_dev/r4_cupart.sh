@@ -12,6 +12,8 @@ except Exception as e:
     print(" ".join(sys.argv[1:]), "failed", e); print(open("gpurun_out/cupart.err").read()[-1500:])
 PY
 }
-run FPC_CU_PARTITION=1 "--net-streams 2"
-run FPC_CU_PARTITION=0 "--net-streams 2"
-run FPC_CU_PARTITION=1 "--net-streams 2 --frames-in-flight 2"
+run "FPC_CU_PARTITION=1 FPC_BENCH_SIDE_STREAM=1" "--frames-in-flight 4"
+run "FPC_CU_PARTITION=1 FPC_BENCH_SIDE_STREAM=1" "--frames-in-flight 8"
+run "FPC_CU_PARTITION=1 FPC_BENCH_SIDE_STREAM=1" "--net-streams 8"
+run "FPC_CU_PARTITION=1 FPC_BENCH_SIDE_STREAM=1 GPU_MAX_HW_QUEUES=16" "--net-streams 8"
+run "FPC_CU_PARTITION=0" ""
