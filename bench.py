@@ -87,7 +87,8 @@ def parse(argv=None):
     ap.add_argument("--gather-every", type=int, default=0, help="frames per pose all-gather on the side stream (0 = frames in flight)")
     ap.add_argument("--check-gather", action="store_true", help="N > 1: verify the gathered pose records against every rank's records rebuilt locally")
     ap.add_argument("--vote-only", action="store_true", help="time only the post-network stages (profiling aid)")
-    ap.add_argument("--tune-mode", type=int, default=0, help="conv autotune objective: 0 latency, 1 latency x sqrt(chip share)")
+    ap.add_argument("--tune-mode", type=int, default=0, help="conv autotune objective of the model's own plan (the `backbone` object): 0 latency, 1 latency x sqrt(chip share)")
+    ap.add_argument("--stream-tune-mode", type=int, default=1, help="the same for the frame-streaming runtime's plans (several frames in flight); -1: the runtime's first plan is the model's own")
     ap.add_argument("--net-streams", type=int, default=4, help="frame streams: native plans on their own HIP streams that take consecutive frames")
     ap.add_argument("--frames-in-flight", type=int, default=0, help="frames submitted before the oldest is collected (0 = frame streams + 1)")
     ap.add_argument("--post-stream", action="store_true", help="run the post-network stages of all frames on one extra stream instead of the frame's own")
@@ -442,8 +443,11 @@ def run_inference(args, encoder, Bq, hn, steps, warmup, world, rank, dev, want_b
     n_inst = 6 * Bq                                           # vote-bench fixture: 6 instances per frame
     cap = 64 * Bq
 
+    # the runtime's plans are autotuned for several frames in flight (latency x sqrt(share of the chip a launch occupies));
+    # the model's own plan — what `backbone` times, one network alone — for latency
+    stream_tune = None if (args.no_pipeline or args.stream_tune_mode < 0) else args.stream_tune_mode
     streamer = FrameStreamer(model_gpu, net_streams=1 if args.no_pipeline else args.net_streams,
-                             post_inline=not args.post_stream, coalesce=coalesce)
+                             post_inline=not args.post_stream, coalesce=coalesce, tune_mode=stream_tune)
     s_net = streamer.net_streams[0]
     depth = 0 if args.no_pipeline else (args.frames_in_flight - 1 if args.frames_in_flight > 0 else len(streamer.models))
     if coalesce > 1:                                          # a group per stream in flight, and one being filled
@@ -555,7 +559,7 @@ def run_inference(args, encoder, Bq, hn, steps, warmup, world, rank, dev, want_b
            "local_s": median(local), "pose_gather": pose_gather,
            "workload": f"{encoder}-FPN + all heads, batch={Bq} 640x480 per GPU per step, {1 + depth} frames in flight on "
                        f"{len(streamer.models)} streams, hn={hn}, {n_inst} instances per step (vote-bench fixture), random-init weights",
-           "global_batch": world * Bq, "frames_in_flight": 1 + depth, "net_streams": len(streamer.models),
+           "global_batch": world * Bq, "frames_in_flight": 1 + depth, "net_streams": len(streamer.models), "stream_tune_mode": stream_tune,
            "ms_per_frame_one_in_flight": round(latency_ms, 4)}
 
     # the same pipeline fed from HOST memory: decoded u8 frames -> pinned staging -> H2D -> preprocessing kernels -> network

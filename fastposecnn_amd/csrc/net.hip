@@ -464,7 +464,7 @@ int run_conv(fpc_net* n, ConvArgs& a, int groups, int ci, hipStream_t s) {
             int rc = launch_conv_plan(a, q, groups, s);     // warm-up (also validates the launch)
             if (rc) { (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); return rc; }
             float ms = 1e30f;
-            for (int rep = 0; rep < 2; ++rep) {
+            for (int rep = 0; rep < 3; ++rep) {
                 float t = 0.f;
                 bool timed = hipEventRecord(e0, s) == hipSuccess && launch_conv_plan(a, q, groups, s) == FPC_OK &&
                              hipEventRecord(e1, s) == hipSuccess && hipEventSynchronize(e1) == hipSuccess &&
@@ -474,14 +474,14 @@ int run_conv(fpc_net* n, ConvArgs& a, int groups, int ci, hipStream_t s) {
             // objective: latency, or (throughput mode) latency x the share of the chip the launch occupies —
             // with several frames in flight a launch that leaves CUs free lets another stream's kernels run
             float score = ms;
-            if (n->tune_mode == 1) {
+            if (n->tune_mode >= 1) {
                 double nblk = q.wino ? (double)cdiv(cdiv(a.Wo, 2), 8) * cdiv(cdiv(a.Ho, 2), (q.wino == 2 || q.wino == 4 || q.wino == 5) ? 8 : 4) * a.B * (a.Cout / 64) * groups
                                      : (double)q.mtiles * q.ntiles * q.nsplit * a.B * groups;
                 double slots = 256.0 * ((q.wino == 2 || q.wino == 4 || q.wino == 5) ? 1.0 : 2.0);
                 double share = nblk / slots;
                 if (share > 1.0) share = 1.0;
                 if (share < 0.125) share = 0.125;
-                score = ms * (float)sqrt(share);
+                score = ms * (float)(n->tune_mode == 2 ? share : sqrt(share));      // 2: latency x share = the launch's CU-time
             }
             if (score < best_ms) { best_ms = score; best = q; }
         }
@@ -724,7 +724,7 @@ extern "C" int fpc_net_forward_bits(fpc_net_t* n, const float* x, float* logits_
 // The NEXT fpc_net_forward times every candidate tiling of every convolution site on the device
 // (it synchronises the stream; not capturable) and keeps the fastest; later forwards reuse the plans.
 extern "C" int fpc_net_autotune_next(fpc_net_t* n, int mode) {
-    if (!n || !n->loaded || mode < 0 || mode > 1) return FPC_EINVAL;
+    if (!n || !n->loaded || mode < 0 || mode > 2) return FPC_EINVAL;
     n->tuning = true;
     n->tune_mode = mode;
     if (n->graph_exec) { (void)hipGraphExecDestroy(n->graph_exec); n->graph_exec = nullptr; }      // tilings may change

@@ -35,19 +35,26 @@ import torch
 
 class FrameStreamer:
 
-    def __init__(self, model, net_streams=4, device=None, post_inline=True, coalesce=1):
+    def __init__(self, model, net_streams=4, device=None, post_inline=True, coalesce=1, tune_mode=None):
         p = next(model.parameters())
         self.device = device if device is not None else p.device
         if self.device.type != "cuda":
             raise RuntimeError("FrameStreamer needs the model on a GPU")
         if model.training:
             raise RuntimeError("FrameStreamer is an inference runtime: call model.eval() first")
-        self.models = [model]
-        for _ in range(max(1, int(net_streams)) - 1):
+        # tune_mode (fpc_net_autotune_next: 1 = latency x sqrt(share of the chip) — the objective for several frames in flight):
+        # every plan of the runtime, the first included, is then a copy with its own HPARAM.ENGINE_TUNE_MODE, and the caller's
+        # model keeps whatever plan it tunes for itself (the tilings differ, so results equal the caller's own forward only to
+        # f32 rounding, like any two tuned plans).  None: the first plan is the caller's model with its own setting.
+        self.models = [model] if tune_mode is None else []
+        while len(self.models) < max(1, int(net_streams)):
             m = copy.copy(model)            # shares parameters / sub-modules, owns its native plans
             m._engines = {}
             m._fused = None
             m._pinned_counts, m._pinned_next = [], -1     # its own read-back slots (post_network_enqueue)
+            if tune_mode is not None:
+                m.HPARAM = copy.copy(model.HPARAM)
+                m.HPARAM.ENGINE_TUNE_MODE = int(tune_mode)
             self.models.append(m)
         self.net_streams = [torch.cuda.Stream(device=self.device) for _ in self.models]
         self.post_stream = None if post_inline else torch.cuda.Stream(device=self.device)

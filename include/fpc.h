@@ -334,7 +334,9 @@ int fpc_net_forward_bits(fpc_net_t* net, const float* x, float* logits_mask, flo
  * a valid forward; it synchronises the stream, so it must not be captured into a graph.
  * fpc_net_conv_plan reports the tiling in use for convolution i: out5 = bm, bn, nsplit, Cout, K. */
 int fpc_net_autotune_next(fpc_net_t* net, int mode /* 0: minimise each conv's latency; 1: latency x sqrt(share of
-                                                      the chip its grid occupies) — for several frames in flight */);
+                                                      the chip its grid occupies) — for several frames in flight
+                                                      (what FrameStreamer(tune_mode=1) and bench.py's stream use);
+                                                      2: latency x share (the launch's CU-time) */);
 /* Split-precision matrix products (library default 0; the Python front end turns it on unless
  * HPARAM.ENGINE_SPLIT_PRECISION is False).  1: autotuning may replace the f32 matrix instructions of a direct OR a
  * Winograd convolution by the exact three-way bf16 split of both operands (x = x1 + x2 + x3, each piece 8 significant

@@ -5,13 +5,11 @@ run() {
   timeout 600 python bench.py --no-train-line --no-config3 --no-hn128 --no-cpu-baseline --no-plain-f32 --no-batch-scan "$@" > gpurun_out/knob.json 2> gpurun_out/knob.err
   python - "$@" <<PY
 import json, sys
-d = json.loads(open("gpurun_out/knob.json").read().strip().splitlines()[-1])
-print(" ".join(sys.argv[1:]) or "(default)", "-> value", d["value"], "backbone", d.get("backbone", {}).get("ms"))
+try:
+    d = json.loads(open("gpurun_out/knob.json").read().strip().splitlines()[-1])
+    print(" ".join(sys.argv[1:]) or "(default)", "-> value", d["value"], "backbone", d.get("backbone", {}).get("ms"))
+except Exception as e:
+    print("failed", e); print(open("gpurun_out/knob.err").read()[-2000:])
 PY
 }
-run
-run --tune-mode 1
-run --net-streams 5
-run --net-streams 3
-run --frames-in-flight 6
-run
+for i in 1 2 3; do run; run --stream-tune-mode -1; done
