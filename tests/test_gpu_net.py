@@ -386,9 +386,11 @@ def test_engine_follows_training_steps(lib, dev):
         assert (o - ref).abs().max().item() <= tol
 
 
-@pytest.mark.parametrize("kw", [dict(), dict(net_streams=2, post_inline=False)], ids=["4-streams-inline", "2-streams+post-stream"])
+@pytest.mark.parametrize("kw", [dict(), dict(net_streams=2, post_inline=False), dict(net_streams=2, tune_mode=1)],
+                         ids=["4-streams-inline", "2-streams+post-stream", "2-streams-throughput-tuned"])
 def test_frame_streamer_matches_forward(lib, dev, kw):
-    """Three frames in flight on the streaming runtime give, frame by frame, what forward() gives."""
+    """Three frames in flight on the streaming runtime give, frame by frame, what forward() gives.  tune_mode=1: every plan
+    of the runtime is a copy tuned for several frames in flight; the caller's model keeps its own plan."""
     from fastposecnn_amd import config, synth
     from fastposecnn_amd.streaming import FrameStreamer
     hp = config.INFERENCE()
@@ -413,6 +415,9 @@ def test_frame_streamer_matches_forward(lib, dev, kw):
     torch.manual_seed(99)
     st.prepare(xs[0], categorical_override=cats[0])        # builds every stream's plan up front (bench.py's set-up)
     assert len(st._warm) == len(st.models)
+    if kw.get("tune_mode") is not None:
+        assert all(mm is not m and mm.HPARAM.ENGINE_TUNE_MODE == kw["tune_mode"] for mm in st.models)
+        assert getattr(m.HPARAM, "ENGINE_TUNE_MODE", 0) == 0
     tickets = []
     for i in range(5):
         torch.manual_seed(100 + i)                     # the vote's sampler seed is drawn at submit time
