@@ -1,9 +1,9 @@
 #!/bin/bash
-# streamed rate of the default plan under bench.py's runtime knobs, one box
+# streamed rate of the default plan under runtime knobs, one box
 cd $GRAFT_REPO_ROOT
 run() {
-  timeout 600 python bench.py --no-train-line --no-config3 --no-hn128 --no-cpu-baseline --no-plain-f32 --no-batch-scan "$@" > gpurun_out/knob.json 2> gpurun_out/knob.err
-  python - "$@" <<PY
+  env $1 timeout 600 python bench.py --no-train-line --no-config3 --no-hn128 --no-cpu-baseline --no-plain-f32 --no-batch-scan $2 > gpurun_out/knob.json 2> gpurun_out/knob.err
+  python - "$1" "$2" <<PY
 import json, sys
 try:
     d = json.loads(open("gpurun_out/knob.json").read().strip().splitlines()[-1])
@@ -12,4 +12,8 @@ except Exception as e:
     print("failed", e); print(open("gpurun_out/knob.err").read()[-2000:])
 PY
 }
-for i in 1 2 3; do run; run --stream-tune-mode -1; done
+run "FPC_X=0" ""
+run "FPC_STREAM_PRIO=-1,0,0,0" ""
+run "FPC_STREAM_PRIO=-1,-1,0,0" ""
+run "FPC_STREAM_PRIO=-1,-1,-1,-1" ""
+run "FPC_X=0" ""
