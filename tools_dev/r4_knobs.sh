@@ -12,8 +12,7 @@ except Exception as e:
     print("failed", e); print(open("gpurun_out/knob.err").read()[-2000:])
 PY
 }
-run "FPC_X=0" ""
-run "FPC_STREAM_PRIO=-1,0,0,0" ""
-run "FPC_STREAM_PRIO=-1,-1,0,0" ""
-run "FPC_STREAM_PRIO=-1,-1,-1,-1" ""
-run "FPC_X=0" ""
+for i in 1 2 3 4; do
+run "FPC_X=1" ""
+run "FPC_X=1" "--stream-tune-mode -1"
+done
