@@ -88,6 +88,7 @@ def parse(argv=None):
     ap.add_argument("--check-gather", action="store_true", help="N > 1: verify the gathered pose records against every rank's records rebuilt locally")
     ap.add_argument("--vote-only", action="store_true", help="time only the post-network stages (profiling aid)")
     ap.add_argument("--tune-mode", type=int, default=0, help="conv autotune objective of the model's own plan (the `backbone` object): 0 latency, 1 latency x sqrt(chip share)")
+    ap.add_argument("--tune-trials", type=int, default=3, help="headline stream: build the runtime's set of plans this many times and keep the set that streams fastest (set-up, untimed)")
     ap.add_argument("--stream-tune-mode", type=int, default=1, help="the same for the frame-streaming runtime's plans (several frames in flight); -1: the runtime's first plan is the model's own")
     ap.add_argument("--net-streams", type=int, default=4, help="frame streams: native plans on their own HIP streams that take consecutive frames")
     ap.add_argument("--frames-in-flight", type=int, default=0, help="frames submitted before the oldest is collected (0 = frame streams + 1)")
@@ -412,7 +413,7 @@ def check_gather(model_gpu, gatherer, cat, Bq, world, rank, cap, dev):
     return bool(flag.item() > 0.5)
 
 
-def run_inference(args, encoder, Bq, hn, steps, warmup, world, rank, dev, want_backbone=True, split_precision=None, coalesce=1):
+def run_inference(args, encoder, Bq, hn, steps, warmup, world, rank, dev, want_backbone=True, split_precision=None, coalesce=1, tune_trials=1):
     """The timed hot path for one (encoder, batch) configuration.  Returns a dict of measurements and the objects
     later sections reuse."""
     import torch
@@ -489,7 +490,8 @@ def run_inference(args, encoder, Bq, hn, steps, warmup, world, rank, dev, want_b
 
     # set-up, not warm-up: every stream's plan is built and autotuned here (seconds), whatever --warmup says
     if not args.vote_only:
-        streamer.prepare(x, categorical_override=cat)
+        # (tune_trials > 1: the set of plans is built that many times and the set that streams fastest is kept — untimed set-up)
+        streamer.prepare(x, categorical_override=cat, tune_trials=1 if args.no_pipeline else tune_trials)
     for _ in range(2 * (depth + 1)):       # ... and every stream's allocator pool has seen a full pipeline of frames
         step()
     drain()
@@ -560,6 +562,7 @@ def run_inference(args, encoder, Bq, hn, steps, warmup, world, rank, dev, want_b
            "workload": f"{encoder}-FPN + all heads, batch={Bq} 640x480 per GPU per step, {1 + depth} frames in flight on "
                        f"{len(streamer.models)} streams, hn={hn}, {n_inst} instances per step (vote-bench fixture), random-init weights",
            "global_batch": world * Bq, "frames_in_flight": 1 + depth, "net_streams": len(streamer.models), "stream_tune_mode": stream_tune,
+           "tune_trials": tune_trials, "trial_rates_img_per_s": getattr(streamer, "trial_rates", []),
            "ms_per_frame_one_in_flight": round(latency_ms, 4)}
 
     # the same pipeline fed from HOST memory: decoded u8 frames -> pinned staging -> H2D -> preprocessing kernels -> network
@@ -750,7 +753,7 @@ def main():
     from fastposecnn_amd import synth, _native
     _native.lib()      # fail loudly if the HIP library is missing
 
-    res, ctx = run_inference(args, args.encoder, args.batch, args.hn, args.steps, args.warmup, world, rank, dev)
+    res, ctx = run_inference(args, args.encoder, args.batch, args.hn, args.steps, args.warmup, world, rank, dev, tune_trials=args.tune_trials)
     multi = (multi_rank_fields(dist, torch, world, rank, dev, res["local_s"], args.batch * args.steps, backend, cores)
              if world > 1 else {"scaling_measured": False})
 
@@ -773,6 +776,8 @@ def main():
                        "parallelism": f"image-sharded dp{world}" if world > 1 else "single GPU",
                        "vote_only": bool(args.vote_only), "frames_in_flight": res["frames_in_flight"],
                        "net_streams": res["net_streams"], "ms_per_frame_one_in_flight": res["ms_per_frame_one_in_flight"],
+                       "stream_tune_mode": res.get("stream_tune_mode"), "tune_trials": res.get("tune_trials"),
+                       "trial_rates_img_per_s": res.get("trial_rates_img_per_s"),
                        "pose_gather": res["pose_gather"],
                        "matrix_products": ("f32 operands, f32 accumulation, f32 results (dtype f32).  Where the autotuner finds it "
                                            "faster a convolution's products run as the EXACT three-way bf16 split of both operands "

@@ -115,13 +115,47 @@ class FrameStreamer:
                         ticket["agg_only"] = model.aggregate(src)
         return ticket
 
-    def prepare(self, x, categorical_override=None):
+    def prepare(self, x, categorical_override=None, tune_trials=1, trial_frames=64):
         """Build (and autotune) every stream's native plan for this input shape now, one at a time on an otherwise
-        idle GPU, by running one frame through each.  Optional: `submit` does the same lazily on a plan's first frame."""
-        for _ in range(len(self.models)):
-            ts = [self.submit(x, categorical_override=categorical_override) for _ in range(self.coalesce if x.shape[0] == 1 else 1)]
-            for t in ts:
-                self.collect(t)
+        idle GPU, by running one frame through each.  Optional: `submit` does the same lazily on a plan's first frame.
+
+        tune_trials = N > 1 (one frame per launch only): the per-convolution autotuning times candidates alone on the chip,
+        and the tilings it picks vary from run to run by 2-3 % of the STREAMED rate; so the whole set of plans is built N
+        times, each set is run as it will be used — `trial_frames` frames through all streams with the usual number in flight —
+        and the set that streams fastest is kept (`self.trial_rates`: frames per second of every trial)."""
+        import time
+        trials = max(1, int(tune_trials)) if self.coalesce == 1 else 1
+        best, self.trial_rates = None, []
+        for trial in range(trials):
+            if trial > 0:                                      # new plans: drop the ones just measured (the best set stays referenced)
+                for m in self.models:
+                    m._engines, m._fused = {}, None
+                self._warm.clear()
+            for _ in range(len(self.models)):
+                ts = [self.submit(x, categorical_override=categorical_override) for _ in range(self.coalesce if x.shape[0] == 1 else 1)]
+                for t in ts:
+                    self.collect(t)
+            if trials == 1:
+                return
+            rates = []
+            for _ in range(3):
+                pend = []
+                torch.cuda.synchronize(self.device)
+                t0 = time.perf_counter()
+                for _ in range(int(trial_frames)):
+                    pend.append(self.submit(x, categorical_override=categorical_override))
+                    if len(pend) > len(self.models):
+                        self.collect(pend.pop(0))
+                while pend:
+                    self.collect(pend.pop(0))
+                torch.cuda.synchronize(self.device)
+                rates.append(int(trial_frames) * x.shape[0] / (time.perf_counter() - t0))
+            rate = sorted(rates)[1]
+            self.trial_rates.append(round(rate, 1))
+            if best is None or rate > best[0]:
+                best = (rate, [(m._engines, m._fused) for m in self.models])
+        for m, (eng, fused) in zip(self.models, best[1]):
+            m._engines, m._fused = eng, fused
 
     def submit(self, x, categorical_override=None, ready=None):
         """Enqueue one frame (see `_submit_now`).  With coalesce = k > 1 and a single-frame x: the frame joins the current group;

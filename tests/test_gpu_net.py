@@ -436,6 +436,36 @@ def test_frame_streamer_matches_forward(lib, dev, kw):
         assert out["aggregated"]["class_ids"].shape[0] == 3
 
 
+def test_frame_streamer_keeps_the_fastest_of_several_plan_sets(lib, dev):
+    """prepare(tune_trials=N): the runtime's plans are built N times, each set streamed, the fastest kept — the kept plans
+    are live (graphs recorded on their streams) and give the model's own forward to rounding."""
+    from fastposecnn_amd import config, synth
+    from fastposecnn_amd.streaming import FrameStreamer
+    hp = config.INFERENCE()
+    hp.RUNTIME_TIMING = False
+    hp.HV_NUM_OF_HYPOTHESES = 128
+    torch.manual_seed(0)
+    m = lib.pose_regressor.MODELS['PoseRegressor'].load_from_ckpt(None, hp).to(dev).eval()
+    H, W = 96, 128
+    x = synth.make_image(3, H, W)[None].to(dev)
+    c, _ = synth.make_vote_frame(3, K=3, H=H, W=W, rmin=8, rmax=20)
+    cat = {k: v.to(dev) for k, v in c.items()}
+    with torch.no_grad():
+        ref = m.pure_model_forward(x)
+    st = FrameStreamer(m, net_streams=2, tune_mode=1)
+    st.prepare(x, categorical_override=cat, tune_trials=3, trial_frames=8)
+    assert len(st.trial_rates) == 3 and all(r > 0 for r in st.trial_rates)
+    assert all(len(mm._engines) == 1 for mm in st.models)
+    kept = [next(iter(mm._engines.values())) for mm in st.models]
+    outs = [st.collect(st.submit(x, categorical_override=cat)) for _ in range(4)]
+    assert [next(iter(mm._engines.values())) for mm in st.models] == kept          # no plan was rebuilt by the frames after prepare
+    for out in outs:
+        for k in ("mask", "quaternion", "scales", "xy", "z"):
+            a, b = out["logits"][k], ref[k]
+            assert (a - b).abs().max().item() <= 1e-4 * max(1.0, b.abs().max().item()), k
+        assert out["aggregated"]["class_ids"].shape[0] == 3
+
+
 def test_frame_streamer_async_consumers_and_dropped_inputs(lib, dev):
     """The ownership rule of FrameStreamer.collect under allocator pressure: every input tensor is created right before
     submit() and dropped right after it, every output is consumed by kernels queued asynchronously on the caller's stream

@@ -7,12 +7,12 @@ run() {
 import json, sys
 try:
     d = json.loads(open("gpurun_out/knob.json").read().strip().splitlines()[-1])
-    print(" ".join(sys.argv[1:]) or "(default)", "-> value", d["value"], "backbone", d.get("backbone", {}).get("ms"))
+    print(" ".join(sys.argv[1:]) or "(default)", "-> value", d["value"], "backbone", d.get("backbone", {}).get("ms"), "trials", d["config"].get("trial_rates_img_per_s"))
 except Exception as e:
     print("failed", e); print(open("gpurun_out/knob.err").read()[-2000:])
 PY
 }
-for i in 1 2 3 4; do
-run "FPC_X=1" ""
-run "FPC_X=1" "--stream-tune-mode -1"
+for i in 1 2 3; do
+run "FPC_X=1" "--tune-trials 4"
+run "FPC_X=1" "--tune-trials 1"
 done
