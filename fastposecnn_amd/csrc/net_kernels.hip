@@ -1362,7 +1362,7 @@ int launch_up4_compress(const Up4Args& a, hipStream_t s) {
 #define FPC_WINO_B3_OLDER 1
 #endif
 #ifndef FPC_WINO_LATE_AT
-#define FPC_WINO_LATE_AT 1
+#define FPC_WINO_LATE_AT 0
 #endif
 constexpr int kWinoTX = 8;                              // tile patch per workgroup: 8 wide, NW tall (NW = 4 or 8 waves)
 constexpr int kWinoRW = 2 * kWinoTX + 2;                // input region width 18
@@ -1909,8 +1909,9 @@ __global__ __launch_bounds__(64 * NW, BF3 ? 1 : 2) void k_conv_wino(const WinoAr
                 __builtin_amdgcn_sched_barrier(0);
                 u0 = n0; u1 = n1; t0 = m0; t1 = m1; h0 = g0; h1 = g1;
                 // stagger: the compute-first half stages after xi FPC_WINO_LATE_AT of its matrix block (3 = after the block): the
-                // pieces land while the rest of the block runs (3415 -> 3170 cycles per K-step against staging after the block;
-                // the stage-first half staging inside its block as well: 3500-4100)
+                // pieces land while the rest of the block runs (3415 -> 3170 cycles per K-step against staging after the block, 3123
+                // after xi 0 once the older half also carries the {b3} pieces; the stage-first half staging inside its block as
+                // well: 3500-4100)
                 if (j == FPC_WINO_LATE_AT && FPC_WINO_LATE_AT < 3 && !stage_first) {
                     FPC_WB_ISSUE_W(cur ^ 1);
                     FPC_WB_ISSUE_IN(cur);
