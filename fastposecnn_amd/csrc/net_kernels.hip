@@ -1361,6 +1361,9 @@ int launch_up4_compress(const Up4Args& a, hipStream_t s) {
 #ifndef FPC_WINO_B3_OLDER
 #define FPC_WINO_B3_OLDER 1
 #endif
+#ifndef FPC_WINO_IN_OLDER
+#define FPC_WINO_IN_OLDER 0
+#endif
 #ifndef FPC_WINO_LATE_AT
 #define FPC_WINO_LATE_AT 0
 #endif
@@ -1406,7 +1409,10 @@ __global__ __launch_bounds__(64 * NW, BF3 ? 1 : 2) void k_conv_wino(const WinoAr
     // address each lane fetches; 72 x 16 units = 18 pieces with 648 of 1152 lanes active.
     constexpr bool PERM = BF3;
     constexpr int NPI = PERM ? 18 : (POS + 31) / 32, LINP = NPI * 256;
-    constexpr int NIN = PERM ? 3 : 2;                        // input pieces per wave and K-step (NW = 8: 18 / 11 pieces over 8 waves)
+    // input pieces per wave and K-step: piece (wave + IST i), i < NIN.  NW = 8: 18 (PERM) / 11 pieces over the 8 waves, or —
+    // FPC_WINO_IN_OLDER — over the four older waves only (see the {b3} pieces)
+    constexpr bool INO = PERM && FPC_WINO_IN_OLDER;
+    constexpr int NIN = INO ? 5 : (PERM ? 3 : 2), IST = INO ? 4 : NW;
     static_assert(!PERM || NW == 8, "permuted input image is laid out for the 18 x 18 region");
     constexpr int kWB = BF3 ? 12288 : kWinoLdsW;            // floats per weight buffer (BF3: 32 KB {b1, b2} + 16 KB {b3})
     constexpr int kLdsFloats = WP ? (kWinoLdsW + 4 * WPI) : P3 ? (3 * IP3 + 3 * kWinoLdsW) : (2 * LINP + 2 * kWB);
@@ -1698,12 +1704,12 @@ __global__ __launch_bounds__(64 * NW, BF3 ? 1 : 2) void k_conv_wino(const WinoAr
         int ry, rx, hf;
         bool inreg;
         if constexpr (PERM) {
-            const int slot = (swv + NW * i) * 64 + lane;              // 16-byte unit this lane's DMA data lands in
+            const int slot = (swv + IST * i) * 64 + lane;             // 16-byte unit this lane's DMA data lands in
             const int blk = slot >> 4, res = slot & 15, g = blk >> 3;
             const int ah = (g / 3) * 4 + (res & 3), qh = (g % 3) * 4 + (res >> 2);
             hf = blk & 1;
             ry = 2 * ah + ((blk >> 2) & 1); rx = 2 * qh + ((blk >> 1) & 1);
-            inreg = swv + NW * i < NPI && ah <= 8 && qh <= 8;
+            inreg = swv + IST * i < NPI && ah <= 8 && qh <= 8 && (!INO || swv < 4);
         } else {
             const int q = (swv + NW * i) * 32 + (lane >> 1);          // LDS position of this lane's 16 bytes
             hf = lane & 1;
@@ -1745,13 +1751,9 @@ __global__ __launch_bounds__(64 * NW, BF3 ? 1 : 2) void k_conv_wino(const WinoAr
     // input region of one K-step -> input buffer BUF (in-image lanes only)
 #define FPC_WB_ISSUE_IN(BUF)                                                                                  \
     do {                                                                                                      \
-        if (iok[0]) asm volatile("s_mov_b32 m0, %0\n s_nop 0\n global_load_lds_dwordx4 %1, %2\n"              \
-                                 :: "s"(FPC_LDS_ADDR(lds + (BUF) * LINP + swv * 256)), "v"(ivo[0]), "s"(isb) : "memory", "m0"); \
-        if (iok[1]) asm volatile("s_mov_b32 m0, %0\n s_nop 0\n global_load_lds_dwordx4 %1, %2\n"              \
-                                 :: "s"(FPC_LDS_ADDR(lds + (BUF) * LINP + (swv + NW) * 256)), "v"(ivo[1]), "s"(isb) : "memory", "m0"); \
-        if constexpr (NIN > 2)                                                                                \
-            if (iok[NIN - 1]) asm volatile("s_mov_b32 m0, %0\n s_nop 0\n global_load_lds_dwordx4 %1, %2\n"     \
-                                 :: "s"(FPC_LDS_ADDR(lds + (BUF) * LINP + (swv + 2 * NW) * 256)), "v"(ivo[NIN - 1]), "s"(isb) : "memory", "m0"); \
+        _Pragma("unroll") for (int i_ = 0; i_ < NIN; ++i_)                                                    \
+            if (iok[i_]) asm volatile("s_mov_b32 m0, %0\n s_nop 0\n global_load_lds_dwordx4 %1, %2\n"         \
+                                      :: "s"(FPC_LDS_ADDR(lds + (BUF) * LINP + (swv + IST * i_) * 256)), "v"(ivo[i_]), "s"(isb) : "memory", "m0"); \
     } while (0)
 
     // ---- fragment addressing
