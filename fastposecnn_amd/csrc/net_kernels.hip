@@ -103,6 +103,9 @@ constexpr int kLdsRow = kConvBK;
 #ifndef FPC_IGEMM_DMA_B
 #define FPC_IGEMM_DMA_B 1
 #endif
+#ifndef FPC_IGEMM_PRIO
+#define FPC_IGEMM_PRIO 1
+#endif
 #ifndef FPC_IGEMM_INTERLEAVE
 #define FPC_IGEMM_INTERLEAVE 1
 #endif
@@ -483,7 +486,7 @@ __global__ __launch_bounds__(256, (BM * BN >= 128 * 128) ? 1 : 2) void k_conv_ig
         FPC_BF3_FRAG(0, ga0, gb0);                                                                            \
         FPC_BF3_FRAG(1, ga1, gb1);                                                                            \
         __builtin_amdgcn_sched_barrier(0);                                                                    \
-        __builtin_amdgcn_s_setprio(1);                                                                        \
+        __builtin_amdgcn_s_setprio(FPC_IGEMM_PRIO);                                                                        \
         FPC_BF3_MFMA(ga0, gb0);                                                                               \
         FPC_BF3_MFMA(ga1, gb1);                                                                               \
         __builtin_amdgcn_s_setprio(0);                                                                        \
@@ -503,7 +506,7 @@ __global__ __launch_bounds__(256, (BM * BN >= 128 * 128) ? 1 : 2) void k_conv_ig
         FPC_BF3_FRAG(0, ga[0], gb[0]);                                                                        \
         FPC_BF3_FRAG(1, ga[1], gb[1]);                                                                        \
         __builtin_amdgcn_sched_barrier(0);                                                                    \
-        __builtin_amdgcn_s_setprio(1);                                                                        \
+        __builtin_amdgcn_s_setprio(FPC_IGEMM_PRIO);                                                                        \
         constexpr int kNM = 12 * TM * TN, kNS = 6 * AR;      /* MFMAs, split micro-steps */                    \
         constexpr int kPa[6] = {2, 0, 1, 1, 0, 0}, kPb[6] = {0, 2, 1, 0, 1, 0};                               \
         unsigned sb1_[AR][4], sb2_[AR][4];                                                                    \
