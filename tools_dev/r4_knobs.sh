@@ -12,7 +12,8 @@ except Exception as e:
     print("failed", e); print(open("gpurun_out/knob.err").read()[-2000:])
 PY
 }
-for i in 1 2 3; do
-run "FPC_X=1" "--tune-trials 4"
-run "FPC_X=1" "--tune-trials 1"
-done
+run "FPC_X=1" ""
+run "FPC_X=1" "--frames-in-flight 6"
+run "FPC_X=1" "--frames-in-flight 8"
+run "FPC_X=1" "--frames-in-flight 4"
+run "FPC_X=1" ""
