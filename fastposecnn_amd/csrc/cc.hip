@@ -500,32 +500,56 @@ __global__ __launch_bounds__(256) void k_cca_label(const CcaArgs a, int32_t* __r
     const int32_t* gw = a.wbase + (size_t)b * nwords;
     const int32_t* rl = a.runlabel + (size_t)b * a.rstride;
     const size_t HW = (size_t)nwords * 64;
+    // Four sweeps, phase by phase: every phase's loads (bit word; left neighbour + id base; run labels) are independent of
+    // each other across the sweeps, so a thread has up to 4 / 8 / 16 of them in flight instead of walking twelve dependent
+    // round trips sweep by sweep.
+    int p0[4], wq[4], base[4];
+    unsigned long long m[4], stt[4];
+    bool fg[4];
 #pragma unroll
     for (int it = 0; it < 4; ++it) {
-        const int p0 = blockIdx.x * 4096 + it * 1024 + threadIdx.x * 4;
-        const int w = p0 >> 6;
-        if (w >= nwords) continue;
-        const unsigned long long m = gb[w];
-        int4 out = make_int4(0, 0, 0, 0);
-        const int x0 = p0 & 63;
-        if ((m >> x0) & 15ull) {
-            const unsigned long long left = (w - cca_div(w, wpr, a.wpr_inv) * wpr) ? gb[w - 1] >> 63 : 0ull;
-            const unsigned long long st = m & ~((m << 1) | left);
-            const int base = gw[w];
-            int lab[4];
+        p0[it] = blockIdx.x * 4096 + it * 1024 + threadIdx.x * 4;
+        wq[it] = p0[it] >> 6;
+        m[it] = wq[it] < nwords ? gb[wq[it]] : 0ull;
+    }
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                lab[j] = 0;
-                const int x = x0 + j;
-                if ((m >> x) & 1ull) {
-                    const int v = rl[base + __popcll(st & ((2ull << x) - 1ull)) - 1];
-                    lab[j] = off + (v & 0x7fffffff);
-                    if (v < 0 && ((st >> x) & 1ull) && root_pix && lab[j] <= cap_roots) root_pix[lab[j] - 1] = (int)((size_t)b * HW + p0 + j);
-                }
-            }
-            out = make_int4(lab[0], lab[1], lab[2], lab[3]);
+    for (int it = 0; it < 4; ++it) {
+        const int w = wq[it], x0 = p0[it] & 63;
+        fg[it] = w < nwords && ((m[it] >> x0) & 15ull);
+        unsigned long long left = 0ull;
+        base[it] = 0;
+        if (fg[it]) {
+            left = (w - cca_div(w, wpr, a.wpr_inv) * wpr) ? gb[w - 1] >> 63 : 0ull;
+            base[it] = gw[w];
         }
-        *reinterpret_cast<int4*>(labels + (size_t)b * HW + p0) = out;
+        stt[it] = m[it] & ~((m[it] << 1) | left);
+    }
+    int v[4][4];
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        const int x0 = p0[it] & 63;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int x = x0 + j;
+            v[it][j] = 0;
+            if (fg[it] && ((m[it] >> x) & 1ull)) v[it][j] = rl[base[it] + __popcll(stt[it] & ((2ull << x) - 1ull)) - 1];
+        }
+    }
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        if (wq[it] >= nwords) continue;
+        const int x0 = p0[it] & 63;
+        int lab[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int x = x0 + j;
+            lab[j] = 0;
+            if (fg[it] && ((m[it] >> x) & 1ull)) {
+                lab[j] = off + (v[it][j] & 0x7fffffff);
+                if (v[it][j] < 0 && ((stt[it] >> x) & 1ull) && root_pix && lab[j] <= cap_roots) root_pix[lab[j] - 1] = (int)((size_t)b * HW + p0[it] + j);
+            }
+        }
+        *reinterpret_cast<int4*>(labels + (size_t)b * HW + p0[it]) = make_int4(lab[0], lab[1], lab[2], lab[3]);
     }
 }
 
