@@ -31,6 +31,8 @@ _SIGNATURES = {
     "fpc_ransac_voting_v3": (_i, [_vp, _vp, _i64, _i64, _i64, _i64, _i, _vp, _i, _i, _i, _vp, _vp, _u64, _f, _i, _i,
                                   _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "fpc_ransac_voting_v3_bits": (_i, [_vp, _vp, _vp, _i64, _i64, _i64, _i64, _i, _vp, _i, _i, _i, _vp, _vp, _u64, _f, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "fpc_vote_set_prune": (_i, [_i, _i, ctypes.POINTER(ctypes.c_int32)]),
+    "fpc_vote_prune_info": (_i, [_vp, _sz, _i, _i, _i, _i, _vp, _vp]),
     "fpc_class_compress": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     "fpc_class_compress_bits": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "fpc_cc_workspace_bytes": (_sz, [_i, _i, _i]),
@@ -109,7 +111,7 @@ def lib():
             fn = getattr(L, name)
             fn.restype = res
             fn.argtypes = args
-        if L.fpc_abi_version() != 9:
+        if L.fpc_abi_version() != 10:
             raise RuntimeError("fastposecnn_amd: libfpc_hip.so ABI version mismatch")
         _lib = L
     return _lib

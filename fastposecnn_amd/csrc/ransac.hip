@@ -47,6 +47,7 @@
 #include <stdlib.h>
 
 #include <algorithm>
+#include <atomic>
 
 #include "vote.hpp"
 
@@ -287,30 +288,6 @@ __global__ __launch_bounds__(256) void k_vote_scan(const ScanParams p) {
 }
 
 // ---- k_vote_plan -------------------------------------------------------------------
-// Exclusive scan of f(i), i in [0, cnt), into out[0..cnt] (out[cnt] = total) by the whole workgroup; out may be LDS or
-// global, and f(i) may read out[i] (every thread reads its element before any thread of the tile writes).
-template <typename F>
-__device__ __forceinline__ int block_scan(F f, int32_t* out, int cnt, int* s_w /* >= 17 ints */) {
-    const int lane = threadIdx.x & (kWave - 1), w = threadIdx.x / kWave, nw = blockDim.x / kWave;
-    int carry = 0;
-    for (int base = 0; base < cnt; base += blockDim.x) {
-        const int i = base + threadIdx.x;
-        const int v = i < cnt ? f(i) : 0;
-        int wt;
-        const int ex = wave_excl_scan(v, wt);
-        __syncthreads();
-        if (lane == 0) s_w[w] = wt;
-        __syncthreads();
-        int off = carry, tile = 0;
-        for (int k = 0; k < nw; ++k) { const int x = s_w[k]; if (k < w) off += x; tile += x; }
-        if (i < cnt) out[i] = off + ex;
-        carry += tile;
-    }
-    if (threadIdx.x == 0) out[cnt] = carry;
-    __syncthreads();                                   // LDS, or global through this CU's own L1 / L2: visible to the block
-    return carry;
-}
-
 // gridDim.y 256-thread workgroups per instance: each repeats the (cheap) prefix and bounding box and takes a share of the
 // hypotheses, part 0 writes the instance's record, units and runs.  dynamic LDS: [2][nch + 1] ints when p.lds_table.
 // INJ: the caller injected pair indices or a keep selection, or wants the out_tn diagnostic (tests and goldens): only that
@@ -405,6 +382,7 @@ __global__ __launch_bounds__(256) void k_vote_plan(const VoteParams p) {
             s_misc[5] = nruns ? atomicAdd(p.ctrl + 1, nruns) : 0;
         }
         if (!votes) {                                     // uniform: no unit, no run; k_vote_final writes the zeros
+            if (part == 0 && threadIdx.x < kPInfoI) p.pinfo[(size_t)inst * kPInfoI + threadIdx.x] = 0;
             for (int i = 2 * h_lo + threadIdx.x; i < 2 * min(hn, h_hi); i += blockDim.x) p.hyp[(size_t)inst * hn * 2 + i] = 0.0f;   // the out_hyp diagnostic
             __syncthreads();
             continue;
@@ -487,17 +465,169 @@ __global__ __launch_bounds__(256) void k_vote_plan(const VoteParams p) {
         FPC_STAMP(1, 5);
         if (part == 0) {
             const int ubase = s_misc[4], rbase = s_misc[5];
-            for (int u = threadIdx.x; u < nunits; u += blockDim.x) {
+            // the records of an instance in the permuted order the progressive count's passes cut (vote.hpp: unit_stride);
+            // the exhaustive count takes them in any order
+            const int ustride = unit_stride(nunits);
+            for (int j = threadIdx.x; j < nunits; j += blockDim.x) {
+                const int u = (int)(((long long)j * ustride) % nunits);
                 const int r0 = u * kUnitEntries, c = rank_chunk(cpre, nch, r0);
                 const int nvalid = min(kUnitEntries, fg - r0);
-                p.units[2 * (ubase + u)] = make_int4(inst | (thin ? 1 << 16 : 0) | ((nvalid - 1) << 17), u, c, (ox & 0xffff) | (oy << 16));
-                p.units[2 * (ubase + u) + 1] = make_int4(c * kChunkPx + (r0 - cpre[c]), cpre[c + 1] - r0, fg, 0);
+                p.units[2 * (ubase + j)] = make_int4(inst | (thin ? 1 << 16 : 0) | ((nvalid - 1) << 17), u, c, (ox & 0xffff) | (oy << 16));
+                p.units[2 * (ubase + j) + 1] = make_int4(c * kChunkPx + (r0 - cpre[c]), cpre[c + 1] - r0, fg, 0);
+            }
+            if (threadIdx.x == 0) {
+                int4* pi = reinterpret_cast<int4*>(p.pinfo + (size_t)inst * kPInfoI);
+                pi[0] = make_int4(ubase, nunits, hn, p.ntiles);
+                pi[1] = make_int4(-1, 0, 0, 0);
             }
             for (int rr = threadIdx.x; rr < nruns; rr += blockDim.x)
                 p.runs[rbase + rr] = make_int4(inst, rr, rank_chunk(cpre, nch, rr * p.run_entries), fg | (thin ? (int)0x80000000 : 0));
         }
         FPC_STAMP(1, 6);
         __syncthreads();               // s_tab / s_misc are reused by the next instance
+    }
+}
+
+// ---- k_vote_lead -------------------------------------------------------------------
+// The progressive count (fpc_vote_set_prune; only the WINNER is an output of the vote, RV/ransac_voting_gpu.py:566-574):
+// the count units of an instance are visited in passes; between two passes this kernel drops every hypothesis that can no
+// longer win, exactly:
+//   * leader = the alive hypothesis with the largest count so far (lowest index on ties); its inliers among the entries
+//     NOT yet counted are counted here with the reference's arithmetic  =>  L = its exact final count, a lower bound of the
+//     winner's count;
+//   * rem = the valid entries not yet counted: count(h) + rem is an upper bound of h's final count;
+//   * h stays alive iff count(h) + rem > L, or == L and h <= leader (an equal count wins only with the lower index:
+//     torch.max's first maximum).  A dropped hypothesis keeps its partial count, which is < L or (== L with a higher index
+//     than a hypothesis that reaches L): k_vote_final's arg-max over ALL count rows is unchanged.
+// The alive hypotheses are compacted in ascending order: slot -> hypothesis map and their B fragments (hypC), the last
+// tile padded with the never-voting fragment.  One 1024-thread workgroup per instance.
+// dynamic LDS: the instance's chunk prefix [nch + 1] when p.lds_table.
+constexpr int kLeadThreads = 1024;
+template <bool KEEP>
+__global__ __launch_bounds__(kLeadThreads) void k_vote_lead(const VoteParams p, const int pass) {
+    extern __shared__ __attribute__((aligned(16))) int s_cpre[];
+    __shared__ int s_w[kLeadThreads / kWave + 4];
+    __shared__ int s_red[3][kLeadThreads / kWave];
+    __shared__ unsigned s_unseen[kProgMaxUnits / 32];
+    const int n_act = active_instances(p.n, p.n_dev);
+    const int lane = threadIdx.x & (kWave - 1), wv = threadIdx.x / kWave;
+    constexpr int NW = kLeadThreads / kWave;
+    const int hn = p.hn, nch = p.nch;
+    FPC_STAMP(1, 8 + 8 * pass);
+    for (int inst = blockIdx.x; inst < n_act; inst += gridDim.x) {
+        int32_t* pi = p.pinfo + (size_t)inst * kPInfoI;
+        const int nunits = pi[1], alive_prev = pi[2];
+        const int lo = pass_begin(p.pcum, p.npass, pass, nunits);
+        if (nunits == 0 || lo >= nunits) continue;                       // uniform: nothing left to count for this instance
+        const int32_t* mapp = pass == 1 ? nullptr : p.hmap + ((size_t)((pass - 1) & 1) * p.n + inst) * p.hnp;
+        int32_t* mapn = p.hmap + ((size_t)(pass & 1) * p.n + inst) * p.hnp;
+        const int32_t* cnt = p.counts + (size_t)inst * p.hnp;
+        const int32_t* gpre = p.chunk_pre + (size_t)inst * (nch + 1);
+        const int fg = p.plan[(size_t)inst * kPlanI], thin = p.plan[(size_t)inst * kPlanI + 2];
+        __syncthreads();                                                  // LDS of the previous instance is free
+        if (p.lds_table)
+            for (int c = threadIdx.x; c <= nch; c += blockDim.x) s_cpre[c] = gpre[c];
+        // which units have not been counted yet: the positions [lo, nunits) of the permuted order, as a bit per unit
+        const int ustride = unit_stride(nunits);
+        for (int w = threadIdx.x; w < (nunits + 31) / 32; w += blockDim.x) s_unseen[w] = 0u;
+        __syncthreads();
+        for (int j = lo + threadIdx.x; j < nunits; j += blockDim.x) {
+            const int u = (int)(((long long)j * ustride) % nunits);
+            atomicOr(&s_unseen[u >> 5], 1u << (u & 31));
+        }
+        // 1. the leader of the alive set
+        int wc = -1, wi = 0x7fffffff;
+        for (int sl = threadIdx.x; sl < alive_prev; sl += blockDim.x) {
+            const int h = mapp ? mapp[sl] : sl;
+            const int cv = cnt[h];
+            if (cv > wc || (cv == wc && h < wi)) { wc = cv; wi = h; }
+        }
+#pragma unroll
+        for (int o = kWave / 2; o > 0; o >>= 1) {
+            const int oc = __shfl_xor(wc, o, kWave), oi = __shfl_xor(wi, o, kWave);
+            if (oc > wc || (oc == wc && oi < wi)) { wc = oc; wi = oi; }
+        }
+        if (lane == 0) { s_red[0][wv] = wc; s_red[1][wv] = wi; }
+        __syncthreads();
+        wc = s_red[0][0]; wi = s_red[1][0];
+        for (int i = 1; i < NW; ++i) {
+            const int oc = s_red[0][i], oi = s_red[1][i];
+            if (oc > wc || (oc == wc && oi < wi)) { wc = oc; wi = oi; }
+        }
+        FPC_STAMP(1, 8 + 8 * pass + 1);
+        const float gx = p.hyp[((size_t)inst * hn + wi) * 2], gy = p.hyp[((size_t)inst * hn + wi) * 2 + 1];
+        // 2. the leader's inliers and the valid entries among the ranks of the units not yet counted
+        const int32_t* cpre = p.lds_table ? s_cpre : gpre;
+        const float4* Lst = p.list + (size_t)inst * p.ls;
+        int lc = 0, rem = 0, c = 0;                                     // c: this lane's chunk cursor (its ranks only grow)
+        for (int r0 = threadIdx.x; r0 < fg; r0 += 4 * kLeadThreads) {
+            float4 q[4];
+            bool on[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int rk = r0 + j * kLeadThreads;
+                q[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+                on[j] = rk < fg && ((s_unseen[rk / (kUnitEntries * 32)] >> ((rk / kUnitEntries) & 31)) & 1u) != 0u;
+                if (on[j]) q[j] = Lst[rank_slot_from(cpre, c, rk)];
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                bool valid = on[j];
+                if (valid && thin) valid = pixel_kept<KEEP>(q[j].x, q[j].y, p.W, p.HW, inst, fg, p.max_num, p.seed, p.keep);
+                if (valid) {
+                    ++rem;
+                    if (pair_is_inlier(q[j].x, q[j].y, q[j].z, q[j].w, sqrtf(q[j].z * q[j].z + q[j].w * q[j].w), gx, gy, p.thresh)) ++lc;
+                }
+            }
+        }
+        lc = wave_reduce_add(lc); rem = wave_reduce_add(rem);
+        __syncthreads();                                                  // s_red of step 1 has been read
+        if (lane == 0) { s_red[0][wv] = lc; s_red[1][wv] = rem; }
+        __syncthreads();
+        lc = 0; rem = 0;
+        for (int i = 0; i < NW; ++i) { lc += s_red[0][i]; rem += s_red[1][i]; }
+        const int L = wc + lc;
+        FPC_STAMP(1, 8 + 8 * pass + 2);
+        // 3. prune and compact, in slot order (ascending hypothesis index)
+        int base = 0;
+        const u32x4* Bo = p.hypB + (size_t)inst * p.ntiles * kWave;
+        u32x4* Bc = p.hypC + (size_t)inst * p.ntiles * kWave;
+        for (int s0 = 0; s0 < alive_prev; s0 += blockDim.x) {
+            const int sl = s0 + threadIdx.x;
+            int h = -1;
+            bool keep = false;
+            if (sl < alive_prev) {
+                h = mapp ? mapp[sl] : sl;
+                const int ub = cnt[h] + rem;
+                keep = ub > L || (ub == L && h <= wi);
+            }
+            int wt;
+            const int ex = wave_excl_scan(keep ? 1 : 0, wt);
+            __syncthreads();
+            if (lane == 0) s_w[wv] = wt;
+            __syncthreads();
+            int off = base, tile = 0;
+            for (int k = 0; k < NW; ++k) { const int x = s_w[k]; if (k < wv) off += x; tile += x; }
+            if (keep) {
+                const int ns = off + ex;
+                mapn[ns] = h;
+                Bc[(ns / kHypTile) * kWave + ns % kHypTile] = Bo[(h / kHypTile) * kWave + h % kHypTile];
+                Bc[(ns / kHypTile) * kWave + ns % kHypTile + kHypTile] = Bo[(h / kHypTile) * kWave + h % kHypTile + kHypTile];
+            }
+            base += tile;
+        }
+        const int tiles = (base + kHypTile - 1) / kHypTile;
+        {   // the padding of the last tile: margin -4 for every entry (never counted, never undecided)
+            u32x4 plo, phi;
+            b_fragment(0.0f, 0.0f, 0.0f, 4.0f, plo, phi);
+            for (int ns = base + threadIdx.x; ns < tiles * kHypTile; ns += blockDim.x) {
+                mapn[ns] = -1;
+                Bc[(ns / kHypTile) * kWave + ns % kHypTile] = plo;
+                Bc[(ns / kHypTile) * kWave + ns % kHypTile + kHypTile] = phi;
+            }
+        }
+        if (threadIdx.x == 0) { pi[2] = base; pi[3] = tiles; pi[4] = wi; pi[5] = L; pi[6] = rem; }
+        FPC_STAMP(1, 8 + 8 * pass + 3);
     }
 }
 
@@ -717,6 +847,37 @@ extern "C" int fpc_voting_for_hypothesis(const float* direct, const float* coord
     return check_launch();
 }
 
+// the progressive count's switch and schedule (process-wide; read at every call)
+static std::atomic<int> g_prune_mode{0};                   // 0: never (default), 1: whenever the count rows are not an output
+static std::atomic<int> g_prune_passes{3};
+static std::atomic<int> g_prune_cum[kMaxPasses + 1] = {{0}, {5}, {10}, {16}, {16}};
+
+extern "C" int fpc_vote_set_prune(int mode, int npass, const int32_t* cum16) {
+    if (mode < 0 || mode > 1) return FPC_EINVAL;
+    if (npass != 0) {
+        if (npass < 2 || npass > kMaxPasses || !cum16) return FPC_EINVAL;
+        int prev = 0;
+        for (int i = 1; i < npass; ++i) {
+            if (cum16[i - 1] <= prev || cum16[i - 1] >= 16) return FPC_EINVAL;
+            prev = cum16[i - 1];
+        }
+        for (int i = 1; i < npass; ++i) g_prune_cum[i].store(cum16[i - 1], std::memory_order_relaxed);
+        g_prune_passes.store(npass, std::memory_order_relaxed);
+    }
+    g_prune_mode.store(mode, std::memory_order_relaxed);
+    return FPC_OK;
+}
+
+extern "C" int fpc_vote_prune_info(const void* ws, size_t ws_bytes, int n, int H, int W, int hn, int32_t* out, fpc_stream_t stream) {
+    if (n < 1 || H < 1 || W < 1 || hn < 1 || !ws || !out) return FPC_EINVAL;
+    Ws w = carve(const_cast<void*>(ws), n, H, W, hn);
+    if (ws_bytes < w.total) return FPC_EWORKSPACE;
+    clear_hip_error();
+    hipError_t e = hipMemcpyAsync(out, w.p.pinfo, sizeof(int32_t) * (size_t)n * kPInfoI, hipMemcpyDeviceToDevice, (hipStream_t)stream);
+    if (e != hipSuccess) { set_hip_error(e); return FPC_ELAUNCH; }
+    return FPC_OK;
+}
+
 extern "C" size_t fpc_ransac_workspace_bytes(int n, int H, int W, int hn) {
     if (n <= 0 || H < 1 || W < 1 || hn < 1) return 256;
     return carve(nullptr, n, H, W, hn).total;
@@ -779,6 +940,19 @@ extern "C" int fpc_ransac_voting_v3_bits(const float* mask, const uint64_t* mask
     // rounding allowance of the margin per unit of magnitude M = |gx - ox| + |gy - oy| + radius (k_vote_count's header)
     p.efac = 3.2e-6f * (1.0f + kappa1);
     p.lds_table = p.nch + 1 <= 2048 ? 1 : 0;              // the chunk tables of an instance in LDS (<= 8 KB each)
+    // Only the winner is an output unless the caller asks for the count rows: the progressive count (k_vote_lead) then
+    // skips the pairs of hypotheses that cannot win.  OFF unless asked for: on the 32-frame / hn = 1000 batch it evaluates
+    // 0.55 of the pairs and still takes 326 us against 283 (profiles/r05_vote_prune.md).
+    const int prune_mode = g_prune_mode.load(std::memory_order_relaxed);
+    const bool prune_fits = !out_counts && n <= kProgMaxInst && p.nux <= kProgMaxUnits;
+    const bool prune = prune_fits && prune_mode > 0;
+    p.npass = 1;
+    for (int i = 0; i <= kMaxPasses; ++i) p.pcum[i] = 16;
+    p.pcum[0] = 0;
+    if (prune) {
+        p.npass = g_prune_passes.load(std::memory_order_relaxed);
+        for (int i = 1; i < p.npass; ++i) p.pcum[i] = g_prune_cum[i].load(std::memory_order_relaxed);
+    }
     const size_t table_lds = p.lds_table ? (size_t)(p.nch + 1) * sizeof(int) : 0;
 
 #ifdef FPC_VOTE_TRACE     // diagnostic build only (python -c "build(extra=['-DFPC_VOTE_TRACE'])"): name the launch that faults
@@ -817,8 +991,21 @@ extern "C" int fpc_ransac_voting_v3_bits(const float* mask, const uint64_t* mask
     const int count_grid = (int)std::min<long long>(cap_tasks, resident);
     p.task_target = count_grid;
     const size_t count_lds = (size_t)std::min(p.ntiles, kMaxSliceTiles) * kHypTile * sizeof(int);
-    launch_vote_count(p, count_grid, count_lds, s);
-    FPC_TRACE("count");
+    if (p.npass > 1) {
+        // the progressive count: passes over disjoint unit sets, k_vote_lead drops the hypotheses that cannot win in between
+        for (int pass = 0; pass < p.npass; ++pass) {
+            if (pass > 0) {
+                if (keep) hipLaunchKernelGGL(k_vote_lead<true>, dim3(std::min(n, 2048)), dim3(kLeadThreads), table_lds, s, p, pass);
+                else hipLaunchKernelGGL(k_vote_lead<false>, dim3(std::min(n, 2048)), dim3(kLeadThreads), table_lds, s, p, pass);
+                FPC_TRACE("lead");
+            }
+            launch_vote_count_prog(p, pass, count_grid, s);
+            FPC_TRACE("count pass");
+        }
+    } else {
+        launch_vote_count(p, count_grid, count_lds, s);
+        FPC_TRACE("count");
+    }
 
     // 4. winner, its inliers, refinement: one task per run of chunks
     const int fin_grid = (int)std::min<long long>(std::max<long long>((long long)n * p.nrx, 1), 512);

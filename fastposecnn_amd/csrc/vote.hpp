@@ -15,6 +15,11 @@ constexpr int kMaxHn = 65536;
 constexpr int kRec = 6;              // doubles per refinement record: inliers, a00, a01, a11, b0, b1
 constexpr int kBandQ = 128;          // queued undecided-pair records per wave and task (one step adds at most 64)
 constexpr float kNeverS = 1.0e30f;   // |s| of an entry that never votes
+constexpr int kPInfoI = 8;           // i32 per instance of the progressive count: unit base, units, alive hypotheses, their tiles,
+                                     // leader, its full count L, valid entries not yet counted, -
+constexpr int kMaxPasses = 4;        // passes of the progressive count at most
+constexpr int kProgMaxInst = 1024;   // instances whose per-pass tables fit k_vote_count_prog's LDS
+constexpr int kProgMaxUnits = 16384; // count units per instance whose "not yet counted" bits fit k_vote_lead's LDS (8.4 M pixels)
 
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -31,6 +36,8 @@ struct VoteParams {
     // derived
     int nch, ntiles, hnp, nux, nrx, lds_table, want_tn, all_wild, task_target;
     int run_entries;                  // foreground ranks per refinement run (k_vote_final task)
+    int npass;                        // progressive count: passes (0 / 1 = the exhaustive k_vote_count)
+    int pcum[kMaxPasses + 1];         // ... pass p takes the unit positions [pass_begin(p), pass_begin(p + 1)) of an instance, in 16ths
     size_t ls;                        // list slots per instance = nch * kChunkPx
     float kappa2, dkappa, efac;
     // workspace
@@ -52,6 +59,12 @@ struct VoteParams {
     int4* units;          // [n * nux, 2]   {instance | thin << 16 | (entries - 1) << 17, block u, chunk c of rank 512 u, ox | oy << 16},
                           //                {list slot of rank 512 u, ranks of the unit inside chunk c, fg, -}
     int4* runs;           // [n * nrx]      {instance, run r (= its record ordinal), chunk of rank r * run_entries, fg | thin << 31}
+    int32_t* pinfo;       // [n, kPInfoI]   progressive count: see kPInfoI (written by k_vote_plan, updated by k_vote_lead)
+    int32_t* hmap;        // [2, n, hnp]    slot -> hypothesis of the alive set (ping-pong between passes; pass 0: identity, not stored)
+    u32x4* hypC;          // [n, ntiles, 64] B fragments of the alive hypotheses, compacted in slot order (k_vote_lead)
+#ifdef FPC_STAMP_VOTE
+    unsigned long long* dbg;      // [kMaxPasses, 1024, 4] per workgroup of k_vote_count_prog: start, end, segments, XCC id (diagnostic build)
+#endif
     unsigned long long* stamps;   // [4, 32]  s_memrealtime (100 MHz) at the phases of workgroup 0 of each kernel: written only by a
                                   //          diagnostic build (-DFPC_STAMP_VOTE, tools_dev/vote_stamps.py); never read by a kernel
 };
@@ -104,6 +117,12 @@ inline Ws carve(void* base, int n, int H, int W, int hn) {
     p.list = (float4*)take(sizeof(float4) * (size_t)n * p.ls);
     p.units = (int4*)take(sizeof(int4) * 2 * (size_t)n * p.nux);
     p.runs = (int4*)take(sizeof(int4) * (size_t)n * p.nrx);
+    p.pinfo = (int32_t*)take(sizeof(int32_t) * (size_t)n * kPInfoI);
+    p.hmap = (int32_t*)take(sizeof(int32_t) * 2 * (size_t)n * p.hnp);
+    p.hypC = (u32x4*)take(sizeof(u32x4) * (size_t)n * p.ntiles * kWave);
+#ifdef FPC_STAMP_VOTE
+    p.dbg = (unsigned long long*)take(sizeof(unsigned long long) * kMaxPasses * 1024 * 4);
+#endif
     p.stamps = (unsigned long long*)take(sizeof(unsigned long long) * 4 * 32);
     w.total = off;
     return w;
@@ -176,6 +195,51 @@ __device__ __forceinline__ int rank_slot_from(const int32_t* __restrict__ cpre, 
     return c * kChunkPx + (r - cpre[c]);
 }
 
+// ---- progressive count: which units a pass takes ---------------------------------------------------------------------
+// An instance's unit records are stored in a PERMUTED order (position j holds unit (j * stride) mod nunits, stride ~ 0.618
+// nunits and coprime to it: every block of consecutive positions spreads over the whole instance); pass p counts the
+// positions [pass_begin(p), pass_begin(p + 1)).
+__host__ __device__ __forceinline__ int unit_stride(int nunits) {
+    if (nunits < 3) return 1;
+    int s = (int)((long long)nunits * 618 / 1000);
+    if (s < 1) s = 1;
+    for (;; ++s) {                                   // nunits - 1 is coprime to nunits: terminates below nunits
+        int a = s, b = nunits;
+        while (b) { const int t = a % b; a = b; b = t; }
+        if (a == 1) return s;
+    }
+}
+__host__ __device__ __forceinline__ int pass_begin(const int* pcum, int npass, int pass, int nunits) {
+    if (pass <= 0) return 0;
+    if (pass >= npass) return nunits;
+    const long long b = ((long long)nunits * pcum[pass] + 15) / 16;
+    return b < nunits ? (int)b : nunits;
+}
+
+// Exclusive scan of f(i), i in [0, cnt), into out[0..cnt] (out[cnt] = total) by the whole workgroup; out may be LDS or
+// global, and f(i) may read out[i] (every thread reads its element before any thread of the tile writes).
+template <typename F>
+__device__ __forceinline__ int block_scan(F f, int32_t* out, int cnt, int* s_w /* >= blockDim.x / 64 + 1 ints */) {
+    const int lane = threadIdx.x & (kWave - 1), w = threadIdx.x / kWave, nw = blockDim.x / kWave;
+    int carry = 0;
+    for (int base = 0; base < cnt; base += blockDim.x) {
+        const int i = base + threadIdx.x;
+        const int v = i < cnt ? f(i) : 0;
+        int wt;
+        const int ex = wave_excl_scan(v, wt);
+        __syncthreads();
+        if (lane == 0) s_w[w] = wt;
+        __syncthreads();
+        int off = carry, tile = 0;
+        for (int k = 0; k < nw; ++k) { const int x = s_w[k]; if (k < w) off += x; tile += x; }
+        if (i < cnt) out[i] = off + ex;
+        carry += tile;
+    }
+    if (threadIdx.x == 0) out[cnt] = carry;
+    __syncthreads();                                   // LDS, or global through this CU's own L1 / L2: visible to the block
+    return carry;
+}
+
 // Is pixel (x, y) of a THINNED instance kept (RV/ransac_voting_gpu.py:541-545)?  KEEP: the caller injected the selection.
 // A template parameter, not a test of the pointer: hipcc 7.2 (clang 22) kept the wave-uniform `keep != nullptr` of the plan
 // kernel in a VGPR under SGPR pressure, re-expanded it to a lane mask with v_cmp under the partial EXEC of one divergent
@@ -228,5 +292,6 @@ __device__ __forceinline__ void b_fragment(float X, float Y, float S, float ES, 
 
 
 void launch_vote_count(const VoteParams& p, int grid, size_t lds_bytes, hipStream_t s);   // picks the KEEP variant from p.keep
+void launch_vote_count_prog(const VoteParams& p, int pass, int grid, hipStream_t s);         // one pass of the progressive count
 
 }  // namespace fpc

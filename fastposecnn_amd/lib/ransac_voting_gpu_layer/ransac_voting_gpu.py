@@ -13,7 +13,8 @@ Keyword-only extensions (not in the reference): `idxs` (i32 [b,hn,vn,2]) injects
 pairs, `keep` (u8/bool [b,h,w]) injects the > max_num thinning selection, `seed` fixes the
 built-in counter-based sampler (include/fpc_rng.h; default: drawn from torch's CPU generator,
 so torch.manual_seed() makes runs repeatable), `return_debug` also returns per-instance
-diagnostics (tn, win_idx, win_count, inlier_count, hyp, counts), `n_dev` (device i32[1]) limits the work
+diagnostics (tn, win_idx, win_count, inlier_count, hyp, counts; `return_debug="winner"` leaves out the count rows, which
+lets the progressive count run: `set_vote_prune`), `n_dev` (device i32[1]) limits the work
 to the first n_dev instances of a capacity-sized batch without a host read (rows past it are left
 uninitialised), `mask_bits` (i64 [b, fpc_mask_bits_words(h,w)]: the foreground as bit words, as the aggregation layer
 writes them) lets the kernels skip the f32 mask planes — same result, a third of the scan's bytes.
@@ -21,6 +22,27 @@ writes them) lets the kernels skip the f32 mask planes — same result, a third 
 import torch
 
 from fastposecnn_amd import _native as nat
+
+
+def set_vote_prune(mode=0, cum16=None):
+    """The progressive count of the vote (include/fpc.h: fpc_vote_set_prune).  mode 0: never (default), 1: whenever the
+    count rows are not asked for.  cum16: e.g. (5, 10) = three passes over 5/16, 5/16, 6/16 of the units."""
+    import ctypes
+    if cum16 is None:
+        nat.check(nat.lib().fpc_vote_set_prune(int(mode), 0, None), "fpc_vote_set_prune")
+    else:
+        arr = (ctypes.c_int32 * len(cum16))(*[int(c) for c in cum16])
+        nat.check(nat.lib().fpc_vote_set_prune(int(mode), len(cum16) + 1, arr), "fpc_vote_set_prune")
+
+
+def vote_prune_info(b, h, w, hn, dev):
+    """i32 [b,8] of the LAST vote call with these sizes on the current stream (include/fpc.h: fpc_vote_prune_info)."""
+    L = nat.lib()
+    out = torch.empty((b, 8), dtype=torch.int32, device=dev)
+    with torch.cuda.device(dev):
+        ws = nat.workspace("ransac", dev, L.fpc_ransac_workspace_bytes(b, h, w, hn))
+        nat.check(L.fpc_vote_prune_info(nat.ptr(ws), ws.numel(), b, h, w, hn, nat.ptr(out), nat.stream()), "fpc_vote_prune_info")
+    return out
 
 
 def b_inv(b_mat):
@@ -85,14 +107,15 @@ def ransac_voting_layer_v3(mask, vertex, round_hyp_num, inlier_thresh=0.999, con
                          win_idx=torch.empty(b, dtype=torch.int32, device=dev),
                          win_count=torch.empty(b, dtype=torch.int32, device=dev),
                          inlier_count=torch.empty(b, dtype=torch.int32, device=dev),
-                         hyp=torch.empty((b, hn, 2), dtype=torch.float32, device=dev),
-                         counts=torch.empty((b, hn), dtype=torch.int32, device=dev))
+                         hyp=torch.empty((b, hn, 2), dtype=torch.float32, device=dev))
+                if return_debug != "winner":     # the count rows of EVERY hypothesis: the exhaustive count runs (include/fpc.h)
+                    d["counts"] = torch.empty((b, hn), dtype=torch.int32, device=dev)
             nat.check(L.fpc_ransac_voting_v3_bits(
                 nat.ptr(mask), nat.ptr(mask_bits), v.data_ptr(), sn, sh, sw, sc, b, nat.ptr(n_dev), h, w, hn, nat.ptr(ii), nat.ptr(keep),
                 (seed + vi) & (2 ** 64 - 1), float(inlier_thresh), int(min_num), int(max_num), nat.ptr(xy),
                 nat.ptr(d["tn"]) if d else None, nat.ptr(d["win_idx"]) if d else None,
                 nat.ptr(d["win_count"]) if d else None, nat.ptr(d["inlier_count"]) if d else None,
-                nat.ptr(d["hyp"]) if d else None, nat.ptr(d["counts"]) if d else None, nat.ptr(refine),
+                nat.ptr(d["hyp"]) if d else None, nat.ptr(d.get("counts")) if d else None, nat.ptr(refine),
                 nat.ptr(ws), ws.numel(), nat.stream()), "fpc_ransac_voting_v3_bits")
             if vn != 1:
                 out[:, vi, :] = xy

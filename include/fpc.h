@@ -43,7 +43,7 @@
 extern "C" {
 #endif
 
-#define FPC_ABI_VERSION 9
+#define FPC_ABI_VERSION 10
 
 #define FPC_OK 0
 #define FPC_EINVAL (-1)      /* bad argument (shape, null pointer, ...) */
@@ -89,9 +89,9 @@ int fpc_voting_for_hypothesis(const float* direct, const float* coords, const fl
  * hn      1 .. 65536.
  * ws      device workspace of at least fpc_ransac_workspace_bytes(n,H,W,hn) bytes, 256-byte aligned.  Contents
  *         are scratch: nothing has to survive between calls and nothing has to be cleared before one (four stateless
- *         launches on `stream`, no memset, no second stream: mask scan + compacted pixel list -> per-instance plan
- *         (hypotheses, work records) -> exact counts on the matrix cores -> winner + refinement; csrc/ransac.hip,
- *         csrc/vote_count.hip).
+ *         launches on `stream` — eight with the progressive count below —, no memset, no second stream: mask scan +
+ *         compacted pixel list -> per-instance plan (hypotheses, work records) -> exact counts on the matrix cores ->
+ *         winner + refinement; csrc/ransac.hip, csrc/vote_count.hip).
  * Results are those of the reference's exhaustive vote bit for bit (counts, winner, inlier set); the refinement solves
  * the 2x2 normal equations in fp64 like b_inv (RV/ransac_voting_gpu.py:503-516: inverse, pseudo-inverse when singular),
  * and also takes the pseudo-inverse when det <= 1e-12 trace^2 (conditioning beyond fp64's reach for f32 votes; torch
@@ -119,6 +119,24 @@ int fpc_ransac_voting_v3_bits(const float* mask, const uint64_t* mask_bits, cons
                               int32_t* out_win_count, int32_t* out_inl_count,
                               float* out_hyp, int32_t* out_counts, double* out_refine,
                               void* ws, size_t ws_bytes, fpc_stream_t stream);
+
+/* The progressive count (OFF by default).  Unless the caller asks for out_counts, only the WINNER of the vote is an output
+ * (RV/ransac_voting_gpu.py:566-574: arg-max of the inlier counts, first maximum).  With fpc_vote_set_prune(1, ...) the count
+ * runs in passes over disjoint sets of each instance's pixels; between two passes every hypothesis h with
+ *     count_so_far(h) + valid pixels not yet counted  <  L      (or == L with an index above the leader's)
+ * is dropped, L being the EXACT final count of the current leader (csrc/ransac.hip: k_vote_lead).  The winner, its count,
+ * its inlier set and the refined centre are those of the exhaustive vote, bit for bit; out_win_idx / out_win_count /
+ * out_inl_count stay available.  With out_counts the exhaustive count runs.  Measured on the 32-frame batch at hn = 1000:
+ * 0.55 of the pairs, but 326 us against the exhaustive 283 us (three count launches and two k_vote_lead launches cost more
+ * than the pairs they save: profiles/r05_vote_prune.md) - hence off unless asked for.
+ * fpc_vote_set_prune: mode 0 = never (default), 1 = whenever out_counts is NULL and the sizes fit (n <= 1024 instances,
+ * <= 8.4 M pixels).  npass = 0 keeps the schedule; else 2..4 passes, cum16[npass - 1] = increasing 16ths of an
+ * instance's count units finished after each pass but the last (default 3 passes: 5, 10).  Process-wide.
+ * fpc_vote_prune_info: copy of the last call's per-instance record out of its workspace -> out i32 [n,8] (device):
+ * {-, count units, alive hypotheses entering the last pass, their 32-wide tiles, last leader, its final count L,
+ * valid pixels that were still uncounted at the last decision, -}. */
+int fpc_vote_set_prune(int mode, int npass, const int32_t* cum16);
+int fpc_vote_prune_info(const void* ws, size_t ws_bytes, int n, int H, int W, int hn, int32_t* out, fpc_stream_t stream);
 
 /* ---- class compression ------------------------------------------------------
  * mask_logits f32 [B,C,HW]; quat [B,4(C-1),HW]; scales [B,3(C-1),HW]; xy [B,2(C-1),HW];

@@ -555,6 +555,136 @@ def test_v3_exact_mode_for_nonpositive_threshold(lib, oracle, dev):
         _assert_v3_equal(out, dbg, want, wdbg)
 
 
+# ----------------------------------------------------------------------------- progressive count (exact pruning)
+
+@pytest.fixture
+def prune_forced(lib):
+    """The progressive count whenever the count rows are not an output (by default only large batches take it)."""
+    import ransac_voting_gpu_layer.ransac_voting_gpu as rvg
+    rvg.set_vote_prune(1, (5, 10))
+    yield rvg
+    rvg.set_vote_prune(0, (5, 10))
+
+
+def _winner_equal(a, da, b, db, what):
+    for k in ("tn", "win_idx", "win_count", "inlier_count"):
+        assert torch.equal(da[0][k], db[0][k]), (what, k)
+    assert torch.equal(da[0]["hyp"], db[0]["hyp"]) or np.array_equal(da[0]["hyp"].cpu().numpy(), db[0]["hyp"].cpu().numpy(), equal_nan=True)
+    assert np.array_equal(a.cpu().numpy(), b.cpu().numpy(), equal_nan=True), what      # same inlier set, same fp64 sums: bit-identical
+
+
+@pytest.mark.parametrize("sched", [(5, 10), (8,), (3, 6, 11), (1, 15)])
+def test_progressive_count_bench_frames_equal_exhaustive_and_oracle(lib, oracle, dev, prune_forced, sched):
+    """Four frames of the vote-bench fixture (24 instances, hn = 1000): the winner, its count, the inlier set and the
+    refined centre of the progressive count equal the exhaustive count's bit for bit, for several pass schedules, and the
+    oracle's; the per-instance record shows that hypotheses were in fact dropped."""
+    import aggregation_layer as al
+    from fastposecnn_amd import synth
+    rvg = prune_forced
+    rvg.set_vote_prune(1, sched)
+    cat_cpu, _ = synth.make_vote_batch(range(4))
+    agg = al.AggregationLayer(None, 7).forward({k: v.to(dev) for k, v in cat_cpu.items()})
+    vertex = agg["xy"].permute(0, 2, 3, 1).unsqueeze(3)
+    masks = agg["instance_masks"]
+    n, hn = masks.shape[0], 1000
+    a, da = rvg.ransac_voting_layer_v3(masks, vertex, hn, seed=77, return_debug="winner")
+    info = rvg.vote_prune_info(n, 480, 640, hn, dev).cpu().numpy()
+    b, db = rvg.ransac_voting_layer_v3(masks, vertex, hn, seed=77, return_debug=True)            # count rows: exhaustive
+    torch.cuda.synchronize()
+    _winner_equal(a, da, b, db, sched)
+    counts = db[0]["counts"].cpu().numpy()
+    assert np.array_equal(da[0]["win_count"].cpu().numpy(), counts.max(1))
+    assert np.array_equal(da[0]["win_idx"].cpu().numpy(), counts.argmax(1))                       # first maximum
+    # the record: alive set shrank, the leader's exact count is a count row entry and <= the winner's
+    assert (info[:, 2] <= hn).all() and (info[:, 2] >= 1).all() and (sched == (1, 15) or (info[:, 2] < hn).all())
+    lead, L = info[:, 4], info[:, 5]
+    assert np.array_equal(counts[np.arange(n), lead], L) and (L <= counts.max(1)).all()
+    if sched == (5, 10):
+        want = oracle.aggregate({k: v.numpy() for k, v in cat_cpu.items()})
+        oracle.set_threads(0)
+        try:
+            wxy, wdbg = oracle.ransac_voting_layer_v3(want["instance_masks"], want["xy"].transpose(0, 2, 3, 1)[:, :, :, None, :],
+                                                      hn, seed=77, return_debug=True)
+        finally:
+            oracle.set_threads(1)
+        for k in ("tn", "win_idx", "win_count", "inlier_count"):
+            assert np.array_equal(da[0][k].cpu().numpy(), wdbg[0][k]), k
+        assert_rel(a.cpu().numpy(), wxy, what="centres")
+
+
+@pytest.mark.parametrize("case", ["ties", "near_ties", "noise", "thinned", "tiny_and_empty"])
+def test_progressive_count_adversarial(lib, oracle, dev, prune_forced, case):
+    """Inputs built against the pruning rule: exact ties between many hypotheses (the LOWEST index must win, also when
+    it is not the leader of an early pass), winners that lead only in the last pass, pure-noise votes with low counts,
+    an instance above max_num (the bound counts kept pixels only), instances of fewer pixels than a count unit and
+    empty ones.  Oracle and exhaustive count agree with the progressive count on every integer output."""
+    rvg = prune_forced
+    rng = np.random.default_rng({"ties": 1, "near_ties": 2, "noise": 3, "thinned": 4, "tiny_and_empty": 5}[case])
+    H, W, hn = 96, 128, 320
+    yy, xx = np.mgrid[0:H, 0:W].astype(np.float32)
+    specs = [(40.3, 30.6, 26), (90.0, 60.0, 30), (64.5, 48.5, 44)]
+    if case == "tiny_and_empty":
+        specs = [(20.0, 20.0, 3), (60.0, 50.0, 0), (100.2, 70.7, 20), (30.0, 80.0, 1)]
+    n = len(specs)
+    mask = np.zeros((n, H, W), np.float32); xy = np.zeros((n, 2, H, W), np.float32)
+    idxs = None
+    kw = {}
+    for i, (cx, cy, r) in enumerate(specs):
+        m = ((xx - cx) ** 2 + (yy - cy) ** 2) <= r * r if r > 0 else np.zeros((H, W), bool)
+        d = np.stack([cx - xx, cy - yy]); v = d / np.maximum(np.sqrt((d ** 2).sum(0)), 1e-9)
+        ang = rng.normal(0, 0.03, (H, W))
+        v = np.stack([np.cos(ang) * v[0] - np.sin(ang) * v[1], np.sin(ang) * v[0] + np.cos(ang) * v[1]])
+        if case == "noise":
+            a = rng.uniform(0, 2 * np.pi, (H, W)); v = np.stack([np.cos(a), np.sin(a)])
+        if case == "near_ties":
+            # the lower half of the blob votes for a second centre 1.5 px away: two families of hypotheses whose counts
+            # cross between the passes (units are visited in a scattered order)
+            d2 = np.stack([cx + 1.5 - xx, cy - yy]); v2 = d2 / np.maximum(np.sqrt((d2 ** 2).sum(0)), 1e-9)
+            v = np.where((yy > cy)[None], v2, v)
+        mask[i] = m; xy[i] = (v * m).astype(np.float32)
+    if case in ("ties", "near_ties"):
+        # injected pairs: blocks of identical pairs -> identical hypotheses -> exactly equal counts at different indices
+        tn = (mask != 0).sum((1, 2))
+        idxs = np.zeros((n, hn, 1, 2), np.int32)
+        for i in range(n):
+            base = rng.integers(0, tn[i], (hn // 8, 2))
+            idxs[i, :, 0, :] = np.repeat(base, 8, axis=0)[rng.permutation(hn)]
+        kw["idxs"] = idxs
+    if case == "thinned":
+        kw["max_num"] = 1500
+    vertex = T(xy, dev).permute(0, 2, 3, 1).unsqueeze(3)
+    ikw = dict(kw)
+    if idxs is not None:
+        ikw["idxs"] = T(idxs, dev)
+    a, da = rvg.ransac_voting_layer_v3(T(mask, dev), vertex, hn, seed=9, return_debug="winner", **ikw)
+    b, db = rvg.ransac_voting_layer_v3(T(mask, dev), vertex, hn, seed=9, return_debug=True, **ikw)
+    torch.cuda.synchronize()
+    _winner_equal(a, da, b, db, case)
+    want, wdbg = oracle.ransac_voting_layer_v3(mask, xy.transpose(0, 2, 3, 1)[:, :, :, None, :], hn, seed=9, return_debug=True, **kw)
+    for k in ("tn", "win_idx", "win_count", "inlier_count"):
+        assert np.array_equal(da[0][k].cpu().numpy(), wdbg[0][k]), k
+    np.testing.assert_allclose(a.cpu().numpy(), want, atol=1e-4, rtol=1e-6)
+    if case == "ties":
+        counts = wdbg[0]["counts"]
+        assert all((counts[i] == counts[i].max()).sum() >= 8 for i in range(n))      # the fixture does produce ties at the top
+
+
+def test_progressive_count_is_off_unless_asked_for(lib, dev, prune_forced):
+    """fpc_vote_set_prune(0) (the default): the record of a call shows the full alive set; mode 1: a shrunken one."""
+    import aggregation_layer as al
+    from fastposecnn_amd import synth
+    rvg = prune_forced
+    cat_cpu, _ = synth.make_vote_batch(range(2))
+    agg = al.AggregationLayer(None, 7).forward({k: v.to(dev) for k, v in cat_cpu.items()})
+    vertex = agg["xy"].permute(0, 2, 3, 1).unsqueeze(3)
+    n, hn = agg["instance_masks"].shape[0], 1000
+    for mode, pruned in ((0, False), (1, True)):
+        rvg.set_vote_prune(mode)
+        rvg.ransac_voting_layer_v3(agg["instance_masks"], vertex, hn, seed=1)
+        info = rvg.vote_prune_info(n, 480, 640, hn, dev).cpu().numpy()
+        assert ((info[:, 2] < hn).all()) == pruned and (info[:, 2] == hn).all() == (not pruned)
+
+
 # ----------------------------------------------------------------------------- deferred post-network path
 
 def test_deferred_post_network_equals_staged(lib, oracle, dev):

@@ -14,7 +14,9 @@ ap.add_argument("--frames", type=int, default=1)
 ap.add_argument("--agg", action="store_true")
 ap.add_argument("--bits", action="store_true", help="pass the aggregation layer's mask bit words (the scan skips the f32 planes)")
 ap.add_argument("--sets", type=int, default=1, help="distinct copies of the inputs, used in rotation (cold reads, as in bench.py)")
-ap.add_argument("--fuse-min", type=int, default=0, help="fpc_vote_set_fuse_min_instances (0: library default)")
+ap.add_argument("--prune", type=int, default=0, help="fpc_vote_set_prune mode: 0 never, 1 always")
+ap.add_argument("--cum", type=str, default="", help="pass schedule in 16ths, e.g. 5,10")
+ap.add_argument("--info", action="store_true", help="print the survivor histogram of the last call")
 a = ap.parse_args()
 dev = torch.device("cuda:0")
 cat_cpu, _ = synth.make_vote_batch(range(a.frames))
@@ -26,7 +28,8 @@ n, H, W = mask.shape
 vertex = xy.permute(0, 2, 3, 1)
 sn, sh, sw, sc = vertex.stride()
 lib = nat.lib()
-if a.fuse_min: lib.fpc_vote_set_fuse_min_instances(a.fuse_min)
+import ransac_voting_gpu_layer.ransac_voting_gpu as rvg
+rvg.set_vote_prune(a.prune, tuple(int(c) for c in a.cum.split(",")) if a.cum else None)
 ws = torch.empty(lib.fpc_ransac_workspace_bytes(n, H, W, a.hn), dtype=torch.uint8, device=dev)
 out = torch.empty((n, 2), device=dev)
 st = torch.cuda.current_stream().cuda_stream
@@ -54,3 +57,10 @@ e1.record(); torch.cuda.synchronize()
 dt = time.perf_counter() - t0
 ms = e0.elapsed_time(e1) / a.iters
 print(f"n={n} hn={a.hn} sets={a.sets} bits={int(a.bits)} per-call {ms*1e3:.1f} us (wall {dt/a.iters*1e6:.1f} us)  alg {n*12*H*W/ms/1e6:.1f} GB/s  out0={out[0].tolist()}")
+if a.info:
+    import numpy as np
+    info = torch.empty((n, 8), dtype=torch.int32, device=dev)
+    nat.check(lib.fpc_vote_prune_info(ws.data_ptr(), ws.numel(), n, H, W, a.hn, info.data_ptr(), st), "info")
+    torch.cuda.synchronize()
+    inf = info.cpu().numpy()
+    print("alive entering the last pass: mean %.0f min %d max %d of %d; units mean %.1f" % (inf[:, 2].mean(), inf[:, 2].min(), inf[:, 2].max(), a.hn, inf[:, 1].mean()))
