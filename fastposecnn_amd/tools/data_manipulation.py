@@ -1,54 +1,41 @@
-"""The pieces of F/tools/data_manipulation.py the ground-truth half of a dataset item needs (tools/dataset.py):
-extract_xyz_R_T_from_RTs (:962-997) and what it calls — the pin-hole projection of the object's origin (:878-935), z from the
-inverse transform (:999-1003), the translation vector through the inverse intrinsics (:1017-1050).  Host-side numpy in
-float64 like the reference; the f32 cast of the projected origin inside create_translation_vector is the reference's."""
+"""Ground-truth pose pieces of a dataset item (tools/dataset.py: generate_agg_data): what the reference derives from the
+side file's RT matrices in F/tools/data_manipulation.py:962-997 (extract_xyz_R_T_from_RTs, with :878-935 projection,
+:999-1003 depth, :1017-1050 translation).  Here ONE batched evaluation over all instances of a frame, host-side numpy in
+float64 like the reference; `tests/test_dataset_gt.py` pins the values against the reference's own class.
+
+Per instance, with M = RT^-1 (camera <- object) and K the intrinsics:
+  origin   o = M[:3, 3]                       the object's origin in the camera frame (the reference projects the points
+                                              0.3 * {0, e_z, e_y, e_x} and keeps only the first)
+  pixel    (u, v) = trunc_int32((K o)[:2] / (K o)[2])
+  xy       = (v, u)                           row, column — the reference flips the projection
+  z        = 1000 * M[2, 3]                   millimetres
+  T        = K^-1 [f32(f32(u) z'), f32(f32(v) z'), z']   z' = z / 1000; the two products are rounded to float32 as in
+                                              the reference (it scales a float32 copy of the pixel in place)
+  R        = RT[:3, :3]
+"""
 import numpy as np
 
 
-def cartesian_2_homogeneous_coord(cartesian_coord):
-    """[3, N] -> [4, N]"""
-    return np.vstack([cartesian_coord, np.ones((1, cartesian_coord.shape[1]), dtype=cartesian_coord.dtype)])
+def project_origins(RTs, intrinsics):
+    """RTs [n,4,4], intrinsics [3,3] -> (pixels int32 [n,2] as (u = column, v = row), z [n] in mm)."""
+    M = np.linalg.inv(np.asarray(RTs, dtype=np.float64).reshape(-1, 4, 4))
+    cam = M[:, :3, 3]                                           # [n,3]
+    proj = cam @ np.asarray(intrinsics, dtype=np.float64).T     # rows = K o
+    pix = (proj[:, :2] / proj[:, 2:3]).astype(np.int32)         # truncation toward zero, as .astype(np.int32) does
+    return pix, M[:, 2, 3] * 1000.0
 
 
-def homogeneous_2_cartesian_coord(homogeneous_coord):
-    """[K, N] -> [K - 1, N], divided by the last row"""
-    return homogeneous_coord[:-1, :] / homogeneous_coord[-1, :]
-
-
-def transform_3d_camera_coords_to_2d_quantized_projections(cartesian_camera_coordinates_3d, RT, intrinsics):
-    """[3, N] camera-frame points, RT [4, 4], intrinsics [3, 3] -> int32 [N, 2] pixel projections (x, y); the reference's
-    "method 2": inverse transform, K [I | 0], perspective division, truncation to int32 (:925)."""
-    homogeneous_camera_coordinates_3d = cartesian_2_homogeneous_coord(cartesian_camera_coordinates_3d)
-    K_matrix = np.hstack([intrinsics, np.zeros((intrinsics.shape[0], 1), dtype=np.float32)])
-    homogeneous_world_coordinates_3d = np.linalg.inv(RT) @ homogeneous_camera_coordinates_3d
-    homogeneous_projections_2d = K_matrix @ homogeneous_world_coordinates_3d
-    cartesian_projections_2d = homogeneous_2_cartesian_coord(homogeneous_projections_2d)
-    cartesian_projections_2d = cartesian_projections_2d.astype(np.int32)
-    return cartesian_projections_2d.transpose()
-
-
-def extract_z_from_RT(RT):
-    return np.linalg.inv(RT)[2, 3] * 1000
-
-
-def create_translation_vector(cartesian_projections_2d_xy_origin, z, intrinsics):
-    """projection [2, 1] of the origin, its depth z (mm), intrinsics -> translation vector [3, 1] (metres)"""
-    p = cartesian_projections_2d_xy_origin.astype(np.float32)
-    p[0, :] = p[0, :] * (z / 1000)
-    p[1, :] = p[1, :] * (z / 1000)
-    homogeneous = np.vstack([p, z / 1000])
-    return np.linalg.inv(intrinsics) @ homogeneous
+def translations_from_pixels(pix, z_mm, intrinsics):
+    """pixels int32 [n,2] (u, v), depths [n] (mm) -> T [n,3] (metres)."""
+    zs = np.asarray(z_mm, dtype=np.float64) / 1000.0
+    uv = (pix.astype(np.float32).astype(np.float64) * zs[:, None]).astype(np.float32).astype(np.float64)
+    rays = np.concatenate([uv, zs[:, None]], axis=1)            # [n,3]
+    return rays @ np.linalg.inv(np.asarray(intrinsics)).T
 
 
 def extract_xyz_R_T_from_RTs(RTs, intrinsics):
-    n = len(RTs)
-    xy, z, R, T = np.zeros((n, 2)), np.zeros((n, 1)), np.zeros((n, 3, 3)), np.zeros((n, 3))
-    for i in range(n):
-        xyz_axis = 0.3 * np.array([[0, 0, 0], [0, 0, 1], [0, 1, 0], [1, 0, 0]]).transpose()
-        projected = transform_3d_camera_coords_to_2d_quantized_projections(xyz_axis, RTs[i], intrinsics)
-        xy[i] = np.flip(projected[0])
-        z[i] = extract_z_from_RT(RTs[i])
-        origin = projected[0, :].reshape((-1, 1))
-        T[i] = create_translation_vector(origin, z[i], intrinsics).T
-        R[i] = np.array(RTs[i])[:3, :3]
-    return {'xy': xy, 'z': z, 'R': R, 'T': T}
+    """-> {'xy' [n,2] (row, column of the projected origin), 'z' [n,1] (mm), 'R' [n,3,3], 'T' [n,3]}, float64."""
+    RTs = np.asarray(RTs, dtype=np.float64).reshape(-1, 4, 4)
+    pix, z = project_origins(RTs, intrinsics)
+    return {'xy': pix[:, ::-1].astype(np.float64), 'z': z[:, None], 'R': RTs[:, :3, :3].copy(),
+            'T': translations_from_pixels(pix, z, intrinsics)}

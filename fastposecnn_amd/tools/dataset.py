@@ -338,31 +338,30 @@ class NOCSDataset(torch.utils.data.Dataset):
         depth = standardize_depth(imread_png(color_fp.replace('_color.png', '_depth.png')))
         json_data = jt.load_from_json(color_fp.replace('_color.png', '_meta+.json'))
 
-        # distractor objects (ids the side file does not list) go
-        instances_mask = np.zeros_like(mask)
-        for instance_id in json_data['instance_dict'].keys():
-            instances_mask[mask == int(instance_id)] = int(instance_id)
-        # ... and so do instances of classes that are not wanted
+        # Which pixels survive: instances the side file lists (distractor objects are not listed) whose class is one of
+        # the wanted ones (F/tools/dataset.py:183-228).  Two 256-entry tables indexed by the mask's instance id — id -> id
+        # and id -> class index — replace the reference's per-instance sweeps over the image.
+        listed = [(int(k), c) for k, c in json_data['instance_dict'].items()]
+        rows = [r for r, (_, c) in enumerate(listed) if c in self.class_values_map]
+        id_of = np.zeros(256, dtype=mask.dtype)
+        class_of = np.zeros(256, dtype=mask.dtype)
         good_json_data = {'instance_dict': {}}
-        good_instances_mask = np.zeros_like(instances_mask)
-        for enumerate_id, (id_value, class_id) in enumerate(json_data['instance_dict'].items()):
-            if class_id in self.class_values_map.keys():
-                good_instances_mask[instances_mask == int(id_value)] = int(id_value)
-                good_json_data['instance_dict'][int(id_value)] = self.class_values_map[class_id]
-                for key in json_data.keys():
-                    if key != 'instance_dict':
-                        good_json_data.setdefault(key, []).append(json_data[key][enumerate_id])
-        for key in good_json_data.keys():
-            if key != 'instance_dict':
-                good_json_data[key] = np.stack(good_json_data[key])
+        for r in rows:
+            inst_id, c = listed[r]
+            id_of[inst_id] = inst_id
+            class_of[inst_id] = self.class_values_map[c]
+            good_json_data['instance_dict'][inst_id] = self.class_values_map[c]
+        if rows:
+            for key, per_instance in json_data.items():
+                if key != 'instance_dict':
+                    good_json_data[key] = np.stack([per_instance[r] for r in rows])
+        pixel_ids = mask.astype(np.intp)
+        good_instances_mask = id_of[pixel_ids]
 
         agg_data = self.generate_agg_data(good_instances_mask, good_json_data)
         if (agg_data['z'] <= 0).any():                             # invalid / corrupt sample
             return None
-
-        class_mask = np.zeros_like(good_instances_mask)
-        for instance_id, class_id in good_json_data['instance_dict'].items():
-            class_mask[good_instances_mask == int(instance_id)] = class_id
+        class_mask = class_of[pixel_ids]
 
         sample = {'clean_image': image, 'image': image, 'mask': class_mask, 'depth': depth}
         if self.preprocessing:
