@@ -111,9 +111,12 @@ class PoseGatherer:
     read the staging buffer.  `latest()` returns a view of a result buffer that the collective two rounds later
     overwrites: clone it to keep it.  With one rank, or on CPU tensors (gloo tests), the same calls run inline."""
 
-    def __init__(self, capacity, every=4, group=None, device=None):
+    def __init__(self, capacity, every=4, group=None, device=None, always_collective=False):
+        """always_collective: issue the all-gather also in a process group of ONE rank (RCCL copies; the single-GPU test of
+        the device path, tests/test_gpu_rccl_one_rank.py) instead of the plain copy a lone rank normally takes."""
         self.capacity, self.every, self.group = int(capacity), max(1, int(every)), group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self._collective = self.world > 1 or (bool(always_collective) and dist.is_initialized())
         self.device = device
         self._stage = None            # two staging buffers [every, capacity + 1, 40]
         self._out = None              # two results [world, every, capacity + 1, 40]
@@ -178,7 +181,7 @@ class PoseGatherer:
                 for ev in self._packed:
                     self._stream.wait_event(ev)
                 self._stream.wait_event(ready)
-                if self.world > 1:
+                if self._collective:
                     _all_gather_flat(dst, src, self.group)
                 else:
                     dst[0].copy_(src)
@@ -189,7 +192,7 @@ class PoseGatherer:
         else:
             if frames < self.every:
                 src[frames:, 0, 0] = 0
-            if self.world > 1:
+            if self._collective:
                 _all_gather_flat(dst, src, self.group)
             else:
                 dst[0].copy_(src)

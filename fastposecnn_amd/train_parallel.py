@@ -32,14 +32,17 @@ def _slot(numel):
 class ShardedLookaheadRAdam:
 
     def __init__(self, model, lr=1e-5, betas=(0.9, 0.999), eps=1e-8, weight_decay=3e-4, la_k=5, la_alpha=0.5,
-                 clip_norm=0.15, bucket_mb=16.0, group=None, step_fn=None):
+                 clip_norm=0.15, bucket_mb=16.0, group=None, step_fn=None, always_collective=False):
         """lr / weight_decay: F/config.py:56-57; clip_norm: F/train.py `gradient_clip_val`; la_k / la_alpha / betas / eps:
         catalyst's defaults (F/lib/pose_regressor.py:420-423).  `step_fn(p, g, m, v, slow, step, ctl)`: replaces the native
-        kernel (CPU tests only; without it CPU parameters are refused — there is no CPU fallback)."""
+        kernel (CPU tests only; without it CPU parameters are refused — there is no CPU fallback).  `always_collective`:
+        run the reduce-scatter / all-reduce / all-gather also in a process group of ONE rank (the single-GPU test of the
+        RCCL device path, tests/test_gpu_rccl_one_rank.py); a lone rank normally skips them."""
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.backend = dist.get_backend(group) if dist.is_initialized() else None
+        self._collective = self.world > 1 or (bool(always_collective) and dist.is_initialized())
         self.hp = dict(lr=lr, beta1=betas[0], beta2=betas[1], eps=eps, weight_decay=weight_decay, la_k=la_k, la_alpha=la_alpha)
         self.clip_norm = clip_norm
         self.step_count = 0
@@ -77,7 +80,7 @@ class ShardedLookaheadRAdam:
         self.m = torch.zeros(shard_total, **f32)
         self.v = torch.zeros(shard_total, **f32)
         self.slow = torch.zeros(shard_total, **f32)
-        self.g_shard = torch.zeros(shard_total, **f32) if self.world > 1 else None
+        self.g_shard = torch.zeros(shard_total, **f32) if self._collective else None
         soff = 0
         self._hooks = []
         for bi, b in enumerate(self.buckets):
@@ -129,7 +132,7 @@ class ShardedLookaheadRAdam:
 
     def _reduce_bucket(self, b):
         b["launched"] = True
-        if self.world == 1:
+        if not self._collective:
             return
         g = self._bucket_grad(b)
         out = self.g_shard[b["shard_offset"]:b["shard_offset"] + b["shard"]]
@@ -159,7 +162,7 @@ class ShardedLookaheadRAdam:
     def _shard_views(self, b):
         so, sh = b["shard_offset"], b["shard"]
         p = self._bucket_param(b)[self.rank * sh:(self.rank + 1) * sh]
-        g = self.g_shard[so:so + sh] if self.world > 1 else self._bucket_grad(b)
+        g = self.g_shard[so:so + sh] if self._collective else self._bucket_grad(b)
         return p, g, self.m[so:so + sh], self.v[so:so + sh], self.slow[so:so + sh]
 
     def step(self):
@@ -183,7 +186,7 @@ class ShardedLookaheadRAdam:
             else:
                 self.stat[0] += (g.double() ** 2).sum()
                 self.stat[1] += (~torch.isfinite(g)).sum()
-        if self.world > 1:
+        if self._collective:
             dist.all_reduce(self.stat, op=dist.ReduceOp.SUM, group=self.group)
         norm = torch.sqrt(self.stat[0]) / self.world
         bad = (self.stat[1] != 0) | ~torch.isfinite(norm)
@@ -202,7 +205,7 @@ class ShardedLookaheadRAdam:
                                                          nat.stream()), "fpc_lookahead_radam_step")
             else:
                 self.step_fn(p, g, m, v, slow, self.step_count, self.ctl, hp)
-        if self.world > 1:
+        if self._collective:
             for b in self.buckets:
                 p = self._shard_views(b)[0]
                 dist.all_gather_into_tensor(self._bucket_param(b), p, group=self.group)

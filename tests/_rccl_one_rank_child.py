@@ -1,0 +1,93 @@
+"""Child process of tests/test_gpu_rccl_one_rank.py: ONE rank, backend "nccl" (= RCCL), the one GPU of the box.
+
+Drives the device branches that the gloo tests cannot reach — `all_gather_into_tensor` on device buffers from a side
+stream behind events of four packing streams (PoseGatherer), `reduce_scatter_tensor` on the communication stream during
+backward, the f64 statistics `all_reduce` and the in-place parameter `all_gather_into_tensor` (ShardedLookaheadRAdam) —
+and compares every result with the same objects running WITHOUT a process group's collectives.  Prints one JSON line."""
+import json
+import os
+import sys
+
+import torch
+import torch.distributed as dist
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from fastposecnn_amd import parallel                                   # noqa: E402
+from fastposecnn_amd.train_parallel import ShardedLookaheadRAdam       # noqa: E402
+
+
+def fake_agg(n, seed, dev):
+    g = torch.Generator().manual_seed(seed)
+    r = lambda *s: torch.randn(*s, generator=g).to(dev)
+    return {"sample_ids": torch.zeros(n, dtype=torch.int64, device=dev), "class_ids": torch.randint(1, 7, (n,), generator=g).to(dev),
+            "quaternion": r(n, 4), "scales": r(n, 3), "xy": r(n, 2), "z": r(n, 1), "R": r(n, 3, 3), "T": r(n, 3), "RT": r(n, 4, 4)}
+
+
+def gatherer_leg(dev):
+    cap, every, frames = 8, 3, 11
+    streams = [torch.cuda.Stream(device=dev) for _ in range(4)]
+    res = {}
+    for tag, always in (("rccl", True), ("plain", False)):
+        pg = parallel.PoseGatherer(cap, every=every, always_collective=always)
+        seen = []
+        for f in range(frames):
+            with torch.cuda.stream(streams[f % 4]):
+                agg = fake_agg(f % (cap + 1), 100 + f, dev)
+                pg.add(agg, sample_offset=f)
+            if pg.pending == 0:                                        # a collective was just issued
+                seen.append(pg.latest().clone())
+        pg.finish(parallel.PoseGatherer.rounds_for(frames, 1, every) + 1, device=dev)     # one partial + one EMPTY round
+        seen.append(pg.latest().clone())
+        torch.cuda.synchronize()
+        res[tag] = (seen, pg.collectives, pg._collective)
+    a, b = res["rccl"], res["plain"]
+    assert a[2] is True and b[2] is False and a[1] == b[1] == 5, (a[1:], b[1:])
+    for x, y in zip(a[0], b[0]):
+        assert torch.equal(x, y)
+    # against records rebuilt directly: round 0 = frames 0..2
+    want = torch.stack([parallel.pack_pose_records(fake_agg(f % (cap + 1), 100 + f, dev), f, cap) for f in range(3)])
+    assert torch.equal(a[0][0][0], want)
+    assert int(a[0][-1][0, :, 0, 0].view(torch.int32).abs().sum()) == 0          # the empty round: every slot count 0
+    return {"collectives": a[1]}
+
+
+def optimiser_leg(dev):
+    def make():
+        torch.manual_seed(3)
+        return torch.nn.Sequential(torch.nn.Conv2d(3, 16, 3, padding=1), torch.nn.ReLU(), torch.nn.Conv2d(16, 8, 3, padding=1),
+                                   torch.nn.Flatten(), torch.nn.Linear(8 * 12 * 12, 5)).to(dev)
+    outs = {}
+    for tag, always in (("rccl", True), ("plain", False)):
+        m = make()
+        opt = ShardedLookaheadRAdam(m, lr=1e-3, bucket_mb=0.004, always_collective=always)       # three buckets
+        g = torch.Generator().manual_seed(9)
+        for step in range(7):                                          # past one Lookahead period (k = 5)
+            x = torch.randn(4, 3, 12, 12, generator=g).to(dev)
+            opt.zero_grad()
+            m(x).square().mean().backward()
+            opt.step()
+        torch.cuda.synchronize()
+        outs[tag] = (opt.flat_p.clone(), len(opt.buckets), opt._collective, int(opt.skipped))
+    a, b = outs["rccl"], outs["plain"]
+    assert a[2] is True and b[2] is False and a[1] == b[1] and a[1] >= 3 and a[3] == b[3] == 0
+    assert torch.equal(a[0], b[0]), float((a[0] - b[0]).abs().max())
+    return {"buckets": a[1]}
+
+
+def main():
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(dev)
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{os.environ.get('FPC_TEST_PORT', '29641')}", rank=0, world_size=1)
+    try:
+        out = {"backend": dist.get_backend(), "world": dist.get_world_size()}
+        out["gatherer"] = gatherer_leg(dev)
+        out["optimiser"] = optimiser_leg(dev)
+        out["hw_queues"] = os.environ.get("GPU_MAX_HW_QUEUES")
+        out["ok"] = True
+    finally:
+        dist.destroy_process_group()
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

@@ -18,7 +18,7 @@ def test_bench_two_ranks_one_gpu_gathered_records_match_single_rank():
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
     out = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "8", "--warmup", "2",
-                          "--min-seconds", "0", "--check-gather", "--gather-every", "3"],
+                          "--min-seconds", "0", "--check-gather", "--gather-every", "3", "--encoder", "resnet18", "--batch", "1"],
                          env=env, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stderr[-3000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
