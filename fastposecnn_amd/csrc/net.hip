@@ -38,7 +38,23 @@ struct PackedConv {
 
 struct Act { size_t off = 0; int H = 0, W = 0, C = 0; };
 
-struct ConvPlan { int bm = 64, bn = 64, nsplit = 1, mtiles = 1, ntiles = 1, wino = 0, bf3 = 0, fused = 0; };
+struct ConvPlan {
+    int bm = 64, bn = 64, nsplit = 1, mtiles = 1, ntiles = 1, wino = 0, bf3 = 0, fused = 0;
+    int lat = 0;             // > 0: k_lateral1x1 with this many workgroups per 128-pixel tile (lateral.hip) instead of k_conv_igemm
+};
+
+// a grouped 1x1 / stride-1 site with K = 64 or 128, bias-only epilogue and one input shared by the groups: the FPN laterals
+// of the stride-4 and stride-8 maps (and fpc_conv2d's test hook)
+static bool lateral_ok(const ConvArgs& a, int groups) {
+    if (a.Kh != 1 || a.Kw != 1 || a.stride != 1 || a.pad != 0 || a.generic != 0 || (a.Cin != 64 && a.Cin != 128) || a.Kpad != a.Cin ||
+        a.Cout % 32 != 0 || a.in_sc != 1 || a.in_sw != a.Cin || a.in_sh != (long long)a.Wi * a.Cin ||
+        a.in_sb != (long long)a.Hi * a.Wi * a.Cin || a.lanepx)
+        return false;
+    for (int g = 0; g < groups; ++g)
+        if (a.p[g].in != a.p[0].in || a.p[g].scale || a.p[g].res || a.p[g].gn_part || ((a.p[g].up != nullptr) != (a.p[0].up != nullptr)))
+            return false;
+    return !(a.p[0].up && ((a.Ho | a.Wo) & 1));
+}
 
 // fused split-K (ConvArgs::fused) needs one arrival counter per output tile
 static bool can_fuse(const ConvPlan& p, int groups, int B) {
@@ -406,6 +422,20 @@ void fill_conv_args(const fpc_net* n, ConvArgs& a, const PackedConv& c, const Co
 }
 
 int launch_conv_plan(ConvArgs& a, const ConvPlan& p, int groups, hipStream_t s) {
+    if (p.lat) {
+        if (!lateral_ok(a, groups)) return FPC_EINVAL;
+        LatArgs l;
+        memset(&l, 0, sizeof(l));
+        l.in = a.p[0].in;
+        for (int g = 0; g < groups; ++g) {
+            // the three bf16 planes sit behind the f32 image (k_pack_weight_bf3)
+            l.wpl[g] = reinterpret_cast<const unsigned short*>(a.p[g].w + (size_t)a.Npad * a.Kpad);
+            l.out[g] = a.p[g].out; l.shift[g] = a.p[g].shift; l.up[g] = a.p[g].up;
+        }
+        l.B = a.B; l.Ho = a.Ho; l.Wo = a.Wo; l.Cout = a.Cout; l.Npad = a.Npad; l.Kpad = a.Kpad; l.groups = groups; l.relu = a.relu;
+        l.parts = p.lat;
+        return launch_lateral1x1(l, s);
+    }
     if (p.wino) {
         WinoArgs w;
         memset(&w, 0, sizeof(w));
@@ -451,6 +481,11 @@ int run_conv(fpc_net* n, ConvArgs& a, int groups, int ci, hipStream_t s) {
             size_t nc = cands.size();
             for (size_t i = 0; i < nc; ++i) { ConvPlan q = cands[i]; q.bf3 = 1; cands.push_back(q); }
         }
+        if (n->split_precision && lateral_ok(a, groups)) {   // pixel-resident lateral product (bf16 x 3 planes)
+            const int tiles = groups * (a.Cout / 32);
+            for (int parts = 1; parts <= tiles; parts *= 2)
+                if (tiles % parts == 0) { ConvPlan lq; lq.lat = parts; cands.push_back(lq); }
+        }
         if (a.wino_w[0] && !a.p[0].up) {
             ConvPlan wq;
             wq.wino = 1; cands.push_back(wq);
@@ -475,7 +510,8 @@ int run_conv(fpc_net* n, ConvArgs& a, int groups, int ci, hipStream_t s) {
             // with several frames in flight a launch that leaves CUs free lets another stream's kernels run
             float score = ms;
             if (n->tune_mode >= 1) {
-                double nblk = q.wino ? (double)cdiv(cdiv(a.Wo, 2), 8) * cdiv(cdiv(a.Ho, 2), (q.wino == 2 || q.wino == 4 || q.wino == 5) ? 8 : 4) * a.B * (a.Cout / 64) * groups
+                double nblk = q.lat ? (double)cdiv(a.Ho * a.Wo, 128) * a.B * q.lat
+                              : q.wino ? (double)cdiv(cdiv(a.Wo, 2), 8) * cdiv(cdiv(a.Ho, 2), (q.wino == 2 || q.wino == 4 || q.wino == 5) ? 8 : 4) * a.B * (a.Cout / 64) * groups
                                      : (double)q.mtiles * q.ntiles * q.nsplit * a.B * groups;
                 double slots = 256.0 * ((q.wino == 2 || q.wino == 4 || q.wino == 5) ? 1.0 : 2.0);
                 double share = nblk / slots;
@@ -736,6 +772,7 @@ extern "C" int fpc_net_conv_count(const fpc_net_t* n) { return n ? (int)n->convs
 extern "C" int fpc_net_conv_plan(const fpc_net_t* n, int i, int* out5) {
     if (!n || !out5 || i < 0 || i >= (int)n->convs.size()) return FPC_EINVAL;
     out5[0] = n->cplan[i].bm; out5[1] = n->cplan[i].bn; out5[2] = n->cplan[i].wino ? -n->cplan[i].wino : n->cplan[i].nsplit;
+    if (n->cplan[i].lat) { out5[0] = 128; out5[1] = 32; out5[2] = 2000 + n->cplan[i].lat; }      // k_lateral1x1 (fpc_conv2d's hook value)
     out5[3] = n->convs[i].Cout; out5[4] = n->convs[i].K;
     return FPC_OK;
 }
@@ -794,6 +831,7 @@ extern "C" int fpc_conv2d_plan(int B, int Ho, int Wo, int Cin, int Cout, int Kh,
                                int* out4) {
     if (!out4) return FPC_EINVAL;
     int Kpad = cdiv(Cin * Kh * Kw, kConvBK) * kConvBK;
+    if (nsplit >= 2000) nsplit = 1;          // k_lateral1x1: no split-K, no GroupNorm rows
     if (nsplit >= 1000) nsplit -= 1000;      // fpc_conv2d's split-precision / two-launch hooks do not change the tiling
     if (nsplit >= 100) nsplit -= 100;
     ConvPlan p = plan_conv(Ho * Wo, B, Cout, Kpad / kConvBK, 1, bm, bn, nsplit);
@@ -804,9 +842,10 @@ extern "C" int fpc_conv2d_plan(int B, int Ho, int Wo, int Cin, int Cout, int Kh,
 
 namespace {
 // the hooks folded into fpc_conv2d's `nsplit` argument
-struct Conv2dRequest { int nsplit; bool bf3, two_launch, wino; };
+struct Conv2dRequest { int nsplit; bool bf3, two_launch, wino; int lat; };
 Conv2dRequest conv2d_request(int nsplit) {
-    Conv2dRequest r{nsplit, false, false, false};
+    Conv2dRequest r{nsplit, false, false, false, 0};
+    if (r.nsplit >= 2000) { r.lat = r.nsplit - 2000; r.bf3 = true; r.nsplit = 1; return r; }      // 2000 + parts = k_lateral1x1 (lateral.hip)
     if (r.nsplit >= 1000) { r.bf3 = true; r.nsplit -= 1000; }          // 1000 + split = split-precision matrix products
     if (r.nsplit >= 100) { r.two_launch = true; r.nsplit -= 100; }      // 100 + split = split-K summed by k_conv_splitk_epilogue
     r.wino = r.nsplit <= -1 && r.nsplit >= -5;      // -1: 4 waves, -2: 8 waves, -3: wave-private, -4: all-DMA 3-stage, -5: 8 waves split precision
@@ -830,6 +869,7 @@ ConvPlan conv2d_plan_for(int B, int Ho, int Wo, int Cin, int Cout, int Kh, int K
     ConvPlan p = plan_conv(Ho * Wo, B, Cout, Kpad / kConvBK, 1, r.wino ? 0 : bm, bn, r.wino ? 1 : r.nsplit);
     p.bf3 = r.bf3 ? 1 : 0;
     if (r.two_launch) p.fused = 0;
+    p.lat = r.lat;
     return p;
 }
 }  // namespace
@@ -900,5 +940,6 @@ extern "C" int fpc_conv2d(const float* in, int64_t sb, int64_t sh, int64_t sw, i
     }
     a.bf3 = (p.bf3 && mode == 0) ? 1 : 0;
     if (p.bf3 && mode != 0) return FPC_EINVAL;
+    if (p.lat) return launch_conv_plan(a, p, 1, s);
     return run_conv(nullptr, a, 1, 0, s);
 }

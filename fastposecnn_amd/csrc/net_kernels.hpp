@@ -38,6 +38,19 @@ struct ConvArgs {
     void* dbg;                        // host side only: diagnostic stamp buffer for k_conv_wino (or null)
 };
 
+// FPN lateral 1x1 convolutions of all decoders as one pixel-resident product (lateral.hip): K = Cin in {64, 128}
+struct LatArgs {
+    const float* in;                        // [B][Ho*Wo][K] channel-last, contiguous; shared by the groups
+    const unsigned short* wpl[kMaxGroup];   // k_pack_weight_bf3's planes: [3][Npad][Kpad] bf16
+    float* out[kMaxGroup];                  // [B][Ho*Wo][Cout]
+    const float* shift[kMaxGroup];          // conv bias or null
+    const float* up[kMaxGroup];             // [B][Ho/2][Wo/2][Cout], nearest-x2 upsampled and added; all null or none
+    int B, Ho, Wo, Cout, Npad, Kpad, groups, relu;
+    unsigned bias_mask;                     // set by launch_lateral1x1: 0 = no bias (shift then points at readable memory)
+    int parts;                              // workgroups per 128-pixel tile: each walks (groups * Cout / 32) / parts weight tiles
+};
+int launch_lateral1x1(const LatArgs& a, hipStream_t s);
+
 constexpr int kMaxGnSites = 4;    // segmentation sites finalized by one launch (x kMaxGroup decoders each)
 struct GnFinArgs {
     const float* gn_part[kMaxGnSites * kMaxGroup];   // [site * kMaxGroup + decoder]: [B][P][C][2]

@@ -3,7 +3,8 @@
 Drives the device branches that the gloo tests cannot reach — `all_gather_into_tensor` on device buffers from a side
 stream behind events of four packing streams (PoseGatherer), `reduce_scatter_tensor` on the communication stream during
 backward, the f64 statistics `all_reduce` and the in-place parameter `all_gather_into_tensor` (ShardedLookaheadRAdam) —
-and compares every result with the same objects running WITHOUT a process group's collectives.  Prints one JSON line."""
+and compares every result with the same objects running WITHOUT a process group's collectives (pose records bit for bit;
+trained parameters to rounding: the convolution backward under them is MIOpen's).  Prints one JSON line."""
 import json
 import os
 import sys
@@ -70,8 +71,10 @@ def optimiser_leg(dev):
         outs[tag] = (opt.flat_p.clone(), len(opt.buckets), opt._collective, int(opt.skipped))
     a, b = outs["rccl"], outs["plain"]
     assert a[2] is True and b[2] is False and a[1] == b[1] and a[1] >= 3 and a[3] == b[3] == 0
-    assert torch.equal(a[0], b[0]), float((a[0] - b[0]).abs().max())
-    return {"buckets": a[1]}
+    # the two legs run MIOpen's convolution backward, which is not run-to-run bit-reproducible (3.7e-9 seen between two runs of
+    # the SAME leg): parameters after 7 steps agree to rounding, the collectives themselves move bytes unchanged
+    assert torch.allclose(a[0], b[0], rtol=1e-5, atol=1e-7), float((a[0] - b[0]).abs().max())
+    return {"buckets": a[1], "max_abs_diff": float((a[0] - b[0]).abs().max())}
 
 
 def main():

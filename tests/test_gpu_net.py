@@ -127,6 +127,13 @@ CONV_CASES = [
     (1, 128, 34, 50, 128, 3, 1, 1, (0, 0, -5), "gn"),
     (1, 8, 7, 9, 64, 3, 1, 1, (0, 0, -5), "bias_relu"),       # a single K-step
     (1, 16, 20, 24, 64, 3, 1, 1, (0, 0, -5), "bias_relu"),    # two K-steps
+    # pixel-resident FPN lateral product, k_lateral1x1 (nsplit = 2000 + workgroups per 128-pixel tile): K = 64 / 128, bf16 x 3 planes
+    (2, 64, 24, 32, 256, 1, 1, 0, (0, 0, 2001), "bias_up"),       # 768 pixels = 6 tiles, one workgroup walks all 8 weight tiles
+    (2, 64, 24, 32, 256, 1, 1, 0, (0, 0, 2004), "bias_up"),
+    (1, 128, 30, 40, 256, 1, 1, 0, (0, 0, 2002), "bias_up"),      # K = 128; 1200 pixels: ragged last tile (48 rows)
+    (1, 128, 30, 40, 256, 1, 1, 0, (0, 0, 2008), "bias"),         # one weight tile per workgroup, no top-down addend
+    (3, 64, 10, 14, 96, 1, 1, 0, (0, 0, 2003), "bias_relu"),      # 140 pixels: waves 1-3 of the second tile partly / fully empty; Cout = 96
+    (1, 64, 6, 8, 32, 1, 1, 0, (0, 0, 2001), "none"),             # no bias: accumulation starts from zero
     # 8-wave form (8x8 tile patch per workgroup, nsplit = -2)
     (1, 64, 30, 40, 64, 3, 1, 1, (0, 0, -2), "bn_relu_res"),
     (2, 256, 15, 20, 128, 3, 1, 1, (0, 0, -2), "gn"),

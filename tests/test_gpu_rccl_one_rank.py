@@ -1,8 +1,8 @@
 """The RCCL branches of the multi-GPU code, executed for real on the one GPU of the box (Next 5): a fresh child
 process initialises backend "nccl" with world_size 1 and drives PoseGatherer (add from four streams / flush / finish /
 latest) and ShardedLookaheadRAdam (reduce-scatter in backward, statistics all-reduce, parameter all-gather) through
-`all_gather_into_tensor` / `reduce_scatter_tensor` on device memory; results must equal the collective-free single-process
-path bit for bit (tests/_rccl_one_rank_child.py).  The gloo tests cover world_size 2 on the CPU."""
+`all_gather_into_tensor` / `reduce_scatter_tensor` on device memory; the gathered pose records must equal the collective-free
+single-process path bit for bit, the trained parameters to rounding (tests/_rccl_one_rank_child.py).  The gloo tests cover world_size 2 on the CPU."""
 import json
 import os
 import subprocess
