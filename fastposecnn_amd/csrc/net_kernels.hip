@@ -804,30 +804,7 @@ __global__ __launch_bounds__(64) void k_gn_finalize(const GnFinArgs a) {
     }
 }
 
-// bilinear source coordinate, align_corners=True, torch's arithmetic (UpSample.cuh):
-// src = dst * (in-1)/(out-1) in f32; i0 = (int)src; l1 = src - i0; i1 = i0 + (i0 < in-1)
-struct Lerp { int i0, i1; float l0, l1; };
-__device__ __forceinline__ Lerp lerp_coord(int dst, int in, int out) {
-    float scale = out > 1 ? (float)(in - 1) / (float)(out - 1) : 0.f;
-    float src = scale * (float)dst;
-    Lerp L;
-    L.i0 = (int)src;
-    L.i1 = L.i0 + (L.i0 < in - 1 ? 1 : 0);
-    L.l1 = src - (float)L.i0;
-    L.l0 = 1.f - L.l1;
-    return L;
-}
-
-// lerp_coord with the scale (in - 1) / (out - 1) computed by the caller once
-__device__ __forceinline__ Lerp lerp_scaled(int dst, int in, float scale) {
-    float src = scale * (float)dst;
-    Lerp L;
-    L.i0 = (int)src;
-    L.i1 = L.i0 + (L.i0 < in - 1 ? 1 : 0);
-    L.l1 = src - (float)L.i0;
-    L.l0 = 1.f - L.l1;
-    return L;
-}
+// Lerp / lerp_coord / lerp_scaled: net_kernels.hpp (shared with up4.hip)
 
 __device__ __forceinline__ float4 gn_relu4(const float* p, float4 sa, float4 sb) {
     float4 v = *reinterpret_cast<const float4*>(p);
@@ -885,7 +862,7 @@ __global__ __launch_bounds__(256) void k_gn_relu_up2(const GnUpArgs a) {
 // GN+ReLU(+x2 upsample) of each branch and with the 1x1 segmentation head:
 //   merged = up2(relu(gn(t5))) + up2(relu(gn(t4))) + up2(relu(gn(t3))) + relu(gn(t2))   (sum order of sum([...]))
 //   logits_lowres[pixel][ch] = bias[ch] + sum_c merged[pixel][c] * W[ch][c]
-// One workgroup = 64 pixels of one image; merged tile and head weights live in LDS.
+// One workgroup = 32 pixels of one image (an 8 x 4 patch where the map divides into patches); merged tile and head weights live in LDS.
 // Dropout2d is the identity in eval mode.  grid (ceil(H2*W2/64), B, G).
 constexpr int kMhPx = 32;
 constexpr int kMhMaxC = 128;
@@ -933,14 +910,61 @@ __global__ __launch_bounds__(256) void k_merge_head(const MergeHeadArgs a) {
     };
     // bilinear source scales (align_corners): computed once, same arithmetic as lerp_coord
     const float sy = H2 > 1 ? (float)(a.h - 1) / (float)(H2 - 1) : 0.f, sx = W2 > 1 ? (float)(a.w - 1) / (float)(W2 - 1) : 0.f;
-    const int y0 = p0 / W2, x0 = p0 - y0 * W2;               // workgroup-uniform
+    // the workgroup's 32 pixels: an 8 x 4 patch where the map divides into patches (its taps are 5 x 3 low-resolution pixels per
+    // branch instead of the 17 x 2 of a 32-pixel row segment: less than half the L2 -> L1 bytes), else 32 consecutive pixels
+    const bool patch = (W2 % 8 == 0) && (H2 % 4 == 0);
+    const int tpr = W2 >> 3;                                 // patches per patch row
+    const int y0 = patch ? 4 * (blockIdx.x / tpr) : p0 / W2, x0 = patch ? 8 * (blockIdx.x % tpr) : p0 - y0 * W2;      // workgroup-uniform
+    if (patch && C4 == 32) {
+        // a thread = one 2 x 2 output block of the patch x one channel quad.  The block's taps lie in a 3 x 3 low-resolution
+        // neighbourhood (the x2 align_corners scale is < 1/2: the second row / column starts at most one tap later), so a
+        // branch costs 9 loads and GroupNorm + ReLU evaluations for FOUR pixels instead of 16, and the horizontal lerp of a
+        // tap row serves both output rows.  Every pixel's value is the expression of the per-pixel loop below on the same
+        // operands, selected from the neighbourhood: bit-identical.
+        const int blk = threadIdx.x >> 5, c4 = c4f;
+        const int Y = y0 + 2 * (blk >> 2), X = x0 + 2 * (blk & 3);
+        const Lerp lya = lerp_scaled(Y, a.h, sy), lyb = lerp_scaled(Y + 1, a.h, sy);
+        const Lerp lxa = lerp_scaled(X, a.w, sx), lxb = lerp_scaled(X + 1, a.w, sx);
+        const int rb = lya.i0, cb = lxa.i0;
+        const bool sy1 = lyb.i0 != rb, sx1 = lxb.i0 != cb;  // the second row / column's first tap is the next one
+        const int rr[3] = {rb, min(rb + 1, a.h - 1), min(rb + 2, a.h - 1)}, cc[3] = {cb, min(cb + 1, a.w - 1), min(cb + 2, a.w - 1)};
+        f32x4 acc[2][2];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[i >> 1][i & 1] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const float* base = a.t_lo[z][k] + (size_t)b * a.h * a.w * C + 4 * c4;
+            f32x4 g[3][3];
+#pragma unroll
+            for (int r = 0; r < 3; ++r)
+#pragma unroll
+                for (int c = 0; c < 3; ++c) g[r][c] = gnr(base + ((size_t)rr[r] * a.w + cc[c]) * C, la[k], lb[k]);
+#pragma unroll
+            for (int dx = 0; dx < 2; ++dx) {
+                const Lerp lxx = dx ? lxb : lxa;
+                const bool s = dx && sx1;
+                f32x4 hrow[3];
+#pragma unroll
+                for (int r = 0; r < 3; ++r) hrow[r] = lxx.l0 * (s ? g[r][1] : g[r][0]) + lxx.l1 * (s ? g[r][2] : g[r][1]);
+                acc[0][dx] += lya.l0 * hrow[0] + lya.l1 * hrow[1];
+                acc[1][dx] += lyb.l0 * (sy1 ? hrow[1] : hrow[0]) + lyb.l1 * (sy1 ? hrow[2] : hrow[1]);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int dy = i >> 1, dx = i & 1;
+            acc[dy][dx] += gnr(a.t_hi[z] + ((size_t)b * H2 * W2 + (size_t)(Y + dy) * W2 + X + dx) * C + 4 * c4, ha, hb);
+            *reinterpret_cast<f32x4*>(&s_m[(2 * (blk >> 2) + dy) * 8 + 2 * (blk & 3) + dx][4 * c4]) = acc[dy][dx];
+        }
+    } else
 #pragma unroll 2
     for (int pl = prow; pl < kMhPx; pl += pstep) {
         const int c4 = c4f;
-        int p = p0 + pl;
+        int p = patch ? (y0 + (pl >> 3)) * W2 + x0 + (pl & 7) : p0 + pl;
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
         if (p < H2 * W2) {
             int y = y0, x = x0 + pl;
+            if (patch) { y = y0 + (pl >> 3); x = x0 + (pl & 7); }
             while (x >= W2) { x -= W2; ++y; }
             Lerp ly = lerp_scaled(y, a.h, sy), lx = lerp_scaled(x, a.w, sx);
 #pragma unroll
@@ -982,8 +1006,8 @@ __global__ __launch_bounds__(256) void k_merge_head(const MergeHeadArgs a) {
     for (int r = 0; r < 16; ++r) part[(wv * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * 33 + li] = acc[r];
     __syncthreads();
     // the 32 pixels' outputs are one contiguous block of 32 * chp floats; 32 lanes per pixel (k < chp active)
-    const int nvalid = min(kMhPx, H2 * W2 - p0);
-    float* ob = a.out[z] + ((size_t)b * H2 * W2 + p0) * chp;
+    const int nvalid = patch ? kMhPx : min(kMhPx, H2 * W2 - p0);
+    float* ob = a.out[z] + (size_t)b * H2 * W2 * chp;
     const int ok = threadIdx.x & 31;
     const float bias = ok < ch ? a.hb[z][ok] : 0.f;
     for (int pl = threadIdx.x >> 5; pl < nvalid; pl += 8) {
@@ -994,7 +1018,8 @@ __global__ __launch_bounds__(256) void k_merge_head(const MergeHeadArgs a) {
 #pragma unroll
             for (int w = 0; w < 4; ++w) v += part[(w * 32 + pl) * 33 + ok];
         }
-        ob[pl * chp + ok] = v;
+        const int p = patch ? (y0 + (pl >> 3)) * W2 + x0 + (pl & 7) : p0 + pl;
+        ob[(size_t)p * chp + ok] = v;
     }
     FPC_MH_STAMP(4);      // partial exchange + stores
 #ifdef FPC_STAMP_MH
@@ -1335,7 +1360,12 @@ int launch_up4_compress(const Up4Args& a, hipStream_t s) {
     if (a.C < 2 || a.C > 32 || a.H > 65535 || a.B > 65535) return FPC_EINVAL;
     if (a.fg_bits && a.W % 64 != 0) return FPC_EINVAL;
     dim3 grid(cdiv(a.W, 256), a.H, a.B);
-    if (a.C == 7 && a.pm == 8 && a.pq == 24 && a.pt == 20 && a.ps == 20)
+    const bool seven = a.C == 7 && a.pm == 8 && a.pq == 24 && a.pt == 20 && a.ps == 20;
+    const bool all_or_none = (a.o_mask != nullptr) == (a.o_quat != nullptr) && (a.o_mask != nullptr) == (a.o_scales != nullptr) &&
+                             (a.o_mask != nullptr) == (a.o_xy != nullptr) && (a.o_mask != nullptr) == (a.o_z != nullptr);
+    if (seven && a.W % 4 == 0 && ((long long)a.H * a.W) % 256 == 0 && (long long)a.H * a.W < (1LL << 31) && all_or_none)
+        launch_up4_compress7x4(a, s);
+    else if (seven)
         hipLaunchKernelGGL(k_up4_compress7, dim3(cdiv(a.W, 128), a.H, a.B), dim3(128), 0, s, a);
     else if (a.C <= 8) hipLaunchKernelGGL(k_up4_compress<8>, grid, dim3(256), 0, s, a);
     else hipLaunchKernelGGL(k_up4_compress<32>, grid, dim3(256), 0, s, a);

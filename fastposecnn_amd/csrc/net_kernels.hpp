@@ -115,6 +115,33 @@ int launch_gn_finalize(const GnFinArgs& a, int groups, hipStream_t s);
 int launch_gn_relu_up2(const GnUpArgs& a, int groups, hipStream_t s);
 int launch_merge_head(const MergeHeadArgs& a, int groups, hipStream_t s);
 int launch_up4_compress(const Up4Args& a, hipStream_t s);
+void launch_up4_compress7x4(const Up4Args& a, hipStream_t s);   // up4.hip; preconditions checked by launch_up4_compress
+
+// bilinear source coordinate, align_corners=True, torch's arithmetic (UpSample.cuh):
+// src = dst * (in-1)/(out-1) in f32; i0 = (int)src; l1 = src - i0; i1 = i0 + (i0 < in-1)
+struct Lerp { int i0, i1; float l0, l1; };
+__device__ __forceinline__ Lerp lerp_coord(int dst, int in, int out) {
+    float scale = out > 1 ? (float)(in - 1) / (float)(out - 1) : 0.f;
+    float src = scale * (float)dst;
+    Lerp L;
+    L.i0 = (int)src;
+    L.i1 = L.i0 + (L.i0 < in - 1 ? 1 : 0);
+    L.l1 = src - (float)L.i0;
+    L.l0 = 1.f - L.l1;
+    return L;
+}
+
+// lerp_coord with the scale (in - 1) / (out - 1) computed by the caller once
+__device__ __forceinline__ Lerp lerp_scaled(int dst, int in, float scale) {
+    float src = scale * (float)dst;
+    Lerp L;
+    L.i0 = (int)src;
+    L.i1 = L.i0 + (L.i0 < in - 1 ? 1 : 0);
+    L.l1 = src - (float)L.i0;
+    L.l0 = 1.f - L.l1;
+    return L;
+}
+
 int launch_pack_weight(const float* w_oihw, float* packed, int Cout, int Cin, int Cinp, int Kh, int Kw, int Kwp, int Npad,
                        int Kpad, hipStream_t s);
 // + the three bf16 planes of the same image behind it (packed + Npad * Kpad floats; 1.5 x Npad * Kpad floats more):
