@@ -605,7 +605,7 @@ def run_inference(args, encoder, Bq, hn, steps, warmup, world, rank, dev, want_b
                 step_host(last=True)
             drain()
 
-        nh = max(10, steps // 4)
+        nh = int(os.environ.get("FPC_BENCH_HOST_FRAMES", "0")) or max(10, steps // 4)
         run_host(depth + 3)
         torch.cuda.synchronize()
         t2 = time.perf_counter()
@@ -706,6 +706,21 @@ def attach_profiled_counters(roof, name):
                         "unit": "G wave-instr/s", "frac": round(rate / VALU_PEAK_WAVE_INSTR_PER_S, 4), "wave_instructions_per_launch": vinst,
                         "note": "SQ_INSTS_VALU of the four kernels (the profile) / the live launch time; peak = 1024 SIMD-32 x 2.4 GHz / 2 "
                                 "cycles per wave64 instruction (tools_dev/mfma_vote_probe.hip measured 2.6 for v_sub + v_alignbit at >= 2 waves per SIMD)"}
+
+
+def attach_mfma_busy(backbone, name):
+    """`backbone.mfma_busy`: matrix-pipe busy share from SQ counters (SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 x 1024
+    SIMDs)) of a separately profiled forward of the same configuration (tools_dev/r5_conv_pmc.sh -> profiles/<name>): the
+    whole forward and its dominant convolution kernels.  Attached LABELLED (`from_profile`), not measured by this run."""
+    prof = load_profile_json(name) if name else None
+    if not prof or backbone is None:
+        return
+    fam = prof.get("families", {})
+    keep = {k: {"mfma_busy": v.get("mfma_busy"), "us_under_pmc": v.get("us_under_pmc"), "clock_GHz_under_pmc": v.get("clock_GHz_under_pmc")}
+            for k, v in fam.items() if v.get("mfma_busy", 0) and ("k_conv" in k or "k_lateral" in k)}
+    backbone["mfma_busy"] = {"forward": prof.get("forward", {}).get("mfma_busy"), "kernels": keep,
+                             "unit": "share of cycles x SIMDs with the matrix pipe busy (counter-based; all kernels of the forward in the denominator)",
+                             "from_profile": {"file": "profiles/" + name, "commit": prof.get("commit")}}
 
 
 def load_profile_json(name):
@@ -857,6 +872,8 @@ def main():
         }
         if "backbone" in res:
             line["backbone"] = res["backbone"]
+            attach_mfma_busy(line["backbone"], "r05_conv_pmc_b1.json" if (args.encoder == "resnet18" and args.batch == 1) else
+                             ("r05_conv_pmc_c3.json" if (args.encoder == "resnet34" and args.batch == 32) else None))
 
     if world == 1:
         # the training value of hn on a 32-frame batch (F/config.py:93): where the sequence is closest to its HBM bound
@@ -923,6 +940,7 @@ def main():
                 c3["backbone"] = r3["backbone"]
             c3["roofline"] = vote_roofline(ctx3["model_gpu"], ctx3["cat"], ctx3["n_inst"], 5, f"batch 32, hn {args.hn}, 192 instances")
             attach_profiled_counters(c3["roofline"], "r04_vote_bits_traffic_b32_hn1000.json" if args.hn == 1000 else None)
+            attach_mfma_busy(c3.get("backbone"), "r05_conv_pmc_c3.json")
             c3["roofline"]["bound_note"] = ("this configuration's count kernel is bound by vector-ALU issue, not HBM: 2 instructions per "
                                             "(entry, hypothesis) register pair behind 1/512 MFMA, ~3.0e9 pairs per call (`valu`); "
                                             "tools_dev/r4_vote_fused/README.md")

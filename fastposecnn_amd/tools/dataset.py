@@ -211,31 +211,35 @@ class PngFramePrefetcher:
     def __init__(self, read_batch, n_batches, batch, height, width, workers=12, ahead=None):
         from concurrent.futures import ThreadPoolExecutor
         self.read_batch, self.n, self.shape = read_batch, int(n_batches), (batch, height, width, 3)
-        self.ahead = int(ahead) if ahead else max(2, (2 * workers) // max(1, batch))
+        self.ahead = int(ahead) if ahead else max(2, -(-2 * workers // max(1, batch)))
         self._pool = ThreadPoolExecutor(max_workers=workers)
         self._pending, self._next = [], 0
         nat.lib()
 
-    def _decode(self, i):
+    def _decode_one(self, buf, dst):
+        nat.check(nat.lib().fpc_png_decode(buf.ctypes.data, buf.size, dst.ctypes.data, dst.nbytes, 3), "fpc_png_decode")
+
+    def _submit(self, i):
+        """One task per FILE (a batch of 32 decoded by one worker kept 2 of 14 workers busy: 350 img/s at batch 32)."""
         files = self.read_batch(i)
         out = np.empty(self.shape, np.uint8)
-        L = nat.lib()
-        for j, f in enumerate(files):
-            buf = np.frombuffer(f, dtype=np.uint8)
-            nat.check(L.fpc_png_decode(buf.ctypes.data, buf.size, out[j].ctypes.data, out[j].nbytes, 3), "fpc_png_decode")
-        return out
+        bufs = [np.frombuffer(f, dtype=np.uint8) for f in files]
+        return out, bufs, [self._pool.submit(self._decode_one, b, out[j]) for j, b in enumerate(bufs)]
 
     def __iter__(self):
         return self
 
     def __next__(self):
         while self._next < self.n and len(self._pending) < self.ahead:
-            self._pending.append(self._pool.submit(self._decode, self._next))
+            self._pending.append(self._submit(self._next))
             self._next += 1
         if not self._pending:
             self._pool.shutdown(wait=False)
             raise StopIteration
-        return self._pending.pop(0).result()
+        out, _bufs, futs = self._pending.pop(0)
+        for f in futs:
+            f.result()
+        return out
 
 
 # ------------------------------------------------------------------------------------------------ ground-truth samples
