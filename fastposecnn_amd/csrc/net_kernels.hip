@@ -1753,10 +1753,6 @@ __global__ __launch_bounds__(64 * NW, BF3 ? 1 : 2) void k_conv_wino(const WinoAr
         iok[i] = inreg && y >= 0 && y < H && x >= 0 && x < W;
         ivo[i] = iok[i] ? (unsigned)((((size_t)y * W + x) * Cin + 4 * hf) * sizeof(float)) : 0u;
     }
-    // out-of-image positions are never written by the DMA (inactive lanes): zero both input buffers once
-    for (int i = t; i < 2 * LINP / 4; i += 64 * NW) reinterpret_cast<f32x4*>(lds)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __syncthreads();
 #pragma clang diagnostic push
 #pragma clang diagnostic ignored "-Winline-asm"
 #define FPC_LDS_ADDR(PTR) ((unsigned)(size_t)(__attribute__((address_space(3))) void*)(PTR))
@@ -1828,7 +1824,15 @@ __global__ __launch_bounds__(64 * NW, BF3 ? 1 : 2) void k_conv_wino(const WinoAr
     // Input k+2 may overwrite I[cur]: step k's fragments were read from it during step k-1.  The body has no
     // branch: past the last step the sources stop advancing, so the final steps stage (and transform) the
     // last step's operands once more into buffers nobody reads.
-    FPC_WB_ISSUE_W(0);
+    FPC_WB_ISSUE_W(0);      // (the weight buffers are not touched by the zero fill below: the first 48 KB are on their way meanwhile)
+    // out-of-image positions are never written by the DMA (inactive lanes): a patch that reaches over the image border zeroes
+    // both input buffers once.  An interior patch (workgroup-uniform) skips the fill and its barrier: every position the
+    // fragment reads touch is rewritten by every step's DMA (the permuted image's padding units are never read).
+    if (y_in0 < 0 || x_in0 < 0 || y_in0 + RH > H || x_in0 + kWinoRW > W) {
+        for (int i = t; i < 2 * LINP / 4; i += 64 * NW) reinterpret_cast<f32x4*>(lds)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
     FPC_WB_ISSUE_IN(0);
     if (nkb > 1) { wsb += kWB; wsb3 += kWB; isb += 8; }
     FPC_WB_ISSUE_IN(1);
