@@ -41,7 +41,16 @@ struct Act { size_t off = 0; int H = 0, W = 0, C = 0; };
 struct ConvPlan {
     int bm = 64, bn = 64, nsplit = 1, mtiles = 1, ntiles = 1, wino = 0, bf3 = 0, fused = 0;
     int lat = 0;             // > 0: k_lateral1x1 with this many workgroups per 128-pixel tile (lateral.hip) instead of k_conv_igemm
+    int stem = 0;            // > 0: k_stem7x7 (stem.hip), a persistent grid of this many workgroups (one per CU: 256)
 };
+
+// the 7x7 / stride-2 / pad-3 stem in its row-per-K-step layout (NHWC4 image, 8 taps x 4 channels per kernel row, K = 224) with a
+// BatchNorm / bias-only epilogue and an output row that divides into 64-pixel segments
+static bool stem_ok(const ConvArgs& a) {
+    return a.lanepx == 1 && a.generic == 0 && a.Kh == 7 && a.stride == 2 && a.pad == 3 && a.Cout == 64 && a.Kpad == 224 &&
+           a.Wo % 64 == 0 && !a.p[0].res && !a.p[0].up && !a.p[0].gn_part && a.in_sc == 1 && a.in_sw == 4 &&
+           a.in_sh == (long long)4 * a.Wi && a.in_sb == (long long)4 * a.Hi * a.Wi;
+}
 
 // a grouped 1x1 / stride-1 site with K = 64 or 128, bias-only epilogue and one input shared by the groups: the FPN laterals
 // of the stride-4 and stride-8 maps (and fpc_conv2d's test hook)
@@ -422,6 +431,17 @@ void fill_conv_args(const fpc_net* n, ConvArgs& a, const PackedConv& c, const Co
 }
 
 int launch_conv_plan(ConvArgs& a, const ConvPlan& p, int groups, hipStream_t s) {
+    if (p.stem) {
+        if (groups != 1 || !stem_ok(a)) return FPC_EINVAL;
+        StemArgs t;
+        memset(&t, 0, sizeof(t));
+        t.in = a.p[0].in;
+        t.wpl = reinterpret_cast<const unsigned short*>(a.p[0].w + (size_t)a.Npad * a.Kpad);      // the bf16 planes behind the f32 image
+        t.out = a.p[0].out; t.scale = a.p[0].scale; t.shift = a.p[0].shift;
+        t.B = a.B; t.Hi = a.Hi; t.Wi = a.Wi; t.Ho = a.Ho; t.Wo = a.Wo; t.Cout = a.Cout; t.Npad = a.Npad; t.Kpad = a.Kpad; t.relu = a.relu;
+        t.grid = p.stem;
+        return launch_stem7x7(t, s);
+    }
     if (p.lat) {
         if (!lateral_ok(a, groups)) return FPC_EINVAL;
         LatArgs l;
@@ -481,6 +501,9 @@ int run_conv(fpc_net* n, ConvArgs& a, int groups, int ci, hipStream_t s) {
             size_t nc = cands.size();
             for (size_t i = 0; i < nc; ++i) { ConvPlan q = cands[i]; q.bf3 = 1; cands.push_back(q); }
         }
+        if (n->split_precision && groups == 1 && stem_ok(a)) {   // weight-resident stem (bf16 x 3 planes), one workgroup per CU
+            ConvPlan sq; sq.stem = 256; cands.push_back(sq);
+        }
         if (n->split_precision && lateral_ok(a, groups)) {   // pixel-resident lateral product (bf16 x 3 planes)
             const int tiles = groups * (a.Cout / 32);
             for (int parts = 1; parts <= tiles; parts *= 2)
@@ -510,7 +533,8 @@ int run_conv(fpc_net* n, ConvArgs& a, int groups, int ci, hipStream_t s) {
             // with several frames in flight a launch that leaves CUs free lets another stream's kernels run
             float score = ms;
             if (n->tune_mode >= 1) {
-                double nblk = q.lat ? (double)cdiv(a.Ho * a.Wo, 128) * a.B * q.lat
+                double nblk = q.stem ? (double)q.stem
+                              : q.lat ? (double)cdiv(a.Ho * a.Wo, 128) * a.B * q.lat
                               : q.wino ? (double)cdiv(cdiv(a.Wo, 2), 8) * cdiv(cdiv(a.Ho, 2), (q.wino == 2 || q.wino == 4 || q.wino == 5) ? 8 : 4) * a.B * (a.Cout / 64) * groups
                                      : (double)q.mtiles * q.ntiles * q.nsplit * a.B * groups;
                 double slots = 256.0 * ((q.wino == 2 || q.wino == 4 || q.wino == 5) ? 1.0 : 2.0);
@@ -773,6 +797,7 @@ extern "C" int fpc_net_conv_plan(const fpc_net_t* n, int i, int* out5) {
     if (!n || !out5 || i < 0 || i >= (int)n->convs.size()) return FPC_EINVAL;
     out5[0] = n->cplan[i].bm; out5[1] = n->cplan[i].bn; out5[2] = n->cplan[i].wino ? -n->cplan[i].wino : n->cplan[i].nsplit;
     if (n->cplan[i].lat) { out5[0] = 128; out5[1] = 32; out5[2] = 2000 + n->cplan[i].lat; }      // k_lateral1x1 (fpc_conv2d's hook value)
+    if (n->cplan[i].stem) { out5[0] = 64; out5[1] = 64; out5[2] = 3000; }                        // k_stem7x7
     out5[3] = n->convs[i].Cout; out5[4] = n->convs[i].K;
     return FPC_OK;
 }
@@ -831,7 +856,7 @@ extern "C" int fpc_conv2d_plan(int B, int Ho, int Wo, int Cin, int Cout, int Kh,
                                int* out4) {
     if (!out4) return FPC_EINVAL;
     int Kpad = cdiv(Cin * Kh * Kw, kConvBK) * kConvBK;
-    if (nsplit >= 2000) nsplit = 1;          // k_lateral1x1: no split-K, no GroupNorm rows
+    if (nsplit >= 2000) nsplit = 1;          // k_lateral1x1 / k_stem7x7: no split-K, no GroupNorm rows
     if (nsplit >= 1000) nsplit -= 1000;      // fpc_conv2d's split-precision / two-launch hooks do not change the tiling
     if (nsplit >= 100) nsplit -= 100;
     ConvPlan p = plan_conv(Ho * Wo, B, Cout, Kpad / kConvBK, 1, bm, bn, nsplit);
@@ -842,9 +867,10 @@ extern "C" int fpc_conv2d_plan(int B, int Ho, int Wo, int Cin, int Cout, int Kh,
 
 namespace {
 // the hooks folded into fpc_conv2d's `nsplit` argument
-struct Conv2dRequest { int nsplit; bool bf3, two_launch, wino; int lat; };
+struct Conv2dRequest { int nsplit; bool bf3, two_launch, wino; int lat; bool stem; };
 Conv2dRequest conv2d_request(int nsplit) {
-    Conv2dRequest r{nsplit, false, false, false, 0};
+    Conv2dRequest r{nsplit, false, false, false, 0, false};
+    if (r.nsplit == 3000) { r.stem = true; r.bf3 = true; r.nsplit = 1; return r; }                   // 3000 = k_stem7x7 (stem.hip): NHWC4 input
     if (r.nsplit >= 2000) { r.lat = r.nsplit - 2000; r.bf3 = true; r.nsplit = 1; return r; }      // 2000 + parts = k_lateral1x1 (lateral.hip)
     if (r.nsplit >= 1000) { r.bf3 = true; r.nsplit -= 1000; }          // 1000 + split = split-precision matrix products
     if (r.nsplit >= 100) { r.two_launch = true; r.nsplit -= 100; }      // 100 + split = split-K summed by k_conv_splitk_epilogue
@@ -870,6 +896,7 @@ ConvPlan conv2d_plan_for(int B, int Ho, int Wo, int Cin, int Cout, int Kh, int K
     p.bf3 = r.bf3 ? 1 : 0;
     if (r.two_launch) p.fused = 0;
     p.lat = r.lat;
+    p.stem = r.stem ? 256 : 0;
     return p;
 }
 }  // namespace
@@ -902,6 +929,20 @@ extern "C" int fpc_conv2d(const float* in, int64_t sb, int64_t sh, int64_t sw, i
     c.K = Cin * Kh * Kw; c.Kpad = cdiv(c.K, kConvBK) * kConvBK; c.Npad = cdiv(Cout, kConvNAlign) * kConvNAlign;
     hipStream_t s = (hipStream_t)stream;
     float* packed = (float*)ws;
+    if (rq.stem) {      // the engine's stem layout: NHWC4 input, 8 taps x 4 channels per kernel row (K = 224), bf16 planes only
+        if (Cin != 4 || Kh != 7 || stride != 2 || pad != 3 || Cout != 64 || sc != 1 || sw != 4 || sh != (int64_t)4 * Wi ||
+            sb != (int64_t)4 * Hi * Wi || res || up || gn_part)
+            return FPC_EINVAL;
+        c.Kwp = 8; c.K = 4 * 7 * 8; c.Kpad = 224;
+        FPC_TRY(launch_pack_weight_bf3(w_oihw, packed, Cout, Cin, Cin, Kh, Kw, c.Kwp, c.Npad, c.Kpad, s));
+        fpc_net tmp0;
+        tmp0.B = B; tmp0.ws = packed; tmp0.splitk_off = lay.packed;
+        ConvArgs a0;
+        fill_conv_args(&tmp0, a0, c, p, Hi, Wi, Ho, Wo, sb, sh, sw, sc, relu != 0, 0);
+        a0.Cin = 8 * c.Cinp; a0.Kw = 1; a0.K = c.K; a0.lanepx = 1;
+        a0.p[0] = ConvPtrs{in, packed, out, scale, shift, nullptr, nullptr, nullptr};
+        return launch_conv_plan(a0, p, 1, s);
+    }
     if (!wino) FPC_TRY(launch_pack_weight(w_oihw, packed, Cout, Cin, Cin, Kh, Kw, Kw, c.Npad, c.Kpad, s));
     if (!wino && p.bf3) FPC_TRY(launch_pack_weight_bf3(w_oihw, packed, Cout, Cin, Cin, Kh, Kw, Kw, c.Npad, c.Kpad, s));
     int mode = (sc == 1 && Cin % kConvBK == 0 && Kh * Kw <= 32 && ((int64_t)Hi + 2 * pad) * sh * 4 < ((int64_t)1 << 31)) ? 0

@@ -51,6 +51,18 @@ struct LatArgs {
 };
 int launch_lateral1x1(const LatArgs& a, hipStream_t s);
 
+// the 7x7 / stride-2 / pad-3 stem on the NHWC4 image as a weight-resident product (stem.hip)
+struct StemArgs {
+    const float* in;             // [B][Hi][Wi][4] f32 (4th channel 0), contiguous
+    const unsigned short* wpl;   // k_pack_weight_bf3's planes [3][Npad][Kpad = 224], k = (kh * 8 + tap) * 4 + channel
+    float* out;                  // [B][Ho][Wo][Cout = 64]
+    const float* scale;          // folded BatchNorm, or null
+    const float* shift;
+    int B, Hi, Wi, Ho, Wo, Cout, Npad, Kpad, relu;
+    int grid;                    // persistent workgroups (0: one per CU of an MI355X)
+};
+int launch_stem7x7(const StemArgs& a, hipStream_t s);
+
 constexpr int kMaxGnSites = 4;    // segmentation sites finalized by one launch (x kMaxGroup decoders each)
 struct GnFinArgs {
     const float* gn_part[kMaxGnSites * kMaxGroup];   // [site * kMaxGroup + decoder]: [B][P][C][2]

@@ -134,6 +134,9 @@ CONV_CASES = [
     (1, 128, 30, 40, 256, 1, 1, 0, (0, 0, 2008), "bias"),         # one weight tile per workgroup, no top-down addend
     (3, 64, 10, 14, 96, 1, 1, 0, (0, 0, 2003), "bias_relu"),      # 140 pixels: waves 1-3 of the second tile partly / fully empty; Cout = 96
     (1, 64, 6, 8, 32, 1, 1, 0, (0, 0, 2001), "none"),             # no bias: accumulation starts from zero
+    # weight-resident 7x7 / s2 stem, k_stem7x7 (nsplit = 3000): NHWC4 image (4th channel 0), output rows of 64-pixel segments
+    (2, 4, 96, 128, 64, 7, 2, 3, (0, 0, 3000), "stem4"),          # 48 x 64 outputs: every border case of a row / column
+    (3, 4, 40, 256, 64, 7, 2, 3, (0, 0, 3000), "stem4"),          # two segments per row, more tiles than waves of one workgroup
     # 8-wave form (8x8 tile patch per workgroup, nsplit = -2)
     (1, 64, 30, 40, 64, 3, 1, 1, (0, 0, -2), "bn_relu_res"),
     (2, 256, 15, 20, 128, 3, 1, 1, (0, 0, -2), "gn"),
@@ -160,9 +163,12 @@ def test_conv2d_vs_float64(lib, dev, case):
         kw["up"] = torch.randn((B, Cout, Ho // 2, Wo // 2), generator=g)
     if "relu" in extra or extra == "stem":
         kw["relu"] = True
-    if extra == "stem":
+    if extra in ("stem", "stem4"):
         kw["scale"] = torch.rand(Cout, generator=g) + 0.5
         kw["shift"] = torch.randn(Cout, generator=g)
+    if extra == "stem4":
+        x[:, 3] = 0.0                                              # the engine's NHWC4 image: the fourth channel is zero
+        kw["relu"] = True
     out, gpart, plan = _conv2d(dev, x, w, stride, pad, gn=("gn" in extra), bm=bm, bn=bn, nsplit=ns,
                                nchw_input=(extra == "stem"), **kw)
     ref = _ref_conv(x, w, stride, pad, **kw)
