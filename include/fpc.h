@@ -379,7 +379,10 @@ int fpc_net_tensor(const fpc_net_t* net, const char* name, const float** ptr, in
 /* Stand-alone convolution on the engine's implicit-GEMM kernel (tests / micro-benchmarks).
  * in: any element strides (sb, sh, sw, sc); w_oihw torch layout; out NHWC [B,Ho,Wo,Cout];
  * optional per-channel scale / shift, residual (as out), nearest-x2 `up` [B,Ho/2,Wo/2,Cout], ReLU,
- * GroupNorm partials gn_part [B][P32][Cout][2]; bm/bn/nsplit = 0 -> chosen by the planner. */
+ * GroupNorm partials gn_part [B][P32][Cout][2]; bm/bn/nsplit = 0 -> chosen by the planner.
+ * `nsplit` also selects the engine's other kernels for tests: -1..-5 Winograd forms (-5 split precision), 100 + k split-K
+ * summed by a second launch, 1000 + k split-precision (bf16 x 3) products, 2000 + parts the pixel-resident FPN lateral
+ * product (1x1, Cin 64 / 128, bias + `up` epilogue), 3000 the weight-resident 7x7 / s2 stem (Cin = 4: NHWC4 image). */
 size_t fpc_conv2d_workspace_bytes(int B, int Ho, int Wo, int Cin, int Cout, int Kh, int Kw);
 /* the exact need of one request (same bm / bn / nsplit as the fpc_conv2d call): <= the bound above, which reserves 32
  * split-K slices of the whole output; fpc_conv2d accepts either size */
