@@ -829,7 +829,12 @@ __device__ __forceinline__ void load_affine4(const float* aff, float4& sa, float
     sb = make_float4(u.y, u.w, v.y, v.w);
 }
 
-// GN + ReLU + x2 bilinear upsample (Conv3x3GNReLU with upsample=True), grid-stride, grid.y = job * kMaxGroup + group
+// GN + ReLU + x2 bilinear upsample (Conv3x3GNReLU with upsample=True), grid-stride, grid.y = job * kMaxGroup + group.
+// A thread = one 2 x 2 output block x one channel quad (round 5; one output pixel before): the block's taps lie in a 3 x 3
+// neighbourhood of the input (the align_corners scale is < 1/2), so 9 loads and GroupNorm + ReLU evaluations serve four
+// outputs instead of 16, and the index arithmetic is 32-bit (the per-pixel form divided 64-bit indices three times per
+// element).  Every output is the per-pixel expression on the same four operands, selected from the neighbourhood (as in
+// k_merge_head): bit-identical.
 __global__ __launch_bounds__(256) void k_gn_relu_up2(const GnUpArgs a) {
     const int z = blockIdx.y;
     const float* in = a.in[z];
@@ -838,22 +843,46 @@ __global__ __launch_bounds__(256) void k_gn_relu_up2(const GnUpArgs a) {
     const int job = z / kMaxGroup;
     const int ah = a.h[job], aw = a.w[job];
     const int C4 = a.C >> 2, H2 = 2 * ah, W2 = 2 * aw;
-    long long total = (long long)a.B * H2 * W2 * C4;
-    for (long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (long long)gridDim.x * blockDim.x) {
-        int c4 = (int)(g % C4);
-        long long r = g / C4;
-        int x = (int)(r % W2); r /= W2;
-        int y = (int)(r % H2);
-        int b = (int)(r / H2);
-        Lerp ly = lerp_coord(y, ah, H2), lx = lerp_coord(x, aw, W2);
-        float4 sa, sb;
-        load_affine4(aff + ((size_t)b * a.C + 4 * c4) * 2, sa, sb);
+    const float sy = H2 > 1 ? (float)(ah - 1) / (float)(H2 - 1) : 0.f, sx = W2 > 1 ? (float)(aw - 1) / (float)(W2 - 1) : 0.f;
+    const unsigned total = (unsigned)a.B * ah * aw * C4;      // < 2^32: launch_gn_relu_up2
+    for (unsigned g = blockIdx.x * blockDim.x + threadIdx.x; g < total; g += gridDim.x * blockDim.x) {
+        const unsigned c4 = g % C4;
+        unsigned r = g / C4;
+        const int bx = (int)(r % aw); r /= aw;
+        const int by = (int)(r % ah);
+        const int b = (int)(r / ah);
+        const int Y = 2 * by, X = 2 * bx;
+        const Lerp lya = lerp_scaled(Y, ah, sy), lyb = lerp_scaled(Y + 1, ah, sy);
+        const Lerp lxa = lerp_scaled(X, aw, sx), lxb = lerp_scaled(X + 1, aw, sx);
+        const int rb = lya.i0, cb = lxa.i0;
+        const bool sy1 = lyb.i0 != rb, sx1 = lxb.i0 != cb;  // the second row / column's first tap is the next one
+        const int rr[3] = {rb, min(rb + 1, ah - 1), min(rb + 2, ah - 1)}, cc[3] = {cb, min(cb + 1, aw - 1), min(cb + 2, aw - 1)};
+        float4 sa4, sb4;
+        load_affine4(aff + ((size_t)b * a.C + 4 * c4) * 2, sa4, sb4);
+        const f32x4 sa = {sa4.x, sa4.y, sa4.z, sa4.w}, sb = {sb4.x, sb4.y, sb4.z, sb4.w};      // native vectors: float4 structs selected by ?: land in scratch
         const float* base = in + (size_t)b * ah * aw * a.C + 4 * c4;
-        float4 v00 = gn_relu4(base + ((size_t)ly.i0 * aw + lx.i0) * a.C, sa, sb);
-        float4 v01 = gn_relu4(base + ((size_t)ly.i0 * aw + lx.i1) * a.C, sa, sb);
-        float4 v10 = gn_relu4(base + ((size_t)ly.i1 * aw + lx.i0) * a.C, sa, sb);
-        float4 v11 = gn_relu4(base + ((size_t)ly.i1 * aw + lx.i1) * a.C, sa, sb);
-        *reinterpret_cast<float4*>(out + (size_t)g * 4) = bilerp4(v00, v01, v10, v11, ly, lx);
+        auto gnr = [&](int i, int j) {
+            f32x4 v = *reinterpret_cast<const f32x4*>(base + ((size_t)rr[i] * aw + cc[j]) * a.C) * sa + sb;
+            v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f);
+            return v;
+        };
+        const f32x4 t00 = gnr(0, 0), t01 = gnr(0, 1), t02 = gnr(0, 2), t10 = gnr(1, 0), t11 = gnr(1, 1), t12 = gnr(1, 2),
+                    t20 = gnr(2, 0), t21 = gnr(2, 1), t22 = gnr(2, 2);
+        float* o = out + (((size_t)b * H2 + Y) * W2 + X) * a.C + 4 * c4;
+#pragma unroll
+        for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+            for (int dx = 0; dx < 2; ++dx) {
+                const Lerp ly = dy ? lyb : lya, lx = dx ? lxb : lxa;
+                const bool sr = dy && sy1, sc = dx && sx1;
+                // rows (r0, r0 + 1) and columns (c0, c0 + 1) of the neighbourhood
+                const f32x4 a0 = sr ? t10 : t00, a1 = sr ? t11 : t01, a2 = sr ? t12 : t02;      // upper tap row
+                const f32x4 b0 = sr ? t20 : t10, b1 = sr ? t21 : t11, b2 = sr ? t22 : t12;      // lower tap row
+                const f32x4 v00 = sc ? a1 : a0, v01 = sc ? a2 : a1, v10 = sc ? b1 : b0, v11 = sc ? b2 : b1;
+                // bilerp4's expression, component-wise
+                const f32x4 res = ly.l0 * (lx.l0 * v00 + lx.l1 * v01) + ly.l1 * (lx.l0 * v10 + lx.l1 * v11);
+                *reinterpret_cast<f32x4*>(o + ((size_t)dy * W2 + dx) * a.C) = res;
+            }
     }
 }
 
@@ -1343,7 +1372,8 @@ int launch_gn_relu_up2(const GnUpArgs& a, int groups, hipStream_t s) {
     if (a.C % 4 != 0) return FPC_EINVAL;
     if (a.jobs < 1 || a.jobs > kMaxUpJobs || groups != kMaxGroup) return FPC_EINVAL;
     long long most = 0;
-    for (int j = 0; j < a.jobs; ++j) most = std::max(most, (long long)a.B * 4 * a.h[j] * a.w[j] * (a.C / 4));
+    for (int j = 0; j < a.jobs; ++j) most = std::max(most, (long long)a.B * a.h[j] * a.w[j] * (a.C / 4));      // 2 x 2 blocks x channel quads
+    if (most >= (1LL << 31)) return FPC_EINVAL;
     hipLaunchKernelGGL(k_gn_relu_up2, dim3(stream_grid(most), a.jobs * kMaxGroup), dim3(256), 0, s, a);
     return check_launch();
 }
