@@ -13,6 +13,7 @@
 // 1 x4-upsample + class-compression kernel.
 #include <math.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <initializer_list>
@@ -162,6 +163,8 @@ struct fpc_net {
     size_t gn_part_off[4][7], gn_aff_off[4][7];
     int gn_P[7];
     Act a_low[4];                 // low-res logits
+    Act a_lsum[4];                // two-pass merge + head: the head of the three upsampled branches' sum at their own resolution
+    int merge_split = -1;         // -1: two passes from batch 2 up (FPC_MERGE_SPLIT=0 / 1 overrides), 0: k_merge_head, 1: two passes
     size_t splitk_off = 0, splitk_floats = 0;
     int use_graph = 0;            // replay the frame-invariant launches as a HIP graph (fpc_net_set_graph)
     int split_precision = 0;      // autotuning may pick the bf16 x 3 form of a direct convolution (fpc_net_set_split_precision)
@@ -300,6 +303,7 @@ extern "C" int fpc_net_create(const char* encoder, int classes, int B, int H, in
         n->a_up[d][1] = n->alloc_act(fh[1], fw[1], 128);   // up2(s5.1)
         n->a_up[d][2] = n->alloc_act(fh[1], fw[1], 128);   // up2(s4.0)
         n->a_low[d] = n->alloc_act(fh[0], fw[0], n->dec[d].head_chp);
+        n->a_lsum[d] = n->alloc_act(fh[1], fw[1], n->dec[d].head_chp);
     }
 
     // ---- conv plans (+ split-K scratch for the worst candidate, GroupNorm partials for the largest P32)
@@ -703,10 +707,40 @@ static int forward_middle(fpc_net* n, hipStream_t s) {
     FPC_TRY(gn_finish({2}));
 
     // merge + head
-    {
+    const int lo[3] = {2, 4, 5};     // s5.2, s4.1, s3.0 (sum order of the reference: p5-, p4-, p3-, p2-branch)
+    int split = n->merge_split;
+    if (split < 0) {
+        const char* e = getenv("FPC_MERGE_SPLIT");
+        split = e ? (atoi(e) != 0) : (B >= 2);
+    }
+    if (split) {
+        // two passes (merge_split.hip): the head of (r5 + r4 + r3) at the branches' resolution, then the head of r2 + bias + its x2 upsample
+        HeadPartArgs hl, hh;
+        memset(&hl, 0, sizeof(hl));
+        memset(&hh, 0, sizeof(hh));
+        for (int d = 0; d < 4; ++d) {
+            for (int k = 0; k < 3; ++k) {
+                hl.t[d][k] = ws + n->a_seg[d][lo[k]].off;
+                hl.aff[d][k] = ws + n->gn_aff_off[d][lo[k]];
+            }
+            hh.t[d][0] = ws + n->a_seg[d][6].off;
+            hh.aff[d][0] = ws + n->gn_aff_off[d][6];
+            hl.hw[d] = hh.hw[d] = n->pptr[n->dec[d].p_head_w];
+            hl.hb[d] = hh.hb[d] = n->pptr[n->dec[d].p_head_b];
+            hl.out[d] = ws + n->a_lsum[d].off;
+            hh.lsum[d] = ws + n->a_lsum[d].off;
+            hh.out[d] = ws + n->a_low[d].off;
+            hl.ch[d] = hh.ch[d] = n->dec[d].head_ch;
+            hl.chp[d] = hh.chp[d] = n->dec[d].head_chp;
+        }
+        hl.B = hh.B = B; hl.C = hh.C = 128;
+        hl.H = n->a_seg[0][2].H; hl.W = n->a_seg[0][2].W; hl.hl = hl.H; hl.wl = hl.W;
+        hh.H = n->a_seg[0][6].H; hh.W = n->a_seg[0][6].W; hh.hl = hl.H; hh.wl = hl.W;
+        FPC_TRY(launch_head_part(hl, false, 4, s));
+        FPC_TRY(launch_head_part(hh, true, 4, s));
+    } else {
         MergeHeadArgs m;
         memset(&m, 0, sizeof(m));
-        const int lo[3] = {2, 4, 5};     // s5.2, s4.1, s3.0 (sum order of the reference: p5-, p4-, p3-, p2-branch)
         for (int d = 0; d < 4; ++d) {
             for (int k = 0; k < 3; ++k) {
                 m.t_lo[d][k] = ws + n->a_seg[d][lo[k]].off;

@@ -97,6 +97,20 @@ struct MergeHeadArgs {
     int B, h, w, C;
 };
 
+// the merge + head in two passes (merge_split.hip): LOW sums the three upsampled branches at their own resolution and applies the
+// head; HI applies it to the p2 branch and adds bias + the x2 upsample of LOW's result
+struct HeadPartArgs {
+    const float* t[kMaxGroup][3];      // pre-GroupNorm maps [B,H,W,C] of this pass (LOW: three, HI: one)
+    const float* aff[kMaxGroup][3];    // their affines [B][C][2]
+    const float* hw[kMaxGroup];        // head weight [Ch][C]
+    const float* hb[kMaxGroup];        // head bias [Ch] (HI)
+    const float* lsum[kMaxGroup];      // HI: pass LOW's output [B,hl,wl,chp]
+    float* out[kMaxGroup];             // LOW: [B,H,W,chp] without bias; HI: the low-resolution logits NHWC [B,H,W,chp]
+    int ch[kMaxGroup], chp[kMaxGroup];
+    int B, H, W, C, hl, wl;
+};
+int launch_head_part(const HeadPartArgs& a, bool hi, int groups, hipStream_t s);
+
 struct Up4Args {
     const float* lm; const float* lq; const float* lt; const float* ls;   // low-res NHWC logits (mask, quat, xyz, scales)
     int pm, pq, pt, ps;                                                   // their channel strides
