@@ -1,4 +1,4 @@
-// merge_split.hip — the FPN merge + 1x1 head in two passes (round 5), for batches where k_merge_head's gather is the cost.
+// merge_split.hip — the FPN merge + 1x1 head in two passes (round 5); k_merge_head (one pass) stays selectable: FPC_MERGE_SPLIT=0.
 //
 // smp: merged = up2(r5) + up2(r4) + up2(r3) + r2 with r_k = relu(gn(t_k)) (the three upsampled branches share one resolution),
 // logits = bias + W merged (Dropout2d is the identity in eval mode; F/lib/pose_regressor.py:709-743, lib/backbone.py).  The head and
@@ -6,8 +6,8 @@
 //     logits = bias + up2( W (r5 + r4 + r3) ) + W r2 :
 // pass LOW sums the three branches at THEIR resolution and applies the head there (32 of 128 channels leave the kernel: 2.4 MB per
 // frame), pass HI applies the head to r2 and adds the x2 upsample of pass LOW's 32-channel result — 4 taps of 128 bytes per pixel
-// instead of 12 taps of 512 bytes, one GroupNorm + ReLU per tap value instead of four to sixteen.  k_merge_head (one pass: gather
-// of the 128-channel taps, then the head) stays the form for small batches.  The result differs from the one-pass form by
+// instead of 12 taps of 512 bytes, one GroupNorm + ReLU per tap value instead of four to sixteen (985 -> 572 us on 32 frames, 32.5 ->
+// 27 us on one).  The result differs from the one-pass form by
 // rounding only (a different association of the same sum: ~1e-7 of the logits; the engine's 1e-4 bar is unchanged).
 // Both passes: one workgroup = 32 pixels x 128 channels; GroupNorm + ReLU'd sum -> LDS; head on the f32 matrix cores (32 px x 32
 // ch tile, K split over the four waves, partials summed in wave order) as in k_merge_head.

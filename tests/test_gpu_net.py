@@ -650,6 +650,34 @@ def test_split_precision_error_is_at_the_plain_f32_level(lib, dev):
     assert errs[True] <= 2e-5, errs
 
 
+def test_two_pass_merge_head_equals_the_one_pass_form_to_rounding(lib, dev, monkeypatch):
+    """The engine applies the head in two passes (merge_split.hip: head of the three upsampled branches' sum at
+    their own resolution, then head of the p2 branch + bias + the x2 upsample of that) instead of k_merge_head's one pass over
+    the gathered 128-channel taps.  Same sum, another association: the logits agree to ~1e-6 of their scale, both forms meet
+    the float64 bar, and a ragged map (H2 W2 not a multiple of the 4 x 32-pixel workgroup) is covered."""
+    import copy
+    from fastposecnn_amd import synth
+    for (h, w) in ((96, 128), (160, 96)):
+        x = torch.stack([synth.make_image(i, h, w) for i in range(3)])
+        outs = {}
+        for split in ("0", "1"):
+            monkeypatch.setenv("FPC_MERGE_SPLIT", split)
+            m, hp = _model(lib, dev, "resnet18")
+            hp.ENGINE_GRAPH = False
+            if split == "0":
+                ref_m = copy.deepcopy(m).double()
+                ref_m.HPARAM = copy.copy(hp); ref_m.HPARAM.USE_NATIVE_ENGINE = False
+                with torch.no_grad():
+                    ref = ref_m.pure_model_forward(x.double())
+            with torch.no_grad():
+                outs[split] = {k: v.cpu().double() for k, v in m.to(dev)(x.to(dev))["logits"].items()}
+        for k in ("mask", "quaternion", "scales", "xy", "z"):
+            scale = max(1.0, ref[k].abs().max().item())
+            assert (outs["0"][k] - outs["1"][k]).abs().max().item() <= 2e-6 * scale, k
+            for split in ("0", "1"):
+                assert (outs[split][k] - ref[k]).abs().max().item() <= 1e-4 * scale, (k, split)
+
+
 def test_frame_streamer_coalescing_returns_each_frames_own_result(lib, dev):
     """FrameStreamer(coalesce=2): consecutive single frames run as one batch-2 engine launch + one batched post-network
     enqueue; every ticket still yields ITS frame's forward() dict — logits / categorical equal to the frame's slice of the
