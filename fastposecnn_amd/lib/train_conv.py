@@ -64,6 +64,8 @@ def conv_nhwc(x, w, bias, stride, pad, up=None):
             cands += [-1, -2, -4]       # Winograd F(2x2,3x3): 4 waves, 8 waves, 8 waves all-DMA
             if SPLIT_PRECISION:
                 cands.append(-5)        # 8 waves, split-precision products
+        if SPLIT_PRECISION and Kh == 1 and Kw == 1 and stride == 1 and pad == 0 and Cin in (64, 128) and Cout % 32 == 0:
+            cands += [2000 + p for p in (1, 2, 4) if (Cout // 32) % p == 0]      # pixel-resident lateral product (lateral.hip)
         best = (float("inf"), 0)
         ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
         for c in cands:
