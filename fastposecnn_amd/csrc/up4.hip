@@ -12,8 +12,18 @@ namespace fpc {
 // k_up4_compress7 (the taps are SELECTED from the three columns, never re-weighted): results are bit-identical.
 __global__ __launch_bounds__(128, 3) void k_up4_compress7x4(const Up4Args a) {
     constexpr int C = 7, G = 6;
-    const int b = blockIdx.y, HW = a.H * a.W;
-    const int p0 = 4 * (blockIdx.x * blockDim.x + threadIdx.x);
+    const int HW = a.H * a.W;
+    // XCD-aware block order.  Workgroups go to the 8 XCDs round-robin by linear id, and every output pixel reads ~100 bytes of
+    // low-resolution taps: in plain order each XCD's L2 (4 MB) saw ALL rows of every frame's low-resolution logits (5.5 MB per
+    // frame) and re-fetched them through the fabric — about 1.4 GB of reads beside 3.1 GB of writes per 32-frame batch.  When the
+    // blocks of a frame divide by 8, XCD x takes the x-th eighth of the frame's rows (0.7 MB of taps): id -> (xcd = id % 8, rest).
+    int b = blockIdx.y, blk = blockIdx.x;
+    if ((gridDim.x & 7) == 0) {
+        const unsigned id = blockIdx.x + gridDim.x * blockIdx.y, per = gridDim.x >> 3, j = id >> 3;
+        b = (int)(j / per);
+        blk = (int)((id & 7) * per + (j - (unsigned)b * per));
+    }
+    const int p0 = 4 * (blk * blockDim.x + threadIdx.x);
     if (p0 >= HW) return;                                   // whole waves only: HW % 256 == 0 (launcher)
     const int y = p0 / a.W, x0 = p0 - y * a.W;
     const Lerp ly = lerp_coord(y, a.hl, a.H);
