@@ -29,7 +29,11 @@ __global__ __launch_bounds__(256, 2) void k_lateral1x1(const LatArgs a) {
     __shared__ __attribute__((aligned(16))) unsigned char s_w[2][3 * TILEB];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, col = lane & 31, h = lane >> 5;
     const int HW = a.Ho * a.Wo, mt = (HW + 127) >> 7;
+    // XCD-aware tile order: workgroups go to the 8 XCDs round-robin by id; with the grid a multiple of 8, XCD x = id % 8 takes the
+    // x-th contiguous eighth of the (image, pixel tile, part) list, so the input pixels and the top-down rows two pixel rows share
+    // are fetched by one L2 instead of two to eight
     int bid = blockIdx.x;
+    if ((gridDim.x & 7) == 0) bid = (int)((blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3));
     const int part = bid % a.parts;
     bid /= a.parts;
     const int m = bid % mt, b = bid / mt;

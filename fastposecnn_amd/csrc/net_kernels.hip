@@ -741,13 +741,25 @@ __global__ __launch_bounds__(256) void k_conv_splitk_epilogue(const ConvArgs a) 
 // ------------------------------------------------------------------------------------------
 // max pooling 3x3 stride 2 pad 1, NHWC, one float4 of channels per thread
 
+// XCD-banded grid-stride walk of `total` items in row order (round 5).  Workgroups go to the 8 XCDs round-robin by linear id; a
+// kernel whose items read NEIGHBOURING input rows (pooling windows, bilinear taps) then makes every XCD's L2 fetch every input
+// row.  With a grid that is a multiple of 8, XCD x = blockIdx.x % 8 walks the x-th contiguous eighth of the items with its own
+// blocks, so an input row is fetched by one L2 (two at a band border).  lo / hi / step in items; 32-bit (launchers check).
+struct XcdWalk { unsigned first, end, step; };
+__device__ __forceinline__ XcdWalk xcd_walk(unsigned total) {
+    if ((gridDim.x & 7) != 0) return XcdWalk{blockIdx.x * blockDim.x + threadIdx.x, total, gridDim.x * blockDim.x};
+    const unsigned per = (total + 7) >> 3, xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const unsigned lo = xcd * per, hi = min(lo + per, total);
+    return XcdWalk{lo + slot * blockDim.x + threadIdx.x, hi, (gridDim.x >> 3) * blockDim.x};
+}
+
 __global__ __launch_bounds__(256) void k_maxpool3x3s2(const float* __restrict__ in, float* __restrict__ out, int B,
                                                       int Hi, int Wi, int C, int Ho, int Wo) {
-    int C4 = C >> 2;
-    long long total = (long long)B * Ho * Wo * C4;
-    for (long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (long long)gridDim.x * blockDim.x) {
+    const unsigned C4 = C >> 2;
+    const XcdWalk wk = xcd_walk((unsigned)B * Ho * Wo * C4);      // < 2^32: launch_maxpool3x3s2
+    for (unsigned g = wk.first; g < wk.end; g += wk.step) {
         int c4 = (int)(g % C4);
-        long long r = g / C4;
+        unsigned r = g / C4;
         int wo = (int)(r % Wo); r /= Wo;
         int ho = (int)(r % Ho);
         int b = (int)(r / Ho);
@@ -844,8 +856,8 @@ __global__ __launch_bounds__(256) void k_gn_relu_up2(const GnUpArgs a) {
     const int ah = a.h[job], aw = a.w[job];
     const int C4 = a.C >> 2, H2 = 2 * ah, W2 = 2 * aw;
     const float sy = H2 > 1 ? (float)(ah - 1) / (float)(H2 - 1) : 0.f, sx = W2 > 1 ? (float)(aw - 1) / (float)(W2 - 1) : 0.f;
-    const unsigned total = (unsigned)a.B * ah * aw * C4;      // < 2^32: launch_gn_relu_up2
-    for (unsigned g = blockIdx.x * blockDim.x + threadIdx.x; g < total; g += gridDim.x * blockDim.x) {
+    const XcdWalk wk = xcd_walk((unsigned)a.B * ah * aw * C4);      // < 2^32: launch_gn_relu_up2; an XCD walks a band of rows
+    for (unsigned g = wk.first; g < wk.end; g += wk.step) {
         const unsigned c4 = g % C4;
         unsigned r = g / C4;
         const int bx = (int)(r % aw); r /= aw;
@@ -1351,11 +1363,12 @@ int launch_conv_splitk_epilogue(const ConvArgs& a, int groups, hipStream_t s) {
 
 static int stream_grid(long long work_items) {
     long long g = (work_items + 255) / 256;
-    return (int)(g < 1 ? 1 : (g > 4096 ? 4096 : g));
+    g = g < 1 ? 1 : (g > 4096 ? 4096 : g);
+    return (int)(g >= 8 ? (g + 7) / 8 * 8 : g);      // a multiple of 8: the XCD-banded walks (xcd_walk) need it, the others do not mind
 }
 
 int launch_maxpool3x3s2(const float* in, float* out, int B, int Hi, int Wi, int C, int Ho, int Wo, hipStream_t s) {
-    if (C % 4 != 0) return FPC_EINVAL;
+    if (C % 4 != 0 || (long long)B * Ho * Wo * (C / 4) >= (1LL << 32)) return FPC_EINVAL;
     hipLaunchKernelGGL(k_maxpool3x3s2, dim3(stream_grid((long long)B * Ho * Wo * (C / 4))), dim3(256), 0, s, in, out, B,
                        Hi, Wi, C, Ho, Wo);
     return check_launch();
