@@ -43,7 +43,15 @@ __global__ __launch_bounds__(512, 1) void k_stem7x7(const StemArgs a) {
 
     const int segs = a.Wo >> 6;                     // 64-pixel segments per output row
     const int ntile = a.B * a.Ho * segs;            // < 2^31: launch_stem7x7
-    for (int tile = blockIdx.x * 8 + wv; tile < ntile; tile += gridDim.x * 8) {
+    // XCD-banded walk: workgroups go to the 8 XCDs round-robin; with the grid a multiple of 8, XCD x = blockIdx.x % 8 walks the
+    // x-th contiguous eighth of the tiles (row segments in raster order), so the 3.5 output rows that share an input row are
+    // served by one L2
+    int t_first = blockIdx.x * 8 + wv, t_end = ntile, t_step = gridDim.x * 8;
+    if ((gridDim.x & 7) == 0) {
+        const int per = (ntile + 7) >> 3, lo = (blockIdx.x & 7) * per;
+        t_first = lo + (blockIdx.x >> 3) * 8 + wv; t_end = min(lo + per, ntile); t_step = (gridDim.x >> 3) * 8;
+    }
+    for (int tile = t_first; tile < t_end; tile += t_step) {
         const int t2 = tile / segs, seg = tile - t2 * segs;
         const int b = t2 / a.Ho, oy = t2 - b * a.Ho;
         const int ox0 = seg * 64;
