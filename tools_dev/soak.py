@@ -44,13 +44,15 @@ dev = torch.device("cuda:0")
 hp = config.INFERENCE(); hp.RUNTIME_TIMING = False
 hp.ENGINE_SPLIT_PRECISION = bool(int(os.environ.get("FPC_SPLIT_PRECISION", "1")))
 hp.ENGINE_GRAPH = bool(int(os.environ.get("FPC_ENGINE_GRAPH", "1")))
+hp.ENCODER = os.environ.get("SOAK_ENCODER", hp.ENCODER)        # SOAK_ENCODER=resnet34 SOAK_BATCH=32: BASELINE config 3
+BATCH = int(os.environ.get("SOAK_BATCH", "1"))
 torch.manual_seed(0)
 model = L.pose_regressor.MODELS[hp.MODEL].load_from_ckpt(None, hp).eval().to(dev)
 K = 3
-xs = [synth.make_image(i)[None].to(dev) for i in range(K)]
+xs = [torch.stack([synth.make_image(i * BATCH + j) for j in range(BATCH)]).to(dev) for i in range(K)]
 cats = []
 for i in range(K):
-    c, _ = synth.make_vote_batch(range(i, i + 1))
+    c, _ = synth.make_vote_batch(range(i * BATCH, (i + 1) * BATCH))
     cats.append({k: v.to(dev) for k, v in c.items()})
     if not os.environ.get("SOAK_NO_FG_BITS"):      # as the class compression hands the mask over: with its foreground bit words
         import aggregation_layer as _al3
