@@ -203,15 +203,37 @@ constexpr int kLdsRow = kConvBK;
 // Epilogue of one lane's 4 rows (p0 + 8k) x 4 channels (n .. n+3) of a 32-row tile: folded BatchNorm / bias, residual,
 // FPN nearest-x2 add, ReLU, store, and the GroupNorm partial sums of the tile's 32 rows per channel.
 struct EpiGeom { int b, HoWo, Wo, Cout, Hu, Wu, P32, relu, lane; };
-__device__ __forceinline__ void conv_epilogue(const ConvPtrs& P, const EpiGeom& g, f32x4 v0, f32x4 v1, f32x4 v2, f32x4 v3, int p0, int n) {
+// The epilogue's own global reads of one lane's 4 rows x 4 channels (Cout % 4 == 0): scale / shift, residual, top-down addend.
+// k_conv_igemm requests them BEFORE a tile's LDS transpose (round 5): issued inside conv_epilogue they sat behind the transpose's
+// s_waitcnt (a memory clobber the compiler cannot move loads across), one exposed L2 round trip per 32 x 32 tile.  Absent
+// operands come back as 1 / 0, so the epilogue uses them unconditionally.
+struct EpiPre { f32x4 sc, sh, res[4], up[4]; };
+__device__ __forceinline__ void conv_epilogue_prefetch(EpiPre& e, const ConvPtrs& P, const EpiGeom& g, int p0, int n) {
+    e.sc = f32x4{1.f, 1.f, 1.f, 1.f}; e.sh = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { e.res[k] = f32x4{0.f, 0.f, 0.f, 0.f}; e.up[k] = e.res[k]; }
+    if ((g.Cout & 3) != 0 || n >= g.Cout) return;
+    if (P.scale) e.sc = *reinterpret_cast<const f32x4*>(P.scale + n);
+    if (P.shift) e.sh = *reinterpret_cast<const f32x4*>(P.shift + n);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int p = p0 + 8 * k;
+        if (p >= g.HoWo) continue;
+        if (P.res) e.res[k] = *reinterpret_cast<const f32x4*>(P.res + ((size_t)g.b * g.HoWo + p) * g.Cout + n);
+        if (P.up) {
+            const int ho = p / g.Wo, wo = p - ho * g.Wo;
+            e.up[k] = *reinterpret_cast<const f32x4*>(P.up + (((size_t)g.b * g.Hu + (ho >> 1)) * g.Wu + (wo >> 1)) * g.Cout + n);
+        }
+    }
+}
+__device__ __forceinline__ void conv_epilogue(const ConvPtrs& P, const EpiGeom& g, f32x4 v0, f32x4 v1, f32x4 v2, f32x4 v3, int p0, int n,
+                                              const EpiPre& pre) {
     const int b = g.b, HoWo = g.HoWo, Wo = g.Wo, Cout = g.Cout, Hu = g.Hu, Wu = g.Wu;
     const f32x4 v[4] = {v0, v1, v2, v3};
     f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};
     if ((Cout & 3) == 0) {
         const bool nv = n < Cout;
-        f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
-        if (nv && P.scale) sc = *reinterpret_cast<const f32x4*>(P.scale + n);
-        if (nv && P.shift) sh = *reinterpret_cast<const f32x4*>(P.shift + n);
+        const f32x4 sc = pre.sc, sh = pre.sh;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             int p = p0 + 8 * k;
@@ -220,11 +242,8 @@ __device__ __forceinline__ void conv_epilogue(const ConvPtrs& P, const EpiGeom& 
             if (P.scale) x = x * sc;
             x = x + sh;
             size_t o = ((size_t)b * HoWo + p) * Cout + n;
-            if (P.res) x += *reinterpret_cast<const f32x4*>(P.res + o);
-            if (P.up) {
-                int ho = p / Wo, wo = p - ho * Wo;
-                x += *reinterpret_cast<const f32x4*>(P.up + (((size_t)b * Hu + (ho >> 1)) * Wu + (wo >> 1)) * Cout + n);
-            }
+            if (P.res) x += pre.res[k];
+            if (P.up) x += pre.up[k];
             if (g.relu) { x[0] = fmaxf(x[0], 0.f); x[1] = fmaxf(x[1], 0.f); x[2] = fmaxf(x[2], 0.f); x[3] = fmaxf(x[3], 0.f); }
             *reinterpret_cast<f32x4*>(P.out + o) = x;
             s1 += x;
@@ -603,6 +622,9 @@ __global__ __launch_bounds__(256, (BM * BN >= 128 * 128) ? 1 : 2) void k_conv_ig
     for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
+            // (this tile's epilogue operands are requested first: they land while the tile goes through the LDS patch)
+            EpiPre pre;
+            if (!ws) conv_epilogue_prefetch(pre, P, eg, m0 + wm * (BM / 2) + i * 32 + trow, n0 + wn * (BN / 2) + j * 32 + tc4);
 #pragma unroll
             for (int r = 0; r < 16; ++r) tp[((r & 3) + 8 * (r >> 2) + 4 * lh) * kTS + li] = acc[i][j][r];
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // same wave: LDS ops complete in order
@@ -623,7 +645,7 @@ __global__ __launch_bounds__(256, (BM * BN >= 128 * 128) ? 1 : 2) void k_conv_ig
                 }
                 continue;
             }
-            conv_epilogue(P, eg, v[0], v[1], v[2], v[3], prow + trow, n);
+            conv_epilogue(P, eg, v[0], v[1], v[2], v[3], prow + trow, n, pre);
         }
     // Fused split-K: every workgroup has written its raw partial tile through to memory; it drains, and takes a ticket
     // of its output tile.  The one that draws the last ticket sums ALL partials in split order (its own included: the
@@ -645,6 +667,8 @@ __global__ __launch_bounds__(256, (BM * BN >= 128 * 128) ? 1 : 2) void k_conv_ig
                 const int prow = m0 + wm * (BM / 2) + i * 32;
                 const int n = n0 + wn * (BN / 2) + j * 32 + tc4;
                 const float* src = ws0 + (size_t)(prow + trow) * Npad + n;
+                EpiPre pre;
+                conv_epilogue_prefetch(pre, P, eg, prow + trow, n);      // beside the partial sums' loads
                 f32x4 v[4];
 #pragma unroll
                 for (int k = 0; k < 4; ++k) v[k] = load_wt128(src + (size_t)(8 * k) * Npad);
@@ -656,7 +680,7 @@ __global__ __launch_bounds__(256, (BM * BN >= 128 * 128) ? 1 : 2) void k_conv_ig
 #pragma unroll
                     for (int k = 0; k < 4; ++k) v[k] += u[k];
                 }
-                conv_epilogue(P, eg, v[0], v[1], v[2], v[3], prow + trow, n);
+                conv_epilogue(P, eg, v[0], v[1], v[2], v[3], prow + trow, n, pre);
             }
         }
     }
