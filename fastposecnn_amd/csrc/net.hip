@@ -977,7 +977,8 @@ extern "C" int fpc_conv2d(const float* in, int64_t sb, int64_t sh, int64_t sw, i
         a0.p[0] = ConvPtrs{in, packed, out, scale, shift, nullptr, nullptr, nullptr};
         return launch_conv_plan(a0, p, 1, s);
     }
-    if (!wino) FPC_TRY(launch_pack_weight(w_oihw, packed, Cout, Cin, Cin, Kh, Kw, Kw, c.Npad, c.Kpad, s));
+    // (the split-precision forms — bf16 x 3 tiles, k_lateral1x1 — read only the planes behind the f32 image: it is not packed for them)
+    if (!wino && !p.bf3) FPC_TRY(launch_pack_weight(w_oihw, packed, Cout, Cin, Cin, Kh, Kw, Kw, c.Npad, c.Kpad, s));
     if (!wino && p.bf3) FPC_TRY(launch_pack_weight_bf3(w_oihw, packed, Cout, Cin, Cin, Kh, Kw, Kw, c.Npad, c.Kpad, s));
     int mode = (sc == 1 && Cin % kConvBK == 0 && Kh * Kw <= 32 && ((int64_t)Hi + 2 * pad) * sh * 4 < ((int64_t)1 << 31)) ? 0
                : (sc == 1 && Cin % 4 == 0 && sw % 4 == 0 && sh % 4 == 0 && sb % 4 == 0 && ((uintptr_t)in & 15) == 0) ? 2 : 1;
@@ -1004,7 +1005,8 @@ extern "C" int fpc_conv2d(const float* in, int64_t sb, int64_t sh, int64_t sw, i
             sh != (int64_t)Wi * Cin || sb != (int64_t)Hi * Wi * Cin)
             return FPC_EINVAL;
         float* wp = packed + lay.packed + lay.splitk;
-        FPC_TRY(launch_wino_pack(w_oihw, wp, Cout, Cin, s));
+        // (the split-precision form reads only its own image: the f32 image is not packed for it — 78 launches of a training step)
+        if (nsplit != -5) FPC_TRY(launch_wino_pack(w_oihw, wp, Cout, Cin, s));
         if (nsplit == -5) FPC_TRY(launch_wino_pack_bf3(w_oihw, wp + (size_t)16 * Cout * Cin, Cout, Cin, s));
         a.wino_w[0] = wp;
         float* zp = wp + lay.wino - 64;
