@@ -1009,9 +1009,12 @@ extern "C" int fpc_conv2d(const float* in, int64_t sb, int64_t sh, int64_t sw, i
         if (nsplit != -5) FPC_TRY(launch_wino_pack(w_oihw, wp, Cout, Cin, s));
         if (nsplit == -5) FPC_TRY(launch_wino_pack_bf3(w_oihw, wp + (size_t)16 * Cout * Cin, Cout, Cin, s));
         a.wino_w[0] = wp;
-        float* zp = wp + lay.wino - 64;
-        if (hipMemsetAsync(zp, 0, 64 * sizeof(float), s) != hipSuccess) return FPC_ELAUNCH;
-        a.zeros = zp;
+        a.zeros = zero_page();       // (the workspace's last 64 floats stay reserved for it: fpc_conv2d_workspace_bytes is unchanged)
+        if (!a.zeros) {
+            float* zp = wp + lay.wino - 64;
+            if (hipMemsetAsync(zp, 0, 64 * sizeof(float), s) != hipSuccess) return FPC_ELAUNCH;
+            a.zeros = zp;
+        }
         p.wino = -nsplit;
         return launch_conv_plan(a, p, 1, s);
     }

@@ -2256,6 +2256,14 @@ __global__ __launch_bounds__(256) void k_wino_pack_bf3(const float* __restrict__
     }
 }
 
+// 256 bytes of zeros that live in the code object (zero-initialised at load, never written): the zero page of the all-DMA and
+// split-precision Winograd forms for callers that have no plan workspace (fpc_conv2d: one memset per call before)
+__device__ __attribute__((aligned(256))) float g_fpc_zero_page[64];
+const float* zero_page() {      // looked up per call: the address belongs to the CURRENT device
+    void* q = nullptr;
+    return hipGetSymbolAddress(&q, HIP_SYMBOL(g_fpc_zero_page)) == hipSuccess ? static_cast<const float*>(q) : nullptr;
+}
+
 int launch_conv_wino(const WinoArgs& a, int groups, hipStream_t s) {
     if (groups < 1 || groups > kMaxGroup || a.Cin % 8 != 0 || a.Cout % kWinoBN != 0 || (a.waves != 4 && a.waves != 8))
         return FPC_EINVAL;

@@ -132,6 +132,7 @@ struct WinoArgs {
     int B, H, W, Cin, Cout, relu, tbx, tby;   // tbx = ceil(ceil(W/2)/8), tby = ceil(ceil(H/2)/waves) tile patches
 };
 int launch_conv_wino(const WinoArgs& a, int groups, hipStream_t s);
+const float* zero_page();      // 64 zero floats in the code object (per device context), or null
 int launch_wino_pack(const float* w_oihw, float* packed, int Cout, int Cin, hipStream_t s);
 int launch_wino_pack_bf3(const float* w_oihw, float* packed, int Cout, int Cin, hipStream_t s);
 int launch_conv(const ConvArgs& a, int groups, hipStream_t s);
