@@ -134,23 +134,60 @@ def launch_ranks(n, argv):
     return rc
 
 
-def pin_rank_to_cores(local_rank, local_world):
-    """Give this rank its own contiguous share of the host cores (before anything touches the GPU; no re-exec).  Eight
-    ranks x one enqueue thread at ~80 launches per frame plus their PNG / staging helpers otherwise migrate over all cores
-    and onto each other.  FPC_BENCH_NO_AFFINITY=1 leaves the launcher's mask alone.  Returns the cores kept (or None)."""
-    if local_world <= 1 or os.environ.get("FPC_BENCH_NO_AFFINITY") or not hasattr(os, "sched_setaffinity"):
-        return None
+def cpu_share():
+    """The CPUs this job may use: the smaller of the scheduler affinity mask and the cgroup's CPU bandwidth quota
+    (v2 `cpu.max`, v1 `cpu.cfs_quota_us / cpu.cfs_period_us`).  A GPU box reports 256 logical CPUs to `os.cpu_count()` while one
+    GPU's job owns 16 of them: thread pools sized by the former burn the quota in spin-waits and get the whole process
+    throttled."""
     try:
-        cores = sorted(os.sched_getaffinity(0))
-        per = len(cores) // local_world
-        if per < 1:
-            return None
-        mine = cores[local_rank * per:(local_rank + 1) * per]
-        os.sched_setaffinity(0, mine)
-        os.environ.setdefault("OMP_NUM_THREADS", str(max(1, min(per, 16))))
-        return mine
+        n = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        n = os.cpu_count() or 1
+    quota = None
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            q, period = f.read().split()[:2]
+            if q != "max":
+                quota = float(q) / float(period)
+    except (OSError, ValueError):
+        try:
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as f, open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as g:
+                q, period = float(f.read()), float(g.read())
+                if q > 0:
+                    quota = q / period
+        except (OSError, ValueError):
+            pass
+    if quota is not None:
+        n = min(n, max(1, int(quota + 0.999)))
+    return max(1, n)
+
+
+def pin_rank_to_cores(local_rank, local_world):
+    """Confine this rank to its share of the host cores (before torch starts its pools and before anything touches the GPU;
+    no re-exec).  N > 1: a contiguous block of the affinity mask per rank — eight ranks x one enqueue thread at ~80 launches
+    per frame plus their PNG / staging helpers otherwise migrate over all cores and onto each other.  N = 1 (round 6): the
+    affinity mask is left alone (other tenants of the host would pick the same block) and the THREAD COUNTS are confined
+    to `cpu_share()` — OMP_NUM_THREADS / MKL_NUM_THREADS before torch is imported, `torch.set_num_threads` in main().
+    FPC_BENCH_NO_AFFINITY=1 leaves everything alone.  Returns (cores kept or None, thread count to use)."""
+    if os.environ.get("FPC_BENCH_NO_AFFINITY") or not hasattr(os, "sched_setaffinity"):
+        return None, None
+    share = cpu_share()
+    try:
+        if local_world > 1:
+            cores = sorted(os.sched_getaffinity(0))
+            per = min(len(cores), share) // local_world
+            if per < 1:
+                return None, None
+            mine = cores[local_rank * per:(local_rank + 1) * per]
+            os.sched_setaffinity(0, mine)
+            nthr = max(1, min(per, 16))
+        else:
+            mine, nthr = None, share
+        for var in ("OMP_NUM_THREADS", "MKL_NUM_THREADS"):
+            os.environ.setdefault(var, str(nthr))
+        return mine, nthr
     except OSError:
-        return None
+        return None, None
 
 
 def multi_rank_fields(dist, torch, world, rank, dev, local_s, units_per_rank, backend, cores):
@@ -180,21 +217,24 @@ def median(xs):
 
 
 def cpu_baseline(model_cpu, image, cat_cpu, hn, inv_k, encoder):
-    """One frame on the host, three samples each: torch CPU backbone (+ class compression) on all cores, and the
-    oracle's C restatement of aggregation / voting / RT on 1 thread (the scalar port) and on all cores (OpenMP over the
-    hypotheses).  Bounded: ~10 s."""
+    """One frame on the host, three samples per leg (medians): torch CPU backbone (+ class compression) and the oracle's C
+    restatement of aggregation / voting / RT, each leg on 1 thread (the scalar port) AND on the job's CPU share
+    (`cpu_share()`: affinity mask and cgroup quota, whichever is smaller; the oracle's OpenMP loop over the hypotheses is
+    capped at FPCO_MAX_THREADS), the better of the two taken per leg — a baseline is the host's best.  `cores` is the
+    count the DOMINANT leg used.  Process-wide thread settings are left as they were found (round 5's version left
+    OpenMP on one thread: the second call timed a one-thread network under a "cores: 16" label).  Bounded: ~15 s."""
     import torch
     from oracle import oracle as orc
     orc.build()
-    threads = torch.get_num_threads()
-    net = []
-    with torch.no_grad():
-        for _ in range(3):
-            t0 = time.perf_counter()
+    saved_torch = torch.get_num_threads()
+    saved_orc = orc.get_threads()
+    share = cpu_share()
+    cat_np = {k: v.numpy() for k, v in cat_cpu.items()}
+
+    def net():
+        with torch.no_grad():
             logits = model_cpu.pure_model_forward(image)
             model_cpu.class_compression(logits)
-            net.append(time.perf_counter() - t0)
-    cat_np = {k: v.numpy() for k, v in cat_cpu.items()}
 
     def post():
         agg = orc.aggregate(cat_np)
@@ -202,26 +242,42 @@ def cpu_baseline(model_cpu, image, cat_cpu, hn, inv_k, encoder):
         xy = orc.ransac_voting_layer_v3(agg["instance_masks"], vertex, hn, seed=1)
         orc.pose_rt(agg["quaternion"], xy[:, 0], agg["z"], inv_k)
 
-    post_t = {}
-    for label, nthr in (("1", 1), ("all", 0)):
-        used = orc.set_threads(nthr)
+    def samples(fn, n=3):
+        fn()                                      # untimed: thread pool start-up, page faults of the first pass
         ts = []
-        for _ in range(3):
+        for _ in range(n):
             t0 = time.perf_counter()
-            post()
+            fn()
             ts.append(time.perf_counter() - t0)
-        post_t[label] = (used, ts)
-    orc.set_threads(1)
-    t_net, t_post1, t_postn = median(net), median(post_t["1"][1]), median(post_t["all"][1])
-    t_post, post_threads = (t_postn, post_t["all"][0]) if t_postn <= t_post1 else (t_post1, 1)      # the better of the two: a baseline is the host's best
-    return {"value": round(1.0 / (t_net + t_post), 4), "unit": "img/s", "cores": max(threads, post_threads), "kind": "port",
-            "sample": f"1 frame x 3 samples (medians): torch-CPU {encoder}-FPN forward + class compression on {threads} threads "
-                      f"({t_net * 1e3:.0f} ms) + oracle/fpc_oracle.c aggregation, hn={hn} voting and RT on {post_threads} thread(s) "
-                      f"({t_post * 1e3:.0f} ms; 1 thread {t_post1 * 1e3:.0f} ms, {post_t['all'][0]} threads {t_postn * 1e3:.0f} ms); host has "
-                      f"{os.cpu_count()} logical CPUs, the oracle's OpenMP loops are capped at FPCO_MAX_THREADS (16: the job's CPU share)",
-            "net_ms": [round(t * 1e3, 1) for t in net], "post_ms_1_thread": [round(t * 1e3, 1) for t in post_t["1"][1]],
-            "post_ms_all_threads": [round(t * 1e3, 1) for t in post_t["all"][1]],
-            "value_1_thread_post": round(1.0 / (t_net + t_post1), 4)}
+        return ts
+
+    net_t, post_t = {}, {}
+    try:
+        for nthr in sorted({1, share}):
+            torch.set_num_threads(nthr)
+            net_t[nthr] = samples(net)
+        torch.set_num_threads(saved_torch)
+        for nthr in sorted({1, share}):
+            used = orc.set_threads(nthr)
+            post_t[used] = samples(post)
+    finally:
+        torch.set_num_threads(saved_torch)
+        orc.set_threads(saved_orc)
+    net_thr = min(net_t, key=lambda k: median(net_t[k]))
+    post_thr = min(post_t, key=lambda k: median(post_t[k]))
+    t_net, t_post = median(net_t[net_thr]), median(post_t[post_thr])
+    dominant = net_thr if t_net >= t_post else post_thr
+
+    def ms(d):
+        return {str(k): [round(t * 1e3, 1) for t in v] for k, v in d.items()}
+    return {"value": round(1.0 / (t_net + t_post), 4), "unit": "img/s", "cores": dominant, "kind": "port",
+            "sample": f"1 frame x 3 samples per leg (medians after one untimed pass): torch-CPU {encoder}-FPN forward + class compression on "
+                      f"{net_thr} thread(s) ({t_net * 1e3:.0f} ms) + oracle/fpc_oracle.c aggregation, hn={hn} voting and RT on {post_thr} "
+                      f"thread(s) ({t_post * 1e3:.0f} ms); each leg timed on 1 thread and on the job's CPU share ({share} of the host's "
+                      f"{os.cpu_count()} logical CPUs: affinity mask / cgroup quota), the faster kept; `cores` = the dominant leg's threads",
+            "cpu_share": share, "threads": {"net": net_thr, "post": post_thr},
+            "net_ms_by_threads": ms(net_t), "post_ms_by_threads": ms(post_t),
+            "torch_threads_before_after": [saved_torch, torch.get_num_threads()]}
 
 
 def vote_roofline(model_gpu, cat, n_inst, reps, label, calls=30, use_bits=True):
@@ -598,20 +654,39 @@ def run_inference(args, encoder, Bq, hn, steps, warmup, world, rank, dev, want_b
                 if len(pending) > depth:
                     finish(pending.pop(0))
 
+        gaps = []
+
         def run_host(n):
+            tp = time.perf_counter()
             for _ in range(n):
                 step_host()
+                tn = time.perf_counter()
+                gaps.append(tn - tp)          # what one upload + submit (+ collect) cost the submitting thread
+                tp = tn
             while uploaded:
                 step_host(last=True)
             drain()
 
-        nh = int(os.environ.get("FPC_BENCH_HOST_FRAMES", "0")) or max(10, steps // 4)
+        # round 6: >= 600 frames per section, three sections, the MEDIAN reported with the submitting thread's longest stall —
+        # round 5's section was 75 frames (50 ms) on a process that did not confine its thread pools to the job's CPU share
+        nh = int(os.environ.get("FPC_BENCH_HOST_FRAMES", "0")) or max(-(-600 // Bq), steps // 4)
         run_host(depth + 3)
-        torch.cuda.synchronize()
-        t2 = time.perf_counter()
-        run_host(nh)
-        torch.cuda.synchronize()
-        res["host_frames_img_per_s"] = round(Bq * nh / (time.perf_counter() - t2), 2)
+        sections = []
+        for _ in range(3):
+            del gaps[:]
+            torch.cuda.synchronize()
+            t2 = time.perf_counter()
+            run_host(nh)
+            torch.cuda.synchronize()
+            dt_h = time.perf_counter() - t2
+            g = sorted(gaps)
+            sections.append({"img_per_s": round(Bq * nh / dt_h, 2), "host_thread_max_gap_ms": round(g[-1] * 1e3, 3),
+                             "host_thread_p99_gap_ms": round(g[int(0.99 * (len(g) - 1))] * 1e3, 3),
+                             "host_thread_median_gap_ms": round(g[len(g) // 2] * 1e3, 3)})
+        mid = sorted(sections, key=lambda d: d["img_per_s"])[1]
+        res["host_frames_img_per_s"] = mid["img_per_s"]
+        res["host_frames"] = {"frames_per_section": Bq * nh, "sections": sections, "host_thread_max_gap_ms": mid["host_thread_max_gap_ms"],
+                              "note": "median of three sections; gap = time the submitting thread spent in one upload + submit (+ collect) step"}
 
         # ... and from ENCODED frames: `*_color.png` files (in memory, as a loader's read-ahead would hold them) -> native PNG
         # decode on a few host threads straight into the pinned staging slot -> the same path (F/tools/dataset.py:158 on
@@ -623,7 +698,7 @@ def run_inference(args, encoder, Bq, hn, steps, warmup, world, rank, dev, want_b
             img = (img + np.random.default_rng(i).integers(0, 24, (480, 640, 3))).clip(0, 255).astype(np.uint8)
             pngs.append(encode_png_rgb_paeth(img))
         from fastposecnn_amd.tools.dataset import PngFramePrefetcher
-        workers = max(1, min(14, (os.cpu_count() or 2) - 2))        # the job's CPU share is 16 on a GPU box
+        workers = max(1, min(14, cpu_share() - 2))        # the job's CPU share (16 on a GPU box) minus the submitting thread and HIP's own
         npng = max(6, nh // 2) if Bq > 1 else max(40, nh)
         pre = PngFramePrefetcher(lambda k: [pngs[(k + j) % len(pngs)] for j in range(Bq)], npng + depth + 2, Bq, 480, 640, workers=workers)
 
@@ -759,7 +834,7 @@ def promote_config3(line, c3, r3, args):
                    "ms_per_step_one_in_flight": r3["ms_per_frame_one_in_flight"],
                    "stream_tune_mode": r3.get("stream_tune_mode"), "tune_trials": r3.get("tune_trials"),
                    "trial_rates_img_per_s": r3.get("trial_rates_img_per_s"), "pose_gather": r3.get("pose_gather"),
-                   "img_per_s_from_host_u8_frames": r3.get("host_frames_img_per_s"),
+                   "img_per_s_from_host_u8_frames": r3.get("host_frames_img_per_s"), "host_frames": r3.get("host_frames"),
                    "img_per_s_from_png_files": r3.get("png_files_img_per_s"), **shared},
         "roofline": c3["roofline"],
     }
@@ -788,10 +863,10 @@ def main():
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} does not match WORLD_SIZE {world}")
     # this rank's share of the host cores, before torch starts its thread pools and before anything touches the GPU
-    cores = pin_rank_to_cores(local_rank, int(os.environ.get("LOCAL_WORLD_SIZE", str(world))))
+    cores, host_threads = pin_rank_to_cores(local_rank, int(os.environ.get("LOCAL_WORLD_SIZE", str(world))))
     import torch
-    if cores:
-        torch.set_num_threads(max(1, min(len(cores), 16)))
+    if host_threads:
+        torch.set_num_threads(host_threads)
     if os.environ.get("FPC_BENCH_DRYRUN"):
         # launch-path check without a GPU (tests/test_host_logic.py): rendezvous over gloo, one collective, rank 0 reports
         import torch.distributed as dist
@@ -859,7 +934,7 @@ def main():
                                           if os.environ.get("FPC_SPLIT_PRECISION", "1") != "0" else
                                           "plain f32 matrix products (v_mfma_f32_32x32x2_f32) everywhere: FPC_SPLIT_PRECISION=0",
                        "post_network_input": "synthetic vote-bench fixture (SURVEY.md 8d), not the random-weight network's output",
-                       "img_per_s_from_host_u8_frames": res.get("host_frames_img_per_s"),
+                       "img_per_s_from_host_u8_frames": res.get("host_frames_img_per_s"), "host_frames": res.get("host_frames"),
                        "img_per_s_from_png_files": res.get("png_files_img_per_s"),
                        "img_per_s_from_png_files_note": "encoded *_color.png frames held in host memory -> native zlib-based decode on "
                                                         f"{res.get('png_decode_workers')} host threads running ahead (PngFramePrefetcher; ~10 ms of inflate + "

@@ -42,21 +42,31 @@
 #endif
 /* Threads used by the parallel loops (bench.py's cpu_baseline): n <= 0 = the cores this process may use, capped at
  * FPCO_MAX_THREADS (default 16: a GPU box gives one GPU's job 16 of its 256 logical CPUs, and 256 threads on that share
- * ran the vote 3.7x SLOWER than one).  Returns the count in effect. */
-int fpco_set_threads(int n) {
+ * ran the vote 3.7x SLOWER than one).  Returns the count in effect.  The count is THIS library's own: it is handed to
+ * every parallel loop through a num_threads clause and the process-wide OpenMP setting (which torch's CPU kernels
+ * share) is never touched — round 5's omp_set_num_threads(1) here left torch on one thread for the rest of the run. */
+static int fpco_threads = 0;          /* 0 = not chosen yet: the capped core count at first use */
+static int fpco_default_threads(void) {
 #ifdef _OPENMP
-    if (n <= 0) {
-        const char* cap = getenv("FPCO_MAX_THREADS");
-        int lim = cap ? atoi(cap) : 16;
-        n = omp_get_num_procs();
-        if (lim > 0 && n > lim) n = lim;
-    }
-    omp_set_num_threads(n);
-    return n;
+    const char* cap = getenv("FPCO_MAX_THREADS");
+    int lim = cap ? atoi(cap) : 16;
+    int n = omp_get_num_procs();
+    if (lim > 0 && n > lim) n = lim;
+    return n < 1 ? 1 : n;
 #else
-    (void)n;
     return 1;
 #endif
+}
+int fpco_set_threads(int n) {
+    fpco_threads = n <= 0 ? fpco_default_threads() : n;
+#ifndef _OPENMP
+    fpco_threads = 1;
+#endif
+    return fpco_threads;
+}
+int fpco_get_threads(void) {
+    if (fpco_threads <= 0) fpco_threads = fpco_default_threads();
+    return fpco_threads;
 }
 
 int fpco_generate_hypothesis(const float* direct, const float* coords, const int32_t* idxs,
@@ -264,7 +274,7 @@ int fpco_ransac_voting_v3(const float* mask, const float* vertex,
         /* the hn x tn decisions are independent: OpenMP over the hypotheses when the library is built with it
          * (bench.py's all-cores baseline; fpco_set_threads(1) = the scalar port); the arg-max stays sequential */
 #ifdef _OPENMP
-#pragma omp parallel for schedule(dynamic, 8)
+#pragma omp parallel for schedule(dynamic, 8) num_threads(fpco_get_threads())
 #endif
         for (int hi = 0; hi < hn; ++hi) {
             int cnt = 0;

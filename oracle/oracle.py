@@ -56,6 +56,13 @@ def set_threads(n):
     return int(f(int(n)))
 
 
+def get_threads():
+    """The count the oracle's parallel loops run on now (its own setting: the process-wide OpenMP count is never touched)."""
+    f = lib().fpco_get_threads
+    f.restype = ctypes.c_int
+    return int(f())
+
+
 def _p(a, t):
     return None if a is None else a.ctypes.data_as(t)
 

@@ -480,3 +480,43 @@ def test_isa_lint_built_library_is_clean():
         pytest.skip("libfpc_hip.so or llvm-objdump not present")
     bad, n_div = isa_lint.findings()
     assert n_div > 0 and bad == []
+
+
+def test_cpu_baseline_leaves_thread_settings_alone_and_names_its_threads():
+    """the oracle's thread count used to be set with omp_set_num_threads — process-wide, shared with
+    torch's CPU kernels — and left at 1, so the SECOND cpu_baseline() of a bench run (config 3, the top-level record) timed a
+    one-thread network under a "cores: 16" label.  Now: torch's count is the same before and after each of two calls, the
+    oracle's setting is its own, both legs are timed on 1 thread and on the job's CPU share, and `cores` is a count the
+    dominant leg really used."""
+    import importlib
+    import numpy as np
+    import torch
+    bench = importlib.import_module("bench")
+    import fastposecnn_amd.lib as L
+    from fastposecnn_amd import config, synth
+    from oracle import oracle as orc
+    hp = config.INFERENCE()
+    hp.RUNTIME_TIMING = False
+    torch.manual_seed(0)
+    model = L.pose_regressor.MODELS["PoseRegressor"].load_from_ckpt(None, hp).eval()
+    image = synth.make_image(0, 64, 96)[None]
+    cat_cpu, _ = synth.make_vote_frame(0, K=2, H=64, W=96, rmin=6, rmax=14)
+    inv_k = np.linalg.inv(hp.NUMPY_INTRINSICS).astype(np.float32)
+    share = bench.cpu_share()
+    assert 1 <= share <= (os.cpu_count() or 1)
+    before = torch.get_num_threads()
+    orc_before = orc.get_threads()
+    for _ in range(2):
+        rec = bench.cpu_baseline(model, image, cat_cpu, 32, inv_k, "resnet18")
+        assert torch.get_num_threads() == before
+        assert orc.get_threads() == orc_before
+        assert rec["torch_threads_before_after"] == [before, before]
+        assert rec["cpu_share"] == share
+        assert rec["threads"]["net"] in (1, share) and rec["threads"]["post"] in (1, min(share, 16))
+        assert rec["cores"] in (rec["threads"]["net"], rec["threads"]["post"])
+        assert set(rec["net_ms_by_threads"]) == {str(k) for k in {1, share}}
+        assert f"on {rec['threads']['net']} thread(s)" in rec["sample"]
+    # the oracle's own setting never reaches the process-wide OpenMP count
+    orc.set_threads(1)
+    assert torch.get_num_threads() == before
+    orc.set_threads(orc_before)
