@@ -199,7 +199,8 @@ struct fpc_net {
         c.w_off = alloc(conv_packed_floats(c.Npad, c.Kpad));      // f32 image + its three bf16 planes
         if (bn_prefix) { c.scale_off = alloc(Cout); c.shift_off = alloc(Cout); }
         c.wino_ok = (k == 3 && stride == 1 && pad == 1 && c.Cinp == Cin && Cin % 8 == 0 && Cout % 64 == 0);
-        if (c.wino_ok) c.wino_off = alloc((size_t)40 * Cout * Cin);      // f32 image (16 x) + split-precision image (24 x)
+        // f32 image (16 x) + split-precision image (24 x) + the 128-channel form's fragment-order image (24 x, wino128.hip)
+        if (c.wino_ok) c.wino_off = alloc((size_t)(Cout % 128 == 0 ? 64 : 40) * Cout * Cin);
         convs.push_back(c);
         return (int)convs.size() - 1;
     }
@@ -400,6 +401,10 @@ extern "C" int fpc_net_load_params(fpc_net_t* n, const float* const* params, int
             if (rc) return rc;
             rc = launch_wino_pack_bf3(n->pptr[c.p_w], n->ws + c.wino_off + (size_t)16 * c.Cout * c.Cin, c.Cout, c.Cin, s);
             if (rc) return rc;
+            if (c.Cout % 128 == 0) {
+                rc = launch_wino_pack_c128(n->pptr[c.p_w], n->ws + c.wino_off + (size_t)40 * c.Cout * c.Cin, c.Cout, c.Cin, s);
+                if (rc) return rc;
+            }
         }
         if (c.p_bn >= 0) {
             rc = launch_fold_bn(n->pptr[c.p_bn], n->pptr[c.p_bn + 1], n->pptr[c.p_bn + 2], n->pptr[c.p_bn + 3], 1e-5f,
@@ -466,7 +471,8 @@ int launch_conv_plan(ConvArgs& a, const ConvPlan& p, int groups, hipStream_t s) 
         for (int g = 0; g < groups; ++g) {
             if (!a.wino_w[g] || a.p[g].up) return FPC_EINVAL;
             w.p[g] = a.p[g];
-            w.p[g].w = a.wino_w[g] + (p.wino == 5 ? (size_t)16 * a.Cout * a.Cin : 0);      // the split-precision image follows the f32 one
+            // the split-precision image follows the f32 one, the 128-channel form's fragment-order image follows that
+            w.p[g].w = a.wino_w[g] + (p.wino == 5 ? (size_t)16 * a.Cout * a.Cin : p.wino == 6 ? (size_t)40 * a.Cout * a.Cin : 0);
         }
         w.variant = p.wino == 3 ? 1 : (p.wino == 4 ? 2 : (p.wino == 5 ? 3 : 0));
         w.zeros = a.zeros;
@@ -475,6 +481,7 @@ int launch_conv_plan(ConvArgs& a, const ConvPlan& p, int groups, hipStream_t s) 
         w.B = a.B; w.H = a.Ho; w.W = a.Wo; w.Cin = a.Cin; w.Cout = a.Cout; w.relu = a.relu;
         w.waves = (p.wino == 2 || p.wino == 4 || p.wino == 5) ? 8 : 4;
         w.tbx = cdiv(cdiv(a.Wo, 2), 8); w.tby = cdiv(cdiv(a.Ho, 2), w.waves);
+        if (p.wino == 6) return a.Cout % 128 == 0 ? launch_conv_wino_c128(w, groups, s) : FPC_EINVAL;      // 8 x 4 tiles x 128 channels (wino128.hip)
         return launch_conv_wino(w, groups, s);
     }
     a.bm = p.bm; a.bn = p.bn; a.nsplit = p.nsplit; a.mtiles = p.mtiles; a.ntiles = p.ntiles; a.groups = groups;
@@ -520,10 +527,12 @@ int run_conv(fpc_net* n, ConvArgs& a, int groups, int ci, hipStream_t s) {
             wq.wino = 3; cands.push_back(wq);
             if (a.zeros) { wq.wino = 4; cands.push_back(wq); }
             if (n->split_precision && a.zeros) { wq.wino = 5; cands.push_back(wq); }      // split-precision products, 8 waves
+            if (n->split_precision && a.Cout % 128 == 0) { wq.wino = 6; cands.push_back(wq); }      // ... 128 channels per workgroup, 4 waves
         }
         for (const ConvPlan& q : cands) {
             if (splitk_floats_for(q, groups, a.B, a.Npad) > cap) continue;
             int rc = launch_conv_plan(a, q, groups, s);     // warm-up (also validates the launch)
+            if (rc == FPC_EINVAL) continue;                 // a candidate whose launcher refuses this site (its own preconditions) is skipped
             if (rc) { (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); return rc; }
             float ms = 1e30f;
             for (int rep = 0; rep < 3; ++rep) {
@@ -539,9 +548,9 @@ int run_conv(fpc_net* n, ConvArgs& a, int groups, int ci, hipStream_t s) {
             if (n->tune_mode >= 1) {
                 double nblk = q.stem ? (double)q.stem
                               : q.lat ? (double)cdiv(a.Ho * a.Wo, 128) * a.B * q.lat
-                              : q.wino ? (double)cdiv(cdiv(a.Wo, 2), 8) * cdiv(cdiv(a.Ho, 2), (q.wino == 2 || q.wino == 4 || q.wino == 5) ? 8 : 4) * a.B * (a.Cout / 64) * groups
+                              : q.wino ? (double)cdiv(cdiv(a.Wo, 2), 8) * cdiv(cdiv(a.Ho, 2), (q.wino == 2 || q.wino == 4 || q.wino == 5) ? 8 : 4) * a.B * (a.Cout / (q.wino == 6 ? 128 : 64)) * groups
                                      : (double)q.mtiles * q.ntiles * q.nsplit * a.B * groups;
-                double slots = 256.0 * ((q.wino == 2 || q.wino == 4 || q.wino == 5) ? 1.0 : 2.0);
+                double slots = 256.0 * ((q.wino == 2 || q.wino == 4 || q.wino == 5 || q.wino == 6) ? 1.0 : 2.0);
                 double share = nblk / slots;
                 if (share > 1.0) share = 1.0;
                 if (share < 0.125) share = 0.125;
@@ -882,7 +891,7 @@ extern "C" size_t fpc_conv2d_workspace_bytes(int B, int Ho, int Wo, int Cin, int
     int K = Cin * Kh * Kw, Kpad = cdiv(K, kConvBK) * kConvBK, Npad = cdiv(Cout, kConvNAlign) * kConvNAlign;
     size_t packed = conv_packed_floats(Npad, Kpad);
     size_t splitk = (size_t)32 * B * (cdiv(Ho * Wo, 128) * 128) * Npad;
-    size_t wino = (size_t)40 * Cout * Cin + 64;      // f32 + split-precision Winograd images + a zero page for the all-DMA form
+    size_t wino = (size_t)64 * Cout * Cin + 64;      // f32 + split-precision (two layouts) Winograd images + a zero page for the all-DMA form
     return (packed + splitk + wino + kConvTickets) * sizeof(float);
 }
 
@@ -894,7 +903,7 @@ extern "C" int fpc_conv2d_plan(int B, int Ho, int Wo, int Cin, int Cout, int Kh,
     if (nsplit >= 1000) nsplit -= 1000;      // fpc_conv2d's split-precision / two-launch hooks do not change the tiling
     if (nsplit >= 100) nsplit -= 100;
     ConvPlan p = plan_conv(Ho * Wo, B, Cout, Kpad / kConvBK, 1, bm, bn, nsplit);
-    if (nsplit <= -1 && nsplit >= -5) { p.wino = -nsplit; p.nsplit = nsplit; }
+    if (nsplit <= -1 && nsplit >= -6) { p.wino = -nsplit; p.nsplit = nsplit; }
     out4[0] = p.bm; out4[1] = p.bn; out4[2] = p.nsplit; out4[3] = plan_gn_rows(p, Ho, Wo);
     return FPC_OK;
 }
@@ -908,7 +917,8 @@ Conv2dRequest conv2d_request(int nsplit) {
     if (r.nsplit >= 2000) { r.lat = r.nsplit - 2000; r.bf3 = true; r.nsplit = 1; return r; }      // 2000 + parts = k_lateral1x1 (lateral.hip)
     if (r.nsplit >= 1000) { r.bf3 = true; r.nsplit -= 1000; }          // 1000 + split = split-precision matrix products
     if (r.nsplit >= 100) { r.two_launch = true; r.nsplit -= 100; }      // 100 + split = split-K summed by k_conv_splitk_epilogue
-    r.wino = r.nsplit <= -1 && r.nsplit >= -5;      // -1: 4 waves, -2: 8 waves, -3: wave-private, -4: all-DMA 3-stage, -5: 8 waves split precision
+    // -1: 4 waves, -2: 8 waves, -3: wave-private, -4: all-DMA 3-stage, -5: 8 waves split precision, -6: split precision, 128 channels per workgroup
+    r.wino = r.nsplit <= -1 && r.nsplit >= -6;
     return r;
 }
 // workspace of ONE fpc_conv2d call (floats): [packed weights | split-K partials of this plan | Winograd images + zero page |
@@ -919,7 +929,7 @@ Conv2dLayout conv2d_layout(int B, int Cin, int Cout, int Kh, int Kw, const ConvP
     Conv2dLayout L;
     L.packed = r.wino ? 0 : conv_packed_floats(Npad, Kpad);
     L.splitk = r.wino ? 0 : (splitk_floats_for(p, 1, B, Npad) + 63) / 64 * 64;
-    L.wino = r.wino ? (size_t)(r.nsplit == -5 ? 40 : 16) * Cout * Cin + 64 : 0;
+    L.wino = r.wino ? (size_t)(r.nsplit == -6 ? 64 : r.nsplit == -5 ? 40 : 16) * Cout * Cin + 64 : 0;
     L.tickets = (!r.wino && p.fused && p.nsplit > 1) ? kConvTickets : 0;
     L.total = L.packed + L.splitk + L.wino + L.tickets;
     return L;
@@ -1006,8 +1016,10 @@ extern "C" int fpc_conv2d(const float* in, int64_t sb, int64_t sh, int64_t sw, i
             return FPC_EINVAL;
         float* wp = packed + lay.packed + lay.splitk;
         // (the split-precision form reads only its own image: the f32 image is not packed for it — 78 launches of a training step)
-        if (nsplit != -5) FPC_TRY(launch_wino_pack(w_oihw, wp, Cout, Cin, s));
+        if (nsplit == -6 && Cout % 128) return FPC_EINVAL;
+        if (nsplit > -5) FPC_TRY(launch_wino_pack(w_oihw, wp, Cout, Cin, s));
         if (nsplit == -5) FPC_TRY(launch_wino_pack_bf3(w_oihw, wp + (size_t)16 * Cout * Cin, Cout, Cin, s));
+        if (nsplit == -6) FPC_TRY(launch_wino_pack_c128(w_oihw, wp + (size_t)40 * Cout * Cin, Cout, Cin, s));
         a.wino_w[0] = wp;
         a.zeros = zero_page();       // (the workspace's last 64 floats stay reserved for it: fpc_conv2d_workspace_bytes is unchanged)
         if (!a.zeros) {

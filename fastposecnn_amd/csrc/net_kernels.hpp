@@ -135,6 +135,10 @@ int launch_conv_wino(const WinoArgs& a, int groups, hipStream_t s);
 const float* zero_page();      // 64 zero floats in the code object (per device context), or null
 int launch_wino_pack(const float* w_oihw, float* packed, int Cout, int Cin, hipStream_t s);
 int launch_wino_pack_bf3(const float* w_oihw, float* packed, int Cout, int Cin, hipStream_t s);
+// wino128.hip: the split-precision form with 128 output channels per workgroup (8 x 4 tile patch, 4 waves; Cout % 128 == 0;
+// .w = the k_wino_pack_c128 fragment-order image, .waves = 4, tby = ceil(ceil(H/2)/4))
+int launch_conv_wino_c128(const WinoArgs& a, int groups, hipStream_t s);
+int launch_wino_pack_c128(const float* w_oihw, float* packed, int Cout, int Cin, hipStream_t s);
 int launch_conv(const ConvArgs& a, int groups, hipStream_t s);
 int launch_conv_splitk_epilogue(const ConvArgs& a, int groups, hipStream_t s);
 int launch_maxpool3x3s2(const float* in, float* out, int B, int Hi, int Wi, int C, int Ho, int Wo, hipStream_t s);

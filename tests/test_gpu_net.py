@@ -141,6 +141,15 @@ CONV_CASES = [
     (1, 64, 30, 40, 64, 3, 1, 1, (0, 0, -2), "bn_relu_res"),
     (2, 256, 15, 20, 128, 3, 1, 1, (0, 0, -2), "gn"),
     (1, 128, 34, 50, 128, 3, 1, 1, (0, 0, -2), "gn"),
+    # split-precision Winograd with 128 output channels per workgroup (nsplit = -6, wino128.hip): 8 x 4 tile patches, 4 waves, weights
+    # straight into the operand registers.  Ragged patches on both axes, every image border, one / two / many K-steps, two
+    # 128-channel blocks, residual + folded BatchNorm, GroupNorm partial sums
+    (1, 64, 30, 40, 128, 3, 1, 1, (0, 0, -6), "bn_relu_res"),
+    (2, 256, 15, 20, 128, 3, 1, 1, (0, 0, -6), "gn"),
+    (1, 128, 34, 50, 256, 3, 1, 1, (0, 0, -6), "gn"),
+    (1, 8, 7, 9, 128, 3, 1, 1, (0, 0, -6), "bias_relu"),        # a single K-step
+    (1, 16, 20, 24, 128, 3, 1, 1, (0, 0, -6), "bias_relu"),     # two K-steps
+    (3, 24, 16, 32, 128, 3, 1, 1, (0, 0, -6), "gn"),            # three K-steps, patches that tile the image exactly
 ]
 
 
