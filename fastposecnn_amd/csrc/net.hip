@@ -472,16 +472,17 @@ int launch_conv_plan(ConvArgs& a, const ConvPlan& p, int groups, hipStream_t s) 
             if (!a.wino_w[g] || a.p[g].up) return FPC_EINVAL;
             w.p[g] = a.p[g];
             // the split-precision image follows the f32 one, the 128-channel form's fragment-order image follows that
-            w.p[g].w = a.wino_w[g] + (p.wino == 5 ? (size_t)16 * a.Cout * a.Cin : p.wino == 6 ? (size_t)40 * a.Cout * a.Cin : 0);
+            w.p[g].w = a.wino_w[g] + ((p.wino == 5 || p.wino == 7) ? (size_t)16 * a.Cout * a.Cin : p.wino == 6 ? (size_t)40 * a.Cout * a.Cin : 0);
         }
         w.variant = p.wino == 3 ? 1 : (p.wino == 4 ? 2 : (p.wino == 5 ? 3 : 0));
         w.zeros = a.zeros;
         w.dbg = (long long*)a.dbg;
         w.groups = groups;
         w.B = a.B; w.H = a.Ho; w.W = a.Wo; w.Cin = a.Cin; w.Cout = a.Cout; w.relu = a.relu;
-        w.waves = (p.wino == 2 || p.wino == 4 || p.wino == 5) ? 8 : 4;
+        w.waves = (p.wino == 2 || p.wino == 4 || p.wino == 5 || p.wino == 7) ? 8 : 4;
         w.tbx = cdiv(cdiv(a.Wo, 2), 8); w.tby = cdiv(cdiv(a.Ho, 2), w.waves);
         if (p.wino == 6) return a.Cout % 128 == 0 ? launch_conv_wino_c128(w, groups, s) : FPC_EINVAL;      // 8 x 4 tiles x 128 channels (wino128.hip)
+        if (p.wino == 7) return launch_conv_wino_w4(w, groups, s);      // 8 x 8 tiles x 64 channels as four waves of 512 registers (wino_w4.hip)
         return launch_conv_wino(w, groups, s);
     }
     a.bm = p.bm; a.bn = p.bn; a.nsplit = p.nsplit; a.mtiles = p.mtiles; a.ntiles = p.ntiles; a.groups = groups;
@@ -495,7 +496,7 @@ int launch_conv_plan(ConvArgs& a, const ConvPlan& p, int groups, hipStream_t s) 
 
 // number of GroupNorm partial rows per image a plan writes
 int plan_gn_rows(const ConvPlan& p, int Ho, int Wo) {
-    return p.wino ? cdiv(cdiv(Wo, 2), 8) * cdiv(cdiv(Ho, 2), (p.wino == 2 || p.wino == 4 || p.wino == 5) ? 8 : 4) : p.mtiles * p.bm / 32;
+    return p.wino ? cdiv(cdiv(Wo, 2), 8) * cdiv(cdiv(Ho, 2), (p.wino == 2 || p.wino == 4 || p.wino == 5 || p.wino == 7) ? 8 : 4) : p.mtiles * p.bm / 32;
 }
 
 // Runs conv site `ci` with its current plan; in tuning mode first times every candidate tiling
@@ -528,6 +529,7 @@ int run_conv(fpc_net* n, ConvArgs& a, int groups, int ci, hipStream_t s) {
             if (a.zeros) { wq.wino = 4; cands.push_back(wq); }
             if (n->split_precision && a.zeros) { wq.wino = 5; cands.push_back(wq); }      // split-precision products, 8 waves
             if (n->split_precision && a.Cout % 128 == 0) { wq.wino = 6; cands.push_back(wq); }      // ... 128 channels per workgroup, 4 waves
+            if (n->split_precision) { wq.wino = 7; cands.push_back(wq); }      // ... 64 channels, four waves of 512 registers, weights direct
         }
         for (const ConvPlan& q : cands) {
             if (splitk_floats_for(q, groups, a.B, a.Npad) > cap) continue;
@@ -548,9 +550,9 @@ int run_conv(fpc_net* n, ConvArgs& a, int groups, int ci, hipStream_t s) {
             if (n->tune_mode >= 1) {
                 double nblk = q.stem ? (double)q.stem
                               : q.lat ? (double)cdiv(a.Ho * a.Wo, 128) * a.B * q.lat
-                              : q.wino ? (double)cdiv(cdiv(a.Wo, 2), 8) * cdiv(cdiv(a.Ho, 2), (q.wino == 2 || q.wino == 4 || q.wino == 5) ? 8 : 4) * a.B * (a.Cout / (q.wino == 6 ? 128 : 64)) * groups
+                              : q.wino ? (double)cdiv(cdiv(a.Wo, 2), 8) * cdiv(cdiv(a.Ho, 2), (q.wino == 2 || q.wino == 4 || q.wino == 5 || q.wino == 7) ? 8 : 4) * a.B * (a.Cout / (q.wino == 6 ? 128 : 64)) * groups
                                      : (double)q.mtiles * q.ntiles * q.nsplit * a.B * groups;
-                double slots = 256.0 * ((q.wino == 2 || q.wino == 4 || q.wino == 5 || q.wino == 6) ? 1.0 : 2.0);
+                double slots = 256.0 * ((q.wino == 2 || q.wino == 4 || q.wino == 5 || q.wino == 6 || q.wino == 7) ? 1.0 : 2.0);
                 double share = nblk / slots;
                 if (share > 1.0) share = 1.0;
                 if (share < 0.125) share = 0.125;
@@ -903,7 +905,7 @@ extern "C" int fpc_conv2d_plan(int B, int Ho, int Wo, int Cin, int Cout, int Kh,
     if (nsplit >= 1000) nsplit -= 1000;      // fpc_conv2d's split-precision / two-launch hooks do not change the tiling
     if (nsplit >= 100) nsplit -= 100;
     ConvPlan p = plan_conv(Ho * Wo, B, Cout, Kpad / kConvBK, 1, bm, bn, nsplit);
-    if (nsplit <= -1 && nsplit >= -6) { p.wino = -nsplit; p.nsplit = nsplit; }
+    if (nsplit <= -1 && nsplit >= -7) { p.wino = -nsplit; p.nsplit = nsplit; }
     out4[0] = p.bm; out4[1] = p.bn; out4[2] = p.nsplit; out4[3] = plan_gn_rows(p, Ho, Wo);
     return FPC_OK;
 }
@@ -918,7 +920,8 @@ Conv2dRequest conv2d_request(int nsplit) {
     if (r.nsplit >= 1000) { r.bf3 = true; r.nsplit -= 1000; }          // 1000 + split = split-precision matrix products
     if (r.nsplit >= 100) { r.two_launch = true; r.nsplit -= 100; }      // 100 + split = split-K summed by k_conv_splitk_epilogue
     // -1: 4 waves, -2: 8 waves, -3: wave-private, -4: all-DMA 3-stage, -5: 8 waves split precision, -6: split precision, 128 channels per workgroup
-    r.wino = r.nsplit <= -1 && r.nsplit >= -6;
+    // -7: split precision, 64 channels, four waves of 512 registers (the -5 image)
+    r.wino = r.nsplit <= -1 && r.nsplit >= -7;
     return r;
 }
 // workspace of ONE fpc_conv2d call (floats): [packed weights | split-K partials of this plan | Winograd images + zero page |
@@ -929,7 +932,7 @@ Conv2dLayout conv2d_layout(int B, int Cin, int Cout, int Kh, int Kw, const ConvP
     Conv2dLayout L;
     L.packed = r.wino ? 0 : conv_packed_floats(Npad, Kpad);
     L.splitk = r.wino ? 0 : (splitk_floats_for(p, 1, B, Npad) + 63) / 64 * 64;
-    L.wino = r.wino ? (size_t)(r.nsplit == -6 ? 64 : r.nsplit == -5 ? 40 : 16) * Cout * Cin + 64 : 0;
+    L.wino = r.wino ? (size_t)(r.nsplit == -6 ? 64 : (r.nsplit == -5 || r.nsplit == -7) ? 40 : 16) * Cout * Cin + 64 : 0;
     L.tickets = (!r.wino && p.fused && p.nsplit > 1) ? kConvTickets : 0;
     L.total = L.packed + L.splitk + L.wino + L.tickets;
     return L;
@@ -1018,7 +1021,7 @@ extern "C" int fpc_conv2d(const float* in, int64_t sb, int64_t sh, int64_t sw, i
         // (the split-precision form reads only its own image: the f32 image is not packed for it — 78 launches of a training step)
         if (nsplit == -6 && Cout % 128) return FPC_EINVAL;
         if (nsplit > -5) FPC_TRY(launch_wino_pack(w_oihw, wp, Cout, Cin, s));
-        if (nsplit == -5) FPC_TRY(launch_wino_pack_bf3(w_oihw, wp + (size_t)16 * Cout * Cin, Cout, Cin, s));
+        if (nsplit == -5 || nsplit == -7) FPC_TRY(launch_wino_pack_bf3(w_oihw, wp + (size_t)16 * Cout * Cin, Cout, Cin, s));
         if (nsplit == -6) FPC_TRY(launch_wino_pack_c128(w_oihw, wp + (size_t)40 * Cout * Cin, Cout, Cin, s));
         a.wino_w[0] = wp;
         a.zeros = zero_page();       // (the workspace's last 64 floats stay reserved for it: fpc_conv2d_workspace_bytes is unchanged)

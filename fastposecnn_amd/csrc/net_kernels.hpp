@@ -139,6 +139,9 @@ int launch_wino_pack_bf3(const float* w_oihw, float* packed, int Cout, int Cin, 
 // .w = the k_wino_pack_c128 fragment-order image, .waves = 4, tby = ceil(ceil(H/2)/4))
 int launch_conv_wino_c128(const WinoArgs& a, int groups, hipStream_t s);
 int launch_wino_pack_c128(const float* w_oihw, float* packed, int Cout, int Cin, hipStream_t s);
+// wino_w4.hip: the split-precision form as four waves of 512 registers (8 x 8 tile patch x 64 channels, weights straight into the
+// operand registers; .w = the k_wino_pack_bf3 image, tby = ceil(ceil(H/2)/8))
+int launch_conv_wino_w4(const WinoArgs& a, int groups, hipStream_t s);
 int launch_conv(const ConvArgs& a, int groups, hipStream_t s);
 int launch_conv_splitk_epilogue(const ConvArgs& a, int groups, hipStream_t s);
 int launch_maxpool3x3s2(const float* in, float* out, int B, int Hi, int Wi, int C, int Ho, int Wo, hipStream_t s);

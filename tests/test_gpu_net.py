@@ -150,6 +150,14 @@ CONV_CASES = [
     (1, 8, 7, 9, 128, 3, 1, 1, (0, 0, -6), "bias_relu"),        # a single K-step
     (1, 16, 20, 24, 128, 3, 1, 1, (0, 0, -6), "bias_relu"),     # two K-steps
     (3, 24, 16, 32, 128, 3, 1, 1, (0, 0, -6), "gn"),            # three K-steps, patches that tile the image exactly
+    # split-precision Winograd as four waves of 512 registers (nsplit = -7, wino_w4.hip): 8 x 8 tile patches x 64 channels, weights
+    # straight into the operand registers, next step's pieces split in place
+    (1, 64, 30, 40, 64, 3, 1, 1, (0, 0, -7), "bn_relu_res"),
+    (2, 256, 15, 20, 128, 3, 1, 1, (0, 0, -7), "gn"),
+    (1, 128, 34, 50, 128, 3, 1, 1, (0, 0, -7), "gn"),
+    (1, 8, 7, 9, 64, 3, 1, 1, (0, 0, -7), "bias_relu"),         # a single K-step
+    (1, 16, 20, 24, 64, 3, 1, 1, (0, 0, -7), "bias_relu"),      # two K-steps
+    (3, 24, 32, 32, 192, 3, 1, 1, (0, 0, -7), "gn"),            # three K-steps, patches that tile the image exactly, three channel blocks
 ]
 
 

@@ -5,14 +5,14 @@ import torch
 from fastposecnn_amd import _native as nat
 dev = torch.device("cuda:0"); L = nat.lib()
 VAR = int(sys.argv[1]) if len(sys.argv) > 1 else -1      # -1: 4-wave barrier form, -4: 8-wave all-DMA form
-NWAVE = 8 if VAR in (-4, -2, -5) else 4
+NWAVE = 8 if VAR in (-4, -2, -5) else 4      # (-6, -7: four waves)
 B, Cin, Hi, Wi, Cout, k = 4, 256, 120, 160, 128, 3
 if len(sys.argv) > 6:      # python tools_dev/wino_stamps.py VAR B Cin H W Cout
     B, Cin, Hi, Wi, Cout = (int(v) for v in sys.argv[2:7])
 x = torch.randn((B, Hi, Wi, Cin), device=dev); w = torch.randn((Cout, Cin, k, k), device=dev) * 0.05
 out = torch.empty((B, Hi, Wi, Cout), device=dev)
 ws = torch.empty(L.fpc_conv2d_workspace_bytes(B, Hi, Wi, Cin, Cout, k, k), dtype=torch.uint8, device=dev)
-nblk = (-(-(Wi // 2) // 8) * (-(-(Hi // 2) // (8 if VAR in (-4, -2, -5) else 4)))) * B * (Cout // (128 if VAR == -6 else 64))
+nblk = (-(-(Wi // 2) // 8) * (-(-(Hi // 2) // (8 if VAR in (-4, -2, -5, -7) else 4)))) * B * (Cout // (128 if VAR == -6 else 64))
 dbg = torch.zeros((nblk, NWAVE, 8), dtype=torch.int64, device=dev)
 sb, sh, sw, sc = x.stride(); st = torch.cuda.current_stream().cuda_stream
 for _ in range(200):
