@@ -847,6 +847,28 @@ extern "C" int fpc_net_conv_plan(const fpc_net_t* n, int i, int* out5) {
     return FPC_OK;
 }
 
+// Plans of `src` -> `dst` (same encoder, classes, H, W; batch sizes may differ): runs a small batch on the tilings, split-K
+// factors and kernel forms a larger one was autotuned to (tests: the headline configuration's kernels against float64 on two
+// frames).  A plan whose split-K partials do not fit dst's workspace keeps dst's own.  Drops dst's recorded graph.
+extern "C" int fpc_net_copy_plans(fpc_net_t* dst, const fpc_net_t* src) {
+    if (!dst || !src || dst->convs.size() != src->convs.size() || dst->H != src->H || dst->W != src->W) return FPC_EINVAL;
+    for (size_t i = 0; i < dst->convs.size(); ++i) {
+        const PackedConv &a = dst->convs[i], &b = src->convs[i];
+        if (a.Cin != b.Cin || a.Cout != b.Cout || a.Kh != b.Kh || a.Kw != b.Kw || a.stride != b.stride || a.Npad != b.Npad ||
+            a.Kpad != b.Kpad || dst->c_groups[i] != src->c_groups[i])
+            return FPC_EINVAL;
+    }
+    for (size_t i = 0; i < dst->convs.size(); ++i) {
+        const ConvPlan& q = src->cplan[i];
+        if (splitk_floats_for(q, dst->c_groups[i] ? dst->c_groups[i] : 1, dst->B, dst->convs[i].Npad) > dst->splitk_floats) continue;
+        if (q.nsplit > 1 && q.fused && !can_fuse(q, dst->c_groups[i] ? dst->c_groups[i] : 1, dst->B)) continue;
+        dst->cplan[i] = q;
+    }
+    dst->tuned = true;
+    if (dst->graph_exec) { (void)hipGraphExecDestroy(dst->graph_exec); dst->graph_exec = nullptr; }
+    return FPC_OK;
+}
+
 // FLOP of one forward over the whole batch: out3[0] = 2 x MACs of the direct convolutions (the algorithmic count the
 // reference's cuDNN path would execute), out3[1] = multiply-adds the CURRENT plans execute (a Winograd F(2x2,3x3)
 // site does 16 instead of 36 per 2x2 output tile: direct / 2.25), out3[2] = share of out3[0] on Winograd sites.

@@ -85,6 +85,10 @@ class NetEngine:
             out.append(tuple(buf))
         return out
 
+    def copy_plans_from(self, other):
+        """Run this engine on the plans `other` (same network and frame size, another batch) was autotuned to."""
+        nat.check(self._lib.fpc_net_copy_plans(self._h, other._h), "fpc_net_copy_plans")
+
     def flops(self):
         """(direct-convolution FLOP, FLOP the current plans execute, Winograd share) of one forward over the batch."""
         buf = (ctypes.c_double * 3)()

@@ -369,6 +369,10 @@ int fpc_net_set_split_precision(fpc_net_t* net, int on);
 int fpc_net_set_graph(fpc_net_t* net, int on);
 int fpc_net_conv_count(const fpc_net_t* net);
 int fpc_net_conv_plan(const fpc_net_t* net, int i, int* out5);
+/* Copies the convolution plans (tilings, split-K factors, kernel forms) of `src` into `dst`: same encoder, classes and frame
+ * size, any batch sizes — a small batch then runs on the kernels a larger one was autotuned to (tests/test_gpu_net.py: the
+ * headline configuration's plan set against float64 on two frames).  Plans whose split-K partials do not fit dst keep dst's own. */
+int fpc_net_copy_plans(fpc_net_t* dst, const fpc_net_t* src);
 /* FLOP of one forward over the batch under the current plans: out3 = {2 x MACs of the direct convolutions (what the
  * reference's cuDNN path executes), multiply-add FLOP the plans execute (Winograd sites: / 2.25), Winograd share}. */
 int fpc_net_flops(const fpc_net_t* net, double* out3);
