@@ -218,6 +218,10 @@ extern "C" int fpc_net_create(const char* encoder, int classes, int B, int H, in
     else if (!strcmp(encoder, "resnet34")) { int l[4] = {3, 4, 6, 3}; memcpy(n->layers, l, sizeof(l)); n->r34 = true; }
     else { delete n; return FPC_EINVAL; }
     n->classes = classes; n->B = B; n->H = H; n->W = W;
+    {   // merge + head in two passes (merge_split.hip) unless FPC_MERGE_SPLIT=0; read once, here
+        const char* e = getenv("FPC_MERGE_SPLIT");
+        n->merge_split = e ? (atoi(e) != 0) : 1;      // (one frame: 27 us in two passes against 32.5 us in one)
+    }
     char buf[256];
 
     // ---- parameters + packed storage (persistent region first)
@@ -548,7 +552,7 @@ int run_conv(fpc_net* n, ConvArgs& a, int groups, int ci, hipStream_t s) {
             // with several frames in flight a launch that leaves CUs free lets another stream's kernels run
             float score = ms;
             if (n->tune_mode >= 1) {
-                double nblk = q.stem ? (double)q.stem
+                double nblk = q.stem ? 512.0      // (a persistent 512-thread, 86 KB workgroup per CU: the whole chip, whatever its grid)
                               : q.lat ? (double)cdiv(a.Ho * a.Wo, 128) * a.B * q.lat
                               : q.wino ? (double)cdiv(cdiv(a.Wo, 2), 8) * cdiv(cdiv(a.Ho, 2), (q.wino == 2 || q.wino == 4 || q.wino == 5 || q.wino == 7) ? 8 : 4) * a.B * (a.Cout / (q.wino == 6 ? 128 : 64)) * groups
                                      : (double)q.mtiles * q.ntiles * q.nsplit * a.B * groups;
@@ -719,11 +723,7 @@ static int forward_middle(fpc_net* n, hipStream_t s) {
 
     // merge + head
     const int lo[3] = {2, 4, 5};     // s5.2, s4.1, s3.0 (sum order of the reference: p5-, p4-, p3-, p2-branch)
-    int split = n->merge_split;
-    if (split < 0) {
-        const char* e = getenv("FPC_MERGE_SPLIT");
-        split = e ? (atoi(e) != 0) : 1;      // (one frame: 27 us in two passes against 32.5 us in one)
-    }
+    const int split = n->merge_split;      // resolved once in fpc_net_create (FPC_MERGE_SPLIT): graph and plain runs agree, no getenv per forward
     if (split) {
         // two passes (merge_split.hip): the head of (r5 + r4 + r3) at the branches' resolution, then the head of r2 + bias + its x2 upsample
         HeadPartArgs hl, hh;
@@ -1013,6 +1013,8 @@ extern "C" int fpc_conv2d(const float* in, int64_t sb, int64_t sh, int64_t sw, i
         return launch_conv_plan(a0, p, 1, s);
     }
     // (the split-precision forms — bf16 x 3 tiles, k_lateral1x1 — read only the planes behind the f32 image: it is not packed for them)
+    static_assert(FPC_IGEMM_DMA_B, "the split-precision direct form stages its B rows from the bf16 planes by LDS-DMA; a build that loads "
+                                   "them from the f32 image must pack that image here as well");
     if (!wino && !p.bf3) FPC_TRY(launch_pack_weight(w_oihw, packed, Cout, Cin, Cin, Kh, Kw, Kw, c.Npad, c.Kpad, s));
     if (!wino && p.bf3) FPC_TRY(launch_pack_weight_bf3(w_oihw, packed, Cout, Cin, Cin, Kh, Kw, Kw, c.Npad, c.Kpad, s));
     int mode = (sc == 1 && Cin % kConvBK == 0 && Kh * Kw <= 32 && ((int64_t)Hi + 2 * pad) * sh * 4 < ((int64_t)1 << 31)) ? 0

@@ -100,9 +100,7 @@ constexpr int kLdsRow = kConvBK;
 
 // ------------------------------------------------------------------------------------------
 // implicit-GEMM convolution
-#ifndef FPC_IGEMM_DMA_B
-#define FPC_IGEMM_DMA_B 1
-#endif
+// (FPC_IGEMM_DMA_B: net_kernels.hpp — fpc_conv2d's packing depends on it)
 #ifndef FPC_IGEMM_PRIO
 #define FPC_IGEMM_PRIO 1
 #endif
@@ -1392,7 +1390,8 @@ static int stream_grid(long long work_items) {
 }
 
 int launch_maxpool3x3s2(const float* in, float* out, int B, int Hi, int Wi, int C, int Ho, int Wo, hipStream_t s) {
-    if (C % 4 != 0 || (long long)B * Ho * Wo * (C / 4) >= (1LL << 32)) return FPC_EINVAL;
+    // (xcd_walk's 32-bit `first + k * step` must not wrap: one grid stride — at most 4096 x 256 items — of headroom below 2^32)
+    if (C % 4 != 0 || (long long)B * Ho * Wo * (C / 4) >= (1LL << 32) - 4096LL * 256 - 8) return FPC_EINVAL;
     hipLaunchKernelGGL(k_maxpool3x3s2, dim3(stream_grid((long long)B * Ho * Wo * (C / 4))), dim3(256), 0, s, in, out, B,
                        Hi, Wi, C, Ho, Wo);
     return check_launch();

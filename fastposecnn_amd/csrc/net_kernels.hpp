@@ -5,6 +5,10 @@
 
 namespace fpc {
 
+#ifndef FPC_IGEMM_DMA_B
+#define FPC_IGEMM_DMA_B 1      // split-precision k_conv_igemm: B rows staged from the bf16 planes by LDS-DMA (0: from the f32 image through registers)
+#endif
+
 constexpr int kMaxGroup = 4;      // the four FPN decoders run as one grouped launch
 constexpr int kConvBK = 32;       // K-step of the implicit GEMM (floats)
 constexpr int kConvNAlign = 128;  // packed weight rows are padded to a multiple of this

@@ -44,9 +44,11 @@ def _run(x, w, bias, stride, pad, code, out, up=None):
     L = nat.lib()
     sb, sc, sh, sw = x.stride()
     ws = nat.workspace("train_conv", x.device, L.fpc_conv2d_workspace_bytes_for(B, Ho, Wo, Cin, Cout, Kh, Kw, 0, 0, code))
-    nat.check(L.fpc_conv2d(x.data_ptr(), sb, sh, sw, sc, w.data_ptr(), None, nat.ptr(bias), None, nat.ptr(up), out.data_ptr(), None,
-                           B, H, W, Cin, Cout, Kh, Kw, stride, pad, 0, 0, 0, code, ws.data_ptr(), ws.numel(), nat.stream()),
-              "fpc_conv2d (training)")
+    # (the library resolves its zero page — a device global — for the CURRENT device: make that the tensor's)
+    with torch.cuda.device(x.device):
+        nat.check(L.fpc_conv2d(x.data_ptr(), sb, sh, sw, sc, w.data_ptr(), None, nat.ptr(bias), None, nat.ptr(up), out.data_ptr(), None,
+                               B, H, W, Cin, Cout, Kh, Kw, stride, pad, 0, 0, 0, code, ws.data_ptr(), ws.numel(), nat.stream()),
+                  "fpc_conv2d (training)")
 
 
 def conv_nhwc(x, w, bias, stride, pad, up=None):
@@ -64,6 +66,9 @@ def conv_nhwc(x, w, bias, stride, pad, up=None):
             cands += [-1, -2, -4]       # Winograd F(2x2,3x3): 4 waves, 8 waves, 8 waves all-DMA
             if SPLIT_PRECISION:
                 cands.append(-5)        # 8 waves, split-precision products
+                cands.append(-7)        # the same products as four waves of 512 registers, weights straight into registers (wino_w4.hip)
+                if Cout % 128 == 0:
+                    cands.append(-6)    # 128 output channels per workgroup (wino128.hip)
         if SPLIT_PRECISION and Kh == 1 and Kw == 1 and stride == 1 and pad == 0 and Cin in (64, 128) and Cout % 32 == 0:
             cands += [2000 + p for p in (1, 2, 4) if (Cout // 32) % p == 0]      # pixel-resident lateral product (lateral.hip)
         best = (float("inf"), 0)

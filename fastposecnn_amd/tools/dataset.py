@@ -219,12 +219,18 @@ class PngFramePrefetcher:
     def _decode_one(self, buf, dst):
         nat.check(nat.lib().fpc_png_decode(buf.ctypes.data, buf.size, dst.ctypes.data, dst.nbytes, 3), "fpc_png_decode")
 
+    def _read_and_decode(self, i, out):
+        """Pool task of batch i: read its files (the I/O of a cold page cache or slow storage stays off the consumer's
+        thread), then one decode task per FILE (a batch of 32 decoded by one worker kept 2 of 14 workers busy: 350 img/s at
+        batch 32).  Returns the per-file futures; the buffers stay referenced by them."""
+        bufs = [np.frombuffer(f, dtype=np.uint8) for f in self.read_batch(i)]
+        if len(bufs) != out.shape[0]:
+            raise ValueError(f"read_batch({i}) returned {len(bufs)} files for a batch of {out.shape[0]}")
+        return [self._pool.submit(self._decode_one, b, out[j]) for j, b in enumerate(bufs)]
+
     def _submit(self, i):
-        """One task per FILE (a batch of 32 decoded by one worker kept 2 of 14 workers busy: 350 img/s at batch 32)."""
-        files = self.read_batch(i)
         out = np.empty(self.shape, np.uint8)
-        bufs = [np.frombuffer(f, dtype=np.uint8) for f in files]
-        return out, bufs, [self._pool.submit(self._decode_one, b, out[j]) for j, b in enumerate(bufs)]
+        return out, self._pool.submit(self._read_and_decode, i, out)
 
     def __iter__(self):
         return self
@@ -236,8 +242,8 @@ class PngFramePrefetcher:
         if not self._pending:
             self._pool.shutdown(wait=False)
             raise StopIteration
-        out, _bufs, futs = self._pending.pop(0)
-        for f in futs:
+        out, reader = self._pending.pop(0)
+        for f in reader.result():      # (a reader never waits for its decode tasks inside the pool: no worker can starve them)
             f.result()
         return out
 
@@ -311,19 +317,18 @@ class NOCSDataset(torch.utils.data.Dataset):
         return len(self.images_fps)
 
     def get_image_paths_in_dir(self, dir_path, max_size=None):
-        """breadth-first over the directory tree, colour frames of a directory in the file system's listing order"""
-        total, eval_paths, i = [], [dir_path], 0
-        while i < len(eval_paths):
-            eval_path = eval_paths[i]
-            i += 1
-            files = [x for x in eval_path.iterdir() if x.is_file()]
-            color_images = [x for x in files if x.name.find('color') != -1 and x.suffix == '.png']
-            total += self.remove_empty_samples(color_images)
-            eval_paths += [x for x in eval_path.iterdir() if x.is_dir()]
-            if max_size is not None and len(total) >= max_size:
-                break
-        total = [x for x in total if x]
-        return total[:max_size] if max_size is not None else total
+        """The frames of the data set in the reference's order (F/tools/dataset.py:295-352): directories level by level
+        (breadth-first, children in the file system's listing order), inside a directory the `*color*.png` frames in
+        listing order, kept when their side file lists an instance of a wanted class; the walk stops after the first
+        directory that brings the count to `max_size`."""
+        from collections import deque
+        frames, todo = [], deque([dir_path])
+        while todo and (max_size is None or len(frames) < max_size):
+            here = todo.popleft()
+            entries = list(here.iterdir())
+            frames.extend(self.remove_empty_samples([e for e in entries if e.is_file() and e.suffix == '.png' and 'color' in e.name]))
+            todo.extend(e for e in entries if e.is_dir())
+        return frames if max_size is None else frames[:max_size]
 
     def remove_empty_samples(self, file_paths):
         good = []
@@ -387,29 +392,32 @@ class NOCSDataset(torch.utils.data.Dataset):
         return my_collate_fn([self[int(k)] for k in ids], device)
 
     def generate_agg_data(self, instances_mask, json_data):
-        """F/tools/dataset.py:373-434: per-instance ground truth in the order of the side file's instance_dict."""
-        h, w = instances_mask.shape
-        n = np.unique(instances_mask).shape[0] - 1
+        """Per-instance ground truth, one row per entry of the side file's instance_dict in file order
+        (F/tools/dataset.py:373-434): n = the number of instance ids present in the mask; class / symmetric ids, the
+        instance's binary mask, quaternion, scales / norm factor, and from the RT matrices the projected origin (flipped to
+        the other coordinate style), z, T and R (tools/data_manipulation.py).  Filled one fancy-indexed block per key."""
+        n = np.unique(instances_mask).size - 1
+        listed = list(json_data['instance_dict'].items())             # (instance id, class id)
+        k = len(listed)
+        inst = np.array([i for i, _ in listed]).reshape(k)
+        cls = np.array([c for _, c in listed], dtype=np.float64).reshape(k)
+        per_instance = dict(dm.extract_xyz_R_T_from_RTs(json_data['RTs'], self.INTRINSICS),      # xy, z, T, R
+                            quaternion=json_data['quaternions'], scales=json_data['scales'], RT=json_data['RTs'])
+
+        def block(values, *shape):
+            out = np.zeros((n,) + shape)
+            out[:k] = np.asarray(values, dtype=np.float64).reshape((-1,) + shape)[:k]
+            return out
+
         agg_data = {
-            'class_ids': np.zeros((n,)), 'symmetric_ids': np.zeros((n,)), 'instance_masks': np.zeros((n, h, w)),
-            'quaternion': np.zeros((n, 4)), 'scales': np.zeros((n, 3)), 'xy': np.zeros((n, 2)), 'z': np.zeros((n, 1)),
-            'T': np.zeros((n, 3)), 'R': np.zeros((n, 3, 3)), 'RT': np.zeros((n, 4, 4)),
+            'class_ids': block(cls), 'symmetric_ids': block(np.isin(cls, self.symmetric_classes)),
+            'instance_masks': block(instances_mask[None] == inst[:, None, None], *instances_mask.shape),
+            'quaternion': block(per_instance['quaternion'], 4),
+            'scales': block(per_instance['scales'], 3) / np.expand_dims(json_data['norm_factors'], axis=1),
+            'xy': block(per_instance['xy'], 2)[:, ::-1],              # (row, col) -> the other style
+            'z': block(per_instance['z'], 1), 'T': block(per_instance['T'], 3),
+            'R': block(per_instance['R'], 3, 3), 'RT': block(per_instance['RT'], 4, 4),
         }
-        json_data['quaternion'] = json_data['quaternions']
-        json_data['RT'] = json_data['RTs']
-        json_data.update(dm.extract_xyz_R_T_from_RTs(json_data['RTs'], self.INTRINSICS))
-        for enumerate_id, (instance_id, class_id) in enumerate(json_data['instance_dict'].items()):
-            for data_name in agg_data.keys():
-                if data_name == 'class_ids':
-                    agg_data[data_name][enumerate_id] = class_id
-                elif data_name == 'symmetric_ids':
-                    agg_data[data_name][enumerate_id] = 1 * (class_id in self.symmetric_classes)
-                elif data_name == 'instance_masks':
-                    agg_data[data_name][enumerate_id] = np.where(instances_mask == instance_id, 1, 0)
-                else:
-                    agg_data[data_name][enumerate_id] = np.array(json_data[data_name])[enumerate_id]
-        agg_data['scales'] /= np.expand_dims(json_data['norm_factors'], axis=1)
-        agg_data['xy'] = np.flip(agg_data['xy'], axis=1)           # (row, col) -> the other style
         return agg_data
 
 

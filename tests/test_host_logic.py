@@ -9,6 +9,7 @@ import ctypes
 import os
 import re
 import socket
+import subprocess
 import sys
 
 import numpy as np
@@ -520,3 +521,24 @@ def test_cpu_baseline_leaves_thread_settings_alone_and_names_its_threads():
     orc.set_threads(1)
     assert torch.get_num_threads() == before
     orc.set_threads(orc_before)
+
+
+def test_zero_edit_overlay_answers_import_lib(tmp_path):
+    """with fastposecnn_amd/overlay on PYTHONPATH a script that says `import lib` — from a directory
+    that has its OWN lib/ package next to it, as the reference's scripts do (F/inference.py:19) — gets this repo's mirror, with
+    the reference's module aliases; FPC_OVERLAY=0 gives the script's own package back."""
+    (tmp_path / "lib").mkdir()
+    (tmp_path / "lib" / "__init__.py").write_text("WHO = 'the script directory own lib'\n")
+    script = tmp_path / "inference_like.py"
+    script.write_text("import lib\n"
+                      "print(getattr(lib, 'WHO', None) or lib.pose_regressor.__file__)\n"
+                      "print(sorted(n for n in ('gtf', 'mg', 'pose_regressor', 'loss', 'metrics') if hasattr(lib, n)))\n")
+    env = dict(os.environ, PYTHONPATH=os.path.join(REPO, "fastposecnn_amd", "overlay"))
+    out = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True, timeout=300, cwd=str(tmp_path))
+    assert out.returncode == 0, out.stderr[-2000:]
+    first, second = out.stdout.strip().splitlines()[-2:]
+    assert os.path.realpath(first) == os.path.realpath(os.path.join(REPO, "fastposecnn_amd", "lib", "pose_regressor.py")), out.stdout
+    assert second == "['gtf', 'loss', 'metrics', 'mg', 'pose_regressor']"
+    off = subprocess.run([sys.executable, str(script)], env=dict(env, FPC_OVERLAY="0"), capture_output=True, text=True, timeout=300,
+                         cwd=str(tmp_path))
+    assert off.returncode == 0 and "the script directory own lib" in off.stdout, off.stdout + off.stderr[-500:]
