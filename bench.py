@@ -799,10 +799,15 @@ def attach_mfma_busy(backbone, name):
 
 
 def load_profile_json(name):
+    """A counter file under profiles/ that names the commit it was measured at; one without a commit is REFUSED (round 5 attached
+    three files with `"commit": null`: nothing to check the kernels against)."""
     path = os.path.join(REPO, "profiles", name)
     if os.path.exists(path):
         with open(path) as f:
-            return json.load(f)
+            prof = json.load(f)
+        if prof.get("commit"):
+            return prof
+        print(f"bench.py: profiles/{name} carries no commit: not attached", file=sys.stderr)
     return None
 
 
@@ -909,7 +914,7 @@ def main():
         roof = vote_roofline(ctx["model_gpu"], ctx["cat"], ctx["n_inst"], max(5, min(args.steps, 20)),
                              f"batch {args.batch}, hn {args.hn}, {ctx['n_inst']} instances")
         roof["measured_copy_GBps"] = measure_copy_ceiling(dev)
-        attach_profiled_counters(roof, "r04_vote_bits_traffic_b1_hn1000.json" if (args.hn == 1000 and args.batch == 1) else None)
+        attach_profiled_counters(roof, "r06_vote_bits_traffic_b1_hn1000.json" if (args.hn == 1000 and args.batch == 1) else None)
         roof["note"] = ("HIP events on the launch stream around the whole call, live in this run; `traffic` and `valu` are PMC "
                         "counters of a separate profiled run of the same call (`from_profile` names the file and the commit it was "
                         "taken at): rocprofv3 cannot collect them inside this process")
@@ -947,8 +952,8 @@ def main():
         }
         if "backbone" in res:
             line["backbone"] = res["backbone"]
-            attach_mfma_busy(line["backbone"], "r05_conv_pmc_b1.json" if (args.encoder == "resnet18" and args.batch == 1) else
-                             ("r05_conv_pmc_c3.json" if (args.encoder == "resnet34" and args.batch == 32) else None))
+            attach_mfma_busy(line["backbone"], "r06_conv_pmc_b1.json" if (args.encoder == "resnet18" and args.batch == 1) else
+                             ("r06_conv_pmc_c3.json" if (args.encoder == "resnet34" and args.batch == 32) else None))
 
     if world == 1:
         # the training value of hn on a 32-frame batch (F/config.py:93): where the sequence is closest to its HBM bound
@@ -960,10 +965,10 @@ def main():
             import aggregation_layer as al
             cat32["mask"] = al.attach_fg_bits(cat32["mask"].to(torch.int64).contiguous())
             line["roofline_hn128"] = vote_roofline(ctx["model_gpu"], cat32, 6 * 32, 9, "batch 32, hn 128, 192 instances")
-            attach_profiled_counters(line["roofline_hn128"], "r04_vote_bits_traffic_b32_hn128.json")
+            attach_profiled_counters(line["roofline_hn128"], "r06_vote_bits_traffic_b32_hn128.json")
             line["roofline_hn128_f32_masks"] = vote_roofline(ctx["model_gpu"], cat32, 6 * 32, 9, "batch 32, hn 128, 192 instances, f32 masks",
                                                              use_bits=False)
-            attach_profiled_counters(line["roofline_hn128_f32_masks"], "r04_vote_traffic_b32_hn128.json")
+            attach_profiled_counters(line["roofline_hn128_f32_masks"], "r06_vote_traffic_b32_hn128.json")
             line["post_network"] = post_network_rates(ctx["model_gpu"], ctx["cat"], ctx["n_inst"], cat32, 6 * 32)
             hp128.HV_NUM_OF_HYPOTHESES = args.hn
             del cat32
@@ -1014,8 +1019,8 @@ def main():
             if "backbone" in r3:
                 c3["backbone"] = r3["backbone"]
             c3["roofline"] = vote_roofline(ctx3["model_gpu"], ctx3["cat"], ctx3["n_inst"], 5, f"batch 32, hn {args.hn}, 192 instances")
-            attach_profiled_counters(c3["roofline"], "r04_vote_bits_traffic_b32_hn1000.json" if args.hn == 1000 else None)
-            attach_mfma_busy(c3.get("backbone"), "r05_conv_pmc_c3.json")
+            attach_profiled_counters(c3["roofline"], "r06_vote_bits_traffic_b32_hn1000.json" if args.hn == 1000 else None)
+            attach_mfma_busy(c3.get("backbone"), "r06_conv_pmc_c3.json")
             c3["roofline"]["bound_note"] = ("this configuration's count kernel is bound by vector-ALU issue, not HBM: 2 instructions per "
                                             "(entry, hypothesis) register pair behind 1/512 MFMA, ~3.0e9 pairs per call (`valu`); "
                                             "tools_dev/r4_vote_fused/README.md")
