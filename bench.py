@@ -497,6 +497,7 @@ def run_inference(args, encoder, Bq, hn, steps, warmup, world, rank, dev, want_b
     hp.ENGINE_TUNE_MODE = args.tune_mode
     hp.ENGINE_SPLIT_PRECISION = (bool(int(os.environ.get('FPC_SPLIT_PRECISION', '1')))      # 0: plain f32 MFMA products only
                                  if split_precision is None else bool(split_precision))
+    hp.ENGINE_SPLIT_F16 = bool(int(os.environ.get('FPC_SPLIT_F16', '1')))      # 0: split-precision sites use the bf16 x 3 forms only
     hp.ENGINE_GRAPH = bool(int(os.environ.get('FPC_ENGINE_GRAPH', '1')))      # HIP graph replay of the frame-invariant launches
     torch.manual_seed(0)
     model = L.pose_regressor.MODELS[hp.MODEL].load_from_ckpt(None, hp).eval()

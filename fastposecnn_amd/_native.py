@@ -77,6 +77,7 @@ _SIGNATURES = {
     "fpc_net_conv_count": (_i, [_vp]),
     "fpc_net_conv_plan": (_i, [_vp, _i, ctypes.POINTER(_i)]),
     "fpc_net_copy_plans": (_i, [_vp, _vp]),
+    "fpc_net_force_winograd": (_i, [_vp, _i]),
     "fpc_net_flops": (_i, [_vp, ctypes.POINTER(ctypes.c_double)]),
     "fpc_net_tensor": (_i, [_vp, ctypes.c_char_p, ctypes.POINTER(_vp), ctypes.POINTER(_i), ctypes.POINTER(_i),
                             ctypes.POINTER(_i)]),

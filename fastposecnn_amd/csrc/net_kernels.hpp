@@ -146,6 +146,10 @@ int launch_wino_pack_c128(const float* w_oihw, float* packed, int Cout, int Cin,
 // wino_w4.hip: the split-precision form as four waves of 512 registers (8 x 8 tile patch x 64 channels, weights straight into the
 // operand registers; .w = the k_wino_pack_bf3 image, tby = ceil(ceil(H/2)/8))
 int launch_conv_wino_w4(const WinoArgs& a, int groups, hipStream_t s);
+// wino_h2.hip: the four-wave form on two fp16 pieces per operand (range-limited, see the file; .w = the k_wino_pack_h2 image
+// incl. its two-float tail: 16 * Cout * Cin + 2 floats)
+int launch_conv_wino_h2(const WinoArgs& a, int groups, hipStream_t s);
+int launch_wino_pack_h2(const float* w_oihw, float* packed, int Cout, int Cin, hipStream_t s);
 int launch_conv(const ConvArgs& a, int groups, hipStream_t s);
 int launch_conv_splitk_epilogue(const ConvArgs& a, int groups, hipStream_t s);
 int launch_maxpool3x3s2(const float* in, float* out, int B, int Hi, int Wi, int C, int Ho, int Wo, hipStream_t s);

@@ -32,7 +32,7 @@ class NetEngine:
         self.generation = 0          # the owner's count of unversioned writes when this plan was last bound (pose_regressor.py)
         self.bind(model)
         if split_precision:
-            nat.check(L.fpc_net_set_split_precision(h, 1), "fpc_net_set_split_precision")
+            nat.check(L.fpc_net_set_split_precision(h, int(split_precision)), "fpc_net_set_split_precision")
         if autotune:
             # one (discarded) forward that times every candidate tiling per convolution on this device
             nat.check(L.fpc_net_autotune_next(h, int(tune_mode)), "fpc_net_autotune_next")
@@ -88,6 +88,13 @@ class NetEngine:
     def copy_plans_from(self, other):
         """Run this engine on the plans `other` (same network and frame size, another batch) was autotuned to."""
         nat.check(self._lib.fpc_net_copy_plans(self._h, other._h), "fpc_net_copy_plans")
+
+    def force_winograd(self, form):
+        """Every 3x3 / stride-1 site on Winograd form `form` (8 = fp16 x 2 pieces); returns the number of sites changed."""
+        rc = self._lib.fpc_net_force_winograd(self._h, int(form))
+        if rc < 0:
+            nat.check(rc, "fpc_net_force_winograd")
+        return rc
 
     def flops(self):
         """(direct-convolution FLOP, FLOP the current plans execute, Winograd share) of one forward over the batch."""

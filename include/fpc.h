@@ -361,7 +361,13 @@ int fpc_net_autotune_next(fpc_net_t* net, int mode /* 0: minimise each conv's la
  * bits) and the six partial products with i + j <= 4 on v_mfma_f32_32x32x16_bf16, accumulated in f32: every kept product
  * is exact, the dropped ones are < 2^-23 of the term, so the result has f32-level accuracy (2.4e-7 of max|ref| against
  * float64, like another summation order) without being bit-identical to the f32 product chain.  Set before
- * fpc_net_autotune_next.  fpc_net_conv_plan reports -5 for a split-precision Winograd site. */
+ * fpc_net_autotune_next.  fpc_net_conv_plan reports -5 / -6 / -7 for a split-precision Winograd site (8 waves / 128 channels per
+ * workgroup / four waves of 512 registers).
+ * 2 (round 6): additionally the fp16 x 2 Winograd form (csrc/wino_h2.hip, reported as -8): two fp16 pieces per operand, three
+ * products in two matrix instructions.  Weights are scaled by a power of two on the device; a transformed ACTIVATION v is
+ * represented to 2^-22 |v| while |v| >= 2^-3, to 2^-25 absolute below, and saturates beyond 1.3e5 — f32-level accuracy for
+ * activations of ordinary scale (the tests hold it to the bars of every other form), NOT for tensors of tiny or huge values.  The
+ * Python front end uses 2 unless HPARAM.ENGINE_SPLIT_F16 is False. */
 int fpc_net_set_split_precision(fpc_net_t* net, int on);
 /* HIP graph replay (default 0).  1: after autotuning, the frame-invariant launches of fpc_net_forward (everything
  * between the image conversion and the final upsample / class compression, ~57 kernels on the plan's workspace) are
@@ -373,6 +379,10 @@ int fpc_net_conv_plan(const fpc_net_t* net, int i, int* out5);
  * size, any batch sizes — a small batch then runs on the kernels a larger one was autotuned to (tests/test_gpu_net.py: the
  * headline configuration's plan set against float64 on two frames).  Plans whose split-K partials do not fit dst keep dst's own. */
 int fpc_net_copy_plans(fpc_net_t* dst, const fpc_net_t* src);
+/* Puts every 3x3 / stride-1 site on Winograd form `form` (1..8: fpc_conv2d's -form; 6 only where Cout % 128 == 0; other sites keep
+ * their plan) — tests hold the whole network on ONE form (8: every eligible product on fp16 x 2 pieces) to the float64 bars.
+ * Returns the number of sites changed or a negative code. */
+int fpc_net_force_winograd(fpc_net_t* net, int form);
 /* FLOP of one forward over the batch under the current plans: out3 = {2 x MACs of the direct convolutions (what the
  * reference's cuDNN path executes), multiply-add FLOP the plans execute (Winograd sites: / 2.25), Winograd share}. */
 int fpc_net_flops(const fpc_net_t* net, double* out3);

@@ -158,6 +158,14 @@ CONV_CASES = [
     (1, 8, 7, 9, 64, 3, 1, 1, (0, 0, -7), "bias_relu"),         # a single K-step
     (1, 16, 20, 24, 64, 3, 1, 1, (0, 0, -7), "bias_relu"),      # two K-steps
     (3, 24, 32, 32, 192, 3, 1, 1, (0, 0, -7), "gn"),            # three K-steps, patches that tile the image exactly, three channel blocks
+    # the four-wave form on two fp16 pieces per operand (nsplit = -8, wino_h2.hip): weights scaled by a power of two on the device,
+    # activations as they come (N(0, 1) here) — held to the same bar as every other form
+    (1, 64, 30, 40, 64, 3, 1, 1, (0, 0, -8), "bn_relu_res"),
+    (2, 256, 15, 20, 128, 3, 1, 1, (0, 0, -8), "gn"),
+    (1, 128, 34, 50, 128, 3, 1, 1, (0, 0, -8), "gn"),
+    (1, 8, 7, 9, 64, 3, 1, 1, (0, 0, -8), "bias_relu"),         # a single K-step
+    (1, 16, 20, 24, 64, 3, 1, 1, (0, 0, -8), "bias_relu"),      # two K-steps
+    (3, 24, 32, 32, 192, 3, 1, 1, (0, 0, -8), "gn"),            # three K-steps, three channel blocks
 ]
 
 
@@ -710,6 +718,42 @@ def test_split_precision_error_is_at_the_plain_f32_level(lib, dev):
                           for k in ("mask", "quaternion", "scales", "xy", "z"))
     assert errs[True] <= 2.0 * errs[False] + 1e-7 and errs[False] <= 2.0 * errs[True] + 1e-7, errs
     assert errs[True] <= 2e-5, errs
+
+
+def test_every_winograd_site_on_fp16_pieces_meets_the_float64_bars(lib, dev):
+    """The fp16 x 2 Winograd form (wino_h2.hip) FORCED onto every 3x3 / stride-1 site of the network (ResNet34: 29 encoder sites + 7 grouped
+    decoder sites = 28 convolutions) — not just where the autotuner happens to pick it: the logits against the float64 CPU module path stay inside
+    north_star's 1e-4 of each tensor's scale and within 4x of the all-bf16x3 error (two fp16 pieces carry 22 significant bits of an
+    operand of ordinary scale; the bf16 x 3 pieces 24).  HPARAM.ENGINE_SPLIT_F16 = False keeps the form out of the plans."""
+    import copy
+    from fastposecnn_amd import synth
+    x = torch.stack([synth.make_image(i, 160, 224) for i in range(2)])
+    m, hp = _model(lib, dev, "resnet34")
+    ref_m = copy.deepcopy(m).double()
+    ref_m.HPARAM = copy.copy(hp); ref_m.HPARAM.USE_NATIVE_ENGINE = False
+    with torch.no_grad():
+        ref = ref_m.pure_model_forward(x.double())
+    del ref_m
+    m = m.to(dev)
+    errs = {}
+    for form in (8, 7):
+        with torch.no_grad():
+            m(x.to(dev))
+            eng = next(iter(m._engines.values()))
+            n = eng.force_winograd(form)
+            assert n >= 30, n            # 29 encoder sites + the 7 decoder sites (one grouped launch for the four decoders each)
+            assert sum(1 for p in eng.conv_plans() if p[2] == -form) >= n
+            out = m(x.to(dev))
+        errs[form] = max((out["logits"][k].cpu().double() - ref[k]).abs().max().item() / max(1.0, ref[k].abs().max().item())
+                         for k in ("mask", "quaternion", "scales", "xy", "z"))
+    assert errs[8] <= 1e-4 and errs[7] <= 1e-4, errs
+    assert errs[8] <= 2e-5 and errs[8] <= 4.0 * errs[7] + 1e-6, errs
+    m2, hp2 = _model(lib, dev, "resnet34")
+    hp2.ENGINE_SPLIT_F16 = False
+    m2 = m2.to(dev)
+    with torch.no_grad():
+        m2(x.to(dev))
+    assert not any(p[2] == -8 for p in next(iter(m2._engines.values())).conv_plans())
 
 
 def test_two_pass_merge_head_equals_the_one_pass_form_to_rounding(lib, dev, monkeypatch):
