@@ -481,7 +481,8 @@ def check_gather(model_gpu, gatherer, cat, Bq, world, rank, cap, dev):
     return bool(flag.item() > 0.5)
 
 
-def run_inference(args, encoder, Bq, hn, steps, warmup, world, rank, dev, want_backbone=True, split_precision=None, coalesce=1, tune_trials=1):
+def run_inference(args, encoder, Bq, hn, steps, warmup, world, rank, dev, want_backbone=True, split_precision=None, coalesce=1, tune_trials=1,
+                  split_f16=None):
     """The timed hot path for one (encoder, batch) configuration.  Returns a dict of measurements and the objects
     later sections reuse."""
     import torch
@@ -497,7 +498,8 @@ def run_inference(args, encoder, Bq, hn, steps, warmup, world, rank, dev, want_b
     hp.ENGINE_TUNE_MODE = args.tune_mode
     hp.ENGINE_SPLIT_PRECISION = (bool(int(os.environ.get('FPC_SPLIT_PRECISION', '1')))      # 0: plain f32 MFMA products only
                                  if split_precision is None else bool(split_precision))
-    hp.ENGINE_SPLIT_F16 = bool(int(os.environ.get('FPC_SPLIT_F16', '1')))      # 0: split-precision sites use the bf16 x 3 forms only
+    hp.ENGINE_SPLIT_F16 = (bool(int(os.environ.get('FPC_SPLIT_F16', '1')))      # 0: split-precision sites use the bf16 x 3 forms only
+                           if split_f16 is None else bool(split_f16))
     hp.ENGINE_GRAPH = bool(int(os.environ.get('FPC_ENGINE_GRAPH', '1')))      # HIP graph replay of the frame-invariant launches
     torch.manual_seed(0)
     model = L.pose_regressor.MODELS[hp.MODEL].load_from_ckpt(None, hp).eval()
@@ -819,7 +821,7 @@ def promote_config3(line, c3, r3, args):
     measurements under `configs.config2`.  The 32-frame vote rooflines (`roofline_hn128*`), `post_network` and `train` are
     not tied to either backbone and stay where they were."""
     moved = ("value", "ms_per_step", "repeats", "ms_per_step_min_max", "config", "roofline", "backbone", "cpu_baseline",
-             "plain_f32_products", "frames_per_launch", "steps", "warmup")
+             "plain_f32_products", "frames_per_launch", "steps", "warmup")      # (config 3's own `bf16x3_products` goes to the top level)
     c2 = {"metric": "img/s end-to-end 640x480 inference", "unit": "img/s", "dtype": "f32"}
     for k in moved:
         if k in line:
@@ -844,7 +846,7 @@ def promote_config3(line, c3, r3, args):
                    "img_per_s_from_png_files": r3.get("png_files_img_per_s"), **shared},
         "roofline": c3["roofline"],
     }
-    for k in ("backbone", "cpu_baseline"):
+    for k in ("backbone", "cpu_baseline", "bf16x3_products"):
         if k in c3:
             top[k] = c3[k]
     for k in ("higher_is_better", "scaling", "vs_baseline", "dtype", "data", "unit"):
@@ -933,10 +935,16 @@ def main():
                        "trial_rates_img_per_s": res.get("trial_rates_img_per_s"),
                        "pose_gather": res["pose_gather"],
                        "matrix_products": ("f32 operands, f32 accumulation, f32 results (dtype f32).  Where the autotuner finds it "
-                                           "faster a convolution's products run as the EXACT three-way bf16 split of both operands "
-                                           "(six partial products on v_mfma_f32_32x32x16_bf16, dropped terms < 2^-23: 2.4e-7 of "
-                                           "max|ref| against float64, the same 1e-4 parity bar, tests/test_gpu_net.py); "
-                                           "FPC_SPLIT_PRECISION=0 keeps every product on v_mfma_f32_32x32x2_f32")
+                                           "faster a convolution's products run in SPLIT PRECISION on the 16-bit matrix instructions: (a) the "
+                                           "exact three-way bf16 split of both operands, six partial products on v_mfma_f32_32x32x16_bf16, "
+                                           "dropped terms < 2^-23 — any operand range; (b) round 6, 3x3 / stride-1 sites only "
+                                           "(csrc/wino_h2.hip): two fp16 pieces per operand (22 significant bits), three products in two "
+                                           "v_mfma_f32_32x32x16_f16, weights scaled by a power of two on the device, activations as they "
+                                           "come: 2^-22 relative for |v| >= 2^-3, 2^-25 absolute below, saturation beyond 1.3e5 — f32-level "
+                                           "for activations of ordinary scale, held to the same bars (2e-5 per convolution, 1e-4 of the "
+                                           "logits against float64 with EVERY eligible site forced onto it: tests/test_gpu_net.py).  "
+                                           "FPC_SPLIT_F16=0 (HPARAM.ENGINE_SPLIT_F16 = False) keeps (a) only — `bf16x3_products` is that "
+                                           "measurement; FPC_SPLIT_PRECISION=0 keeps every product on v_mfma_f32_32x32x2_f32")
                                           if os.environ.get("FPC_SPLIT_PRECISION", "1") != "0" else
                                           "plain f32 matrix products (v_mfma_f32_32x32x2_f32) everywhere: FPC_SPLIT_PRECISION=0",
                        "post_network_input": "synthetic vote-bench fixture (SURVEY.md 8d), not the random-weight network's output",
@@ -1025,6 +1033,16 @@ def main():
             c3["roofline"]["bound_note"] = ("this configuration's count kernel is bound by vector-ALU issue, not HBM: 2 instructions per "
                                             "(entry, hypothesis) register pair behind 1/512 MFMA, ~3.0e9 pairs per call (`valu`); "
                                             "tools_dev/r4_vote_fused/README.md")
+            if args.promote and not args.no_plain_f32 and os.environ.get("FPC_SPLIT_F16", "1") != "0" and os.environ.get("FPC_SPLIT_PRECISION", "1") != "0":
+                # the same configuration with the fp16 x 2 Winograd form switched off: every split-precision site on bf16 x 3 pieces
+                torch.cuda.empty_cache()
+                rb3, ctxb3 = run_inference(args, "resnet34", 32, args.hn, max(6, st // 3), 2, 1, 0, dev, split_f16=False)
+                c3["bf16x3_products"] = {"value": rb3["value"], "unit": "img/s", "ms_per_step": rb3["ms_per_step"], "steps": rb3["steps"],
+                                         "backbone": {k: rb3["backbone"][k] for k in ("ms", "achieved", "frac")} if "backbone" in rb3 else None,
+                                         "note": "HPARAM.ENGINE_SPLIT_F16 = False: split-precision sites may only use the three-way bf16 split "
+                                                 "(no operand-range limit); a shorter timed region than `value`'s"}
+                del rb3, ctxb3
+                torch.cuda.empty_cache()
             if args.promote and not args.no_cpu_baseline:
                 one3 = {k: v[:1] for k, v in ctx3["cat_cpu"].items()}
                 c3["cpu_baseline"] = cpu_baseline(ctx3["model"].to("cpu"), ctx3["image"][:1], one3, args.hn,
