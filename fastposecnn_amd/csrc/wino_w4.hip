@@ -340,17 +340,31 @@ __global__ __launch_bounds__(256, 1) void k_conv_wino_w4(const WinoArgs a) {
     const int n = nb * kBN + oq * 4;
     const f32x4 e_sc = P.scale ? *reinterpret_cast<const f32x4*>(P.scale + n) : f32x4{1.f, 1.f, 1.f, 1.f};
     const f32x4 e_sh = P.shift ? *reinterpret_cast<const f32x4*>(P.shift + n) : f32x4{0.f, 0.f, 0.f, 0.f};
+    // the residual of this thread's 4 x 4 outputs is requested BEFORE the output transform's barriers (one workgroup per CU: nothing
+    // else hides that latency; k_conv_wino does the same)
+    f32x4 e_res[4][4];
+#pragma unroll
+    for (int tp = 0; tp < 4; ++tp)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int ot = otl + 16 * tp;
+            const int y = 2 * (ty0 + (ot >> 3)) + (q >> 1), x = 2 * (tx0 + (ot & 7)) + (q & 1);
+            e_res[tp][q] = (P.res && y < H && x < W) ? *reinterpret_cast<const f32x4*>(P.res + ((size_t)b * HW + (size_t)y * W + x) * Cout + n)
+                                                     : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
     __syncthreads();
+    float* const zb = lds + ((wi * 2) * kNT + 4 * lh) * kBN + li;
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int m = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                // one base register per lane + a compile-time offset (< 64 KB: the instruction's immediate) per store
+                const int mc = mt * 32 + (r & 3) + 8 * (r >> 2);
                 const float m0 = acc[0][mt][nt][r], m1 = acc[1][mt][nt][r], m2 = acc[2][mt][nt][r], m3 = acc[3][mt][nt][r];
-                lds[((wi * 2 + 0) * kNT + m) * kBN + nt * 32 + li] = m0 + m1 + m2;
-                lds[((wi * 2 + 1) * kNT + m) * kBN + nt * 32 + li] = m1 - m2 - m3;
+                zb[(0 * kNT + mc) * kBN + nt * 32] = m0 + m1 + m2;
+                zb[(1 * kNT + mc) * kBN + nt * 32] = m1 - m2 - m3;
             }
     __syncthreads();
     f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};
@@ -373,7 +387,7 @@ __global__ __launch_bounds__(256, 1) void k_conv_wino_w4(const WinoArgs a) {
                 if (P.scale) val = val * e_sc;
                 val = val + e_sh;
                 const size_t o = ((size_t)b * HW + (size_t)y * W + x) * Cout + n;
-                if (P.res) val += *reinterpret_cast<const f32x4*>(P.res + o);
+                if (P.res) val += e_res[tp][2 * rr + cc];
                 if (a.relu) { val[0] = fmaxf(val[0], 0.f); val[1] = fmaxf(val[1], 0.f); val[2] = fmaxf(val[2], 0.f); val[3] = fmaxf(val[3], 0.f); }
                 *reinterpret_cast<f32x4*>(P.out + o) = val;
                 s1 += val;
