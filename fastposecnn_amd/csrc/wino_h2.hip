@@ -1,14 +1,14 @@
 // wino_h2.hip — k_conv_wino_h2: the four-wave Winograd F(2x2, 3x3) convolution (wino_w4.hip) on TWO fp16 pieces per operand
-// instead of three bf16 pieces: three products in two matrix instructions per K-step instead of six in three (round 6).
+// instead of three bf16 pieces: four products in two matrix instructions per K-step instead of six in three (round 6).
 //
 // Why.  The split-precision forms are bound by instruction issue and by chip power: per K-step of 8 channels and
 // 64 x 64 (tiles x channels) the bf16 x 3 form issues 48 matrix instructions, ~330 vector instructions (176 of them the three-way
 // split, 96 operand moves) and streams 48 KB of weights.  With fp16 pieces an f32 operand needs TWO: x = h1 + h2 + rest with
-// |rest| <= 2^-22 |x| (11 + 11 significant bits; truncating conversions, residuals exact in f32), and of the four piece products
-// h1 g1, h1 g2 and h2 g1 are kept (h2 g2 <= 2^-22 of the term): A = {h1, h1} x B = {g1, g2} and A = {h2, 0} x B = {g1, g2} — the
-// SAME 16-byte weight fragment serves both, so a K-step is 32 matrix instructions, ~190 vector instructions (a pair of values
-// splits in 7: v_cvt_pkrtz_f16_f32, two conversions back, two subtractions, v_cvt_pkrtz again, one copy; the zero half of
-// {h2, 0} is written once per workgroup) and 32 KB of weights; no {b3} fragment, no operand rebuild.
+// |rest| <= 2^-22 |x| (11 + 11 significant bits; truncating conversions, residuals exact in f32).  All four piece products are
+// kept: A = {h1, h1} x B = {g1, g2} and A = {h2, h2} x B = {g1, g2} — (h1 + h2)(g1 + g2) exactly, f32 accumulation; the SAME
+// 16-byte weight fragment serves both, so a K-step is 32 matrix instructions, ~200 vector instructions (a pair of values
+// splits in 8: v_cvt_pkrtz_f16_f32, two conversions back, two subtractions, v_cvt_pkrtz again, two copies) and 32 KB of
+// weights; no {b3} fragment, no operand rebuild.
 //
 // Range (what fp16 pieces cost).  fp16 spans 2^-24 .. 65504.  WEIGHTS: k_wino_pack_h2 scales the transformed weights of a
 // convolution by a power of two s (from max |w| of the convolution, found on the device) so that max |U s| < 2^13, and the kernel
@@ -184,7 +184,7 @@ __global__ __launch_bounds__(256, 1) void k_conv_wino_h2(const WinoArgs a) {
     __syncthreads();
 
     // operands of the current step's transformed fragments, as the matrix instructions take them: TA1[j][mt] = {h1, h1},
-    // TA2[j][mt] = {h2, 0} (four channels per piece; the zero half is written here, once); transformed values vn[mt][j] of the step
+    // TA2[j][mt] = {h2, h2} (four channels per piece); transformed values vn[mt][j] of the step
     // whose pieces are being built (xi 3's wait there across the loop's back edge)
     u32x4 TA1[4][2], TA2[4][2];
     f32x4 vn[2][4];
@@ -197,7 +197,7 @@ __global__ __launch_bounds__(256, 1) void k_conv_wino_h2(const WinoArgs a) {
         const unsigned k1_ = __builtin_bit_cast(unsigned, h_);                                                \
         const unsigned k2_ = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(r0_, r1_));              \
         asm volatile("" :: "v"(k1_), "v"(k2_));                                                               \
-        TA1[J][MT][PAIR] = k1_; TA1[J][MT][2 + (PAIR)] = k1_; TA2[J][MT][PAIR] = k2_;                         \
+        TA1[J][MT][PAIR] = k1_; TA1[J][MT][2 + (PAIR)] = k1_; TA2[J][MT][PAIR] = k2_; TA2[J][MT][2 + (PAIR)] = k2_; \
     } while (0)
 #pragma unroll
     for (int j = 0; j < 4; ++j)
@@ -229,7 +229,7 @@ __global__ __launch_bounds__(256, 1) void k_conv_wino_h2(const WinoArgs a) {
         const float* In = lds + (cur ^ 1) * kInFloats;
         f32x4 da[2][4], db[2][4], e[2][4];
         __builtin_amdgcn_s_setprio(1);
-        // Slot sl = 8 j + 4 g + 2 mt + nt: g = 0: h1 g1 + h1 g2, g = 1: h2 g1 (the zero half of {h2, 0} meets g2).  One item per slot:
+        // Slot sl = 8 j + 4 g + 2 mt + nt: g = 0: h1 g1 + h1 g2, g = 1: h2 g1 + h2 g2.  One item per slot:
         //   sl  0- 3  fragment reads of step kb + 1 (two columns of one tile half each) + the split of THIS step's xi 3 (one pair of
         //             values each: half 0 pairs 0, 1, half 1 pairs 0, 1)
         //   sl  4-11  row transform e = da + sgn db (one column of one half each)      sl 12-19  column transform vn (one xi of one half each)
