@@ -29,8 +29,25 @@ from fastposecnn_amd import _native as nat
 
 ENABLED = bool(int(os.environ.get("FPC_TRAIN_NATIVE_CONV", "1")))
 SPLIT_PRECISION = bool(int(os.environ.get("FPC_SPLIT_PRECISION", "1")))      # the bf16 x 3 product forms may be chosen
+SPLIT_F16 = SPLIT_PRECISION and bool(int(os.environ.get("FPC_SPLIT_F16", "1")))      # ... and, for forward convolutions, the fp16 x 2 Winograd form
 _plan_cache = {}            # (device index, B, Cin, H, W, Cout, k, stride, pad) -> nsplit code of fpc_conv2d
-counters = {"fwd_native": 0, "dgrad_native": 0, "wgrad_native": 0, "dgrad_aten": 0, "wgrad_aten": 0}
+counters = {"fwd_native": 0, "dgrad_native": 0, "wgrad_native": 0, "dgrad_aten": 0, "wgrad_aten": 0, "wgrad_direct": 0}
+
+
+# Weight-gradient sinks (round 6): an optimiser that keeps `p.grad` as views of one flat buffer (train_parallel.py) registers
+# {weight data pointer -> GradSink}; the weight-gradient kernel then writes STRAIGHT into that view and the autograd function returns
+# None for the weight — no temporary, no AccumulateGrad add launch per convolution (~70 of the ~270 add launches of a step), the
+# sink's callback stands in for the post-accumulate hook.  A weight used twice in a step falls back to the ordinary path (the
+# second gradient is returned and accumulated by autograd).
+class GradSink:
+    __slots__ = ("view", "callback", "written", "owner")
+
+    def __init__(self, view, callback, owner):
+        import weakref
+        self.view, self.callback, self.written, self.owner = view, callback, False, weakref.ref(owner)
+
+
+grad_sinks = {}
 
 
 def _channels_last(t):
@@ -51,14 +68,14 @@ def _run(x, w, bias, stride, pad, code, out, up=None):
                   "fpc_conv2d (training)")
 
 
-def conv_nhwc(x, w, bias, stride, pad, up=None):
+def conv_nhwc(x, w, bias, stride, pad, up=None, allow_f16=False):
     """x [B,Cin,H,W] channel-last, w OIHW contiguous -> [B,Cout,Ho,Wo] channel-last, on the engine's kernels.
     up [B,Cout,Ho/2,Wo/2] channel-last contiguous: added nearest-x2 upsampled in the kernel's epilogue (the FPN top-down merge)."""
     B, Cin, H, W = x.shape
     Cout, _, Kh, Kw = w.shape
     Ho, Wo = (H + 2 * pad - Kh) // stride + 1, (W + 2 * pad - Kw) // stride + 1
     out = torch.empty((B, Cout, Ho, Wo), dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
-    key = (x.device.index, B, Cin, H, W, Cout, Kh, stride, pad)
+    key = (x.device.index, B, Cin, H, W, Cout, Kh, stride, pad, bool(allow_f16))
     code = _plan_cache.get(key)
     if code is None:
         cands = [0] + ([1000] if SPLIT_PRECISION else [])      # heuristic tiling; the same with split-precision products
@@ -69,6 +86,9 @@ def conv_nhwc(x, w, bias, stride, pad, up=None):
                 cands.append(-7)        # the same products as four waves of 512 registers, weights straight into registers (wino_w4.hip)
                 if Cout % 128 == 0:
                     cands.append(-6)    # 128 output channels per workgroup (wino128.hip)
+                if allow_f16 and SPLIT_F16:
+                    cands.append(-8)    # two fp16 pieces per operand (wino_h2.hip): FORWARD convolutions only — their operand is an
+                    #                     activation of ordinary scale; a data gradient's operand is dy, whose values are tiny
         if SPLIT_PRECISION and Kh == 1 and Kw == 1 and stride == 1 and pad == 0 and Cin in (64, 128) and Cout % 32 == 0:
             cands += [2000 + p for p in (1, 2, 4) if (Cout // 32) % p == 0]      # pixel-resident lateral product (lateral.hip)
         best = (float("inf"), 0)
@@ -155,7 +175,13 @@ def _conv_backward(x, w, gy, stride, pad, needs, has_bias):
         L = nat.lib()
         B, _, H, W = x.shape
         Ho, Wo = gy.shape[2], gy.shape[3]
-        gw = torch.empty_like(w)
+        sink = grad_sinks.get(w.data_ptr()) if Cw == Cout else None
+        if sink is not None and sink.owner() is None:        # its optimiser is gone: the address may belong to another tensor now
+            del grad_sinks[w.data_ptr()]
+            sink = None
+        if sink is not None and (sink.written or sink.view.shape != w.shape or not sink.view.is_contiguous()):
+            sink = None
+        gw = sink.view if sink is not None else torch.empty_like(w)
         sb, sc, sh, sw = x.stride()
         ws = nat.workspace("train_wgrad", x.device, L.fpc_conv2d_wgrad_workspace_bytes(B, Ho, Wo, Cin, Cw, Kh, Kw))
         wgrad = L.fpc_conv2d_wgrad_split if SPLIT_PRECISION else L.fpc_conv2d_wgrad
@@ -164,6 +190,11 @@ def _conv_backward(x, w, gy, stride, pad, needs, has_bias):
         if Cw != Cout:
             gw = gw[:Cout].contiguous()
         counters["wgrad_native"] += 1
+        if sink is not None:                # written in place: nothing for autograd to accumulate
+            sink.written = True
+            sink.callback()
+            gw = None
+            counters["wgrad_direct"] += 1
     if aten_x or aten_w:
         ax, aw, _ = torch.ops.aten.convolution_backward(gy[:, :Cout] if Cw != Cout else gy, x, w_full, None, [stride, stride], [pad, pad],
                                                         [1, 1], False, [0, 0], 1, [aten_x, aten_w, False])
@@ -182,7 +213,7 @@ class _Conv2dFn(torch.autograd.Function):
         ctx.stride, ctx.pad, ctx.has_bias = stride, pad, bias is not None
         ctx.save_for_backward(x, w)
         counters["fwd_native"] += 1
-        return conv_nhwc(x, w, bias, stride, pad)
+        return conv_nhwc(x, w, bias, stride, pad, allow_f16=True)
 
     @staticmethod
     def backward(ctx, gy):

@@ -83,6 +83,12 @@ class ShardedLookaheadRAdam:
         self.g_shard = torch.zeros(shard_total, **f32) if self._collective else None
         soff = 0
         self._hooks = []
+        self._sinks = []                   # (weight data pointer, GradSink) of the convolution weights: written by the weight-gradient kernel
+        self._counted = set()              # parameters whose gradient has arrived this step (hook or sink, whichever came first)
+        try:
+            from fastposecnn_amd.lib import train_conv as _tc      # the module object the model's convolutions use (lib/backbone.py)
+        except ImportError:
+            _tc = None
         for bi, b in enumerate(self.buckets):
             o = b["offset"]
             for p in b["params"]:
@@ -93,7 +99,12 @@ class ShardedLookaheadRAdam:
                 view.copy_(p.data)
                 p.data = view
                 p.grad = self.flat_g[o:o + n].view_as(p)
-                self._hooks.append(p.register_post_accumulate_grad_hook(self._make_hook(bi)))
+                hook = self._make_hook(bi, id(p))
+                self._hooks.append(p.register_post_accumulate_grad_hook(hook))
+                if _tc is not None and p.dim() == 4 and self.device.type == "cuda":
+                    sink = _tc.GradSink(p.grad, (lambda h=hook, q=p: h(q)), self)
+                    _tc.grad_sinks[p.data_ptr()] = sink
+                    self._sinks.append((p.data_ptr(), sink))
                 o += _slot(n)
             b["shard"] = b["numel"] // self.world
             b["shard_offset"] = soff
@@ -107,8 +118,11 @@ class ShardedLookaheadRAdam:
         self.skipped = torch.zeros(1, dtype=torch.int64, device=self.device)     # steps whose gradients the inf / NaN guard zeroed
 
     # ---- backward-time reduction -------------------------------------------------------------------------------
-    def _make_hook(self, bi):
+    def _make_hook(self, bi, pid):
         def hook(_p):
+            if pid in self._counted:       # (a weight whose first gradient went through its sink and a second one through autograd)
+                return
+            self._counted.add(pid)
             b = self.buckets[bi]
             b["pending"] -= 1
             if b["pending"] == 0:
@@ -149,6 +163,9 @@ class ShardedLookaheadRAdam:
     def zero_grad(self):
         self.flat_g.zero_()
         self._next = 0
+        self._counted.clear()
+        for _, sink in self._sinks:
+            sink.written = False
         for b in self.buckets:
             b["pending"] = len(b["params"])
             b["launched"] = False

@@ -720,6 +720,30 @@ def test_split_precision_error_is_at_the_plain_f32_level(lib, dev):
     assert errs[True] <= 2e-5, errs
 
 
+def test_fp16_pieces_operand_range(lib, dev):
+    """What wino_h2.hip's header states about operand ranges, measured: activations of scale 1 and 1e3 keep the 2e-5 bar of the other
+    forms (weights are rescaled on the device whatever their scale: 1e-4 .. 1e2 here); activations of scale 1e-2 — every second piece
+    subnormal — stay within 1e-5 of the output's scale; a value beyond fp16's range saturates: the output stays finite."""
+    g = torch.Generator().manual_seed(5)
+    B, Cin, H, W, Cout = 1, 64, 24, 40, 128
+    for a_scale, w_scale, bar in ((1.0, 1.0, 2e-5), (1e3, 1e-4, 2e-5), (1.0, 1e2, 2e-5), (1e-2, 1.0, 1e-5)):
+        x = torch.randn((B, Cin, H, W), generator=g) * a_scale
+        w = torch.randn((Cout, Cin, 3, 3), generator=g) * (w_scale / (Cin * 9) ** 0.5)
+        out, _, plan = _conv2d(dev, x, w, 1, 1, nsplit=-8)
+        ref = _ref_conv(x, w, 1, 1)
+        err = (out.double() - ref).abs().max().item() / ref.abs().max().item()
+        assert err <= bar, (a_scale, w_scale, err)
+    x = torch.randn((B, Cin, H, W), generator=g)
+    x[0, 3, 5, 7] = 1.0e6                                        # beyond 2 x 65504: saturates
+    w = torch.randn((Cout, Cin, 3, 3), generator=g) / (Cin * 9) ** 0.5
+    out, _, _ = _conv2d(dev, x, w, 1, 1, nsplit=-8)
+    assert torch.isfinite(out).all()
+    far = torch.ones_like(out, dtype=torch.bool)
+    far[:, :, 3:8, 5:10] = False                                  # outputs the huge value does not reach are unaffected
+    ref = _ref_conv(x, w, 1, 1)
+    assert ((out.double() - ref).abs()[far]).max().item() <= 2e-5 * ref[far].abs().max().item()
+
+
 def test_every_winograd_site_on_fp16_pieces_meets_the_float64_bars(lib, dev):
     """The fp16 x 2 Winograd form (wino_h2.hip) FORCED onto every 3x3 / stride-1 site of the network (ResNet34: 29 encoder sites + 7 grouped
     decoder sites = 28 convolutions) — not just where the autotuner happens to pick it: the logits against the float64 CPU module path stay inside
