@@ -86,16 +86,7 @@ __global__ __launch_bounds__(256, 1) void k_conv_wino_h2(const WinoArgs a) {
     const int ty0 = by * kTY, tx0 = bx * kTX;
     const int y_in0 = 2 * ty0 - 1, x_in0 = 2 * tx0 - 1;
 
-    f32x16 acc[4][2][2];      // [xi column j][tile half mt][32-channel tile nt]
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-#pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-            for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[j][mt][nt][r] = 0.f;
-
+    f32x16 acc[4][2][2];      // [xi column j][tile half mt][32-channel tile nt]; zeroed while the first operands are on their way
     // ---- weights: buffer loads of this wave's fragments, one 16-byte {g1, g2} per (xi, 32-channel tile, lane) and K-step
     const __amdgpu_buffer_rsrc_t rs_w = make_rsrc(reinterpret_cast<const char*>(P.w) + (size_t)nb * nkb * kStepBytes);
     const float inv_s = P.w[(size_t)nnb * nkb * (kStepBytes / 4)];      // 1 / (the power of two the weights were scaled by)
@@ -180,8 +171,20 @@ __global__ __launch_bounds__(256, 1) void k_conv_wino_h2(const WinoArgs a) {
     if (nkb > 1) isb += 8;
     FPC_H2_ISSUE_IN(1);
     if (nkb > 2) isb += 8;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[j][mt][nt][r] = 0.f;
+
+    const long long t_issued = a.dbg ? clock64() : 0;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const long long t_landed = a.dbg ? clock64() : 0;
     __syncthreads();
+    const long long t_synced = a.dbg ? clock64() : 0;
 
     // operands of the current step's transformed fragments, as the matrix instructions take them: TA1[j][mt] = {h1, h1},
     // TA2[j][mt] = {h2, h2} (four channels per piece); transformed values vn[mt][j] of the step
@@ -300,7 +303,7 @@ __global__ __launch_bounds__(256, 1) void k_conv_wino_h2(const WinoArgs a) {
     const long long t_kend = a.dbg ? clock64() : 0;
     if (a.dbg && lane == 0) {      // tools_dev/wino_stamps.py: shader-clock ticks and 100 MHz reference ticks of the K loop, entry -> loop
         long long* o = a.dbg + ((size_t)blockIdx.x * 4 + wi) * 8;
-        o[0] = 0; o[1] = 0; o[2] = 0;
+        o[0] = t_issued - t_entry; o[1] = t_landed - t_issued; o[2] = t_synced - t_landed;      // entry: set-up + issue | first operands land | barrier
         o[3] = t_kend - c_begin; o[4] = wall_clock64() - r_begin; o[5] = nkb; o[6] = c_begin - t_entry;
     }
 

@@ -87,16 +87,7 @@ __global__ __launch_bounds__(256, 1) void k_conv_wino_w4(const WinoArgs a) {
     const int ty0 = by * kTY, tx0 = bx * kTX;
     const int y_in0 = 2 * ty0 - 1, x_in0 = 2 * tx0 - 1;
 
-    f32x16 acc[4][2][2];      // [xi column j][tile half mt][32-channel tile nt]
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-#pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-            for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[j][mt][nt][r] = 0.f;
-
+    f32x16 acc[4][2][2];      // [xi column j][tile half mt][32-channel tile nt]; zeroed while the first operands are on their way
     // ---- weights: buffer loads from k_wino_pack_bf3's image.  {b1, b2} of (xi, channel co, channel half hw): 16 bytes at
     // xi * 2048 + co * 32 + 16 * (hw ^ ((co >> 3) & 1)); {b3}: 8 bytes at 32768 + xi * 1024 + co * 16 + 8 * (hw ^ ((co >> 4) & 1))
     const __amdgpu_buffer_rsrc_t rs_w = make_rsrc(reinterpret_cast<const char*>(P.w) + (size_t)nb * nkb * kStepBytes);
@@ -183,6 +174,15 @@ __global__ __launch_bounds__(256, 1) void k_conv_wino_w4(const WinoArgs a) {
     if (nkb > 1) isb += 8;
     FPC_W4_ISSUE_IN(1);
     if (nkb > 2) isb += 8;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[j][mt][nt][r] = 0.f;
+
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
