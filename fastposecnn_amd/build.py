@@ -27,7 +27,7 @@ FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-ffp-contract=
 FILE_FLAGS = {"vote_count.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form", "-fno-slp-vectorize"],
               # one wave per SIMD beside its own MFMAs: a packed f32 instruction costs ~13 cycles more than the two scalar ones it
               # replaces (MI355X_MICROARCH.md, "price of one filler beside MFMAs"); plain -O3 SLP-packs the splits' subtractions
-              "wino_w4.hip": ["-fno-slp-vectorize"], "wino128.hip": ["-fno-slp-vectorize"], "wino_h2.hip": ["-fno-slp-vectorize"]}
+              "wino_w4.hip": ["-fno-slp-vectorize"], "wino128.hip": ["-fno-slp-vectorize"], "wino_h2.hip": ["-fno-slp-vectorize"], "wino_h3.hip": ["-fno-slp-vectorize"]}
 
 
 def sources():

@@ -201,7 +201,7 @@ struct fpc_net {
         c.wino_ok = (k == 3 && stride == 1 && pad == 1 && c.Cinp == Cin && Cin % 8 == 0 && Cout % 64 == 0);
         // f32 image (16 x) + split-precision image (24 x) + the 128-channel form's fragment-order image (24 x, wino128.hip)
         // ... + the fp16 x 2 form's fragment-order image (16 x + its two-float tail, wino_h2.hip)
-        if (c.wino_ok) c.wino_off = alloc((size_t)(Cout % 128 == 0 ? 80 : 56) * Cout * Cin + 64);
+        if (c.wino_ok) c.wino_off = alloc((size_t)(Cout % 128 == 0 ? 96 : 72) * Cout * Cin + 80);
         convs.push_back(c);
         return (int)convs.size() - 1;
     }
@@ -365,7 +365,7 @@ extern "C" void fpc_net_destroy(fpc_net_t* n) {
 // by rounding (about 2^-24 relative per product, like a different f32 summation order), not bit for bit.
 extern "C" int fpc_net_set_split_precision(fpc_net_t* n, int on) {
     if (!n) return FPC_EINVAL;
-    n->split_precision = on < 0 ? 0 : (on > 2 ? 2 : on);      // 0: f32 products only, 1: + bf16 x 3 forms, 2: + the fp16 x 2 Winograd form
+    n->split_precision = on < 0 ? 0 : (on > 3 ? 3 : on);      // 0: f32 products only, 1: + bf16 x 3 forms, 2: + the fp16 x 2 Winograd form, 3: + its three-product form
     return FPC_OK;
 }
 
@@ -412,6 +412,10 @@ extern "C" int fpc_net_load_params(fpc_net_t* n, const float* const* params, int
             }
             rc = launch_wino_pack_h2(n->pptr[c.p_w], n->ws + c.wino_off + (size_t)(c.Cout % 128 == 0 ? 64 : 40) * c.Cout * c.Cin, c.Cout, c.Cin, s);
             if (rc) return rc;
+            if (c.Cin % 16 == 0) {      // the pair-order image of the three-product fp16 form, behind the fp16 x 2 image and its tail
+                rc = launch_wino_pack_h3(n->pptr[c.p_w], n->ws + c.wino_off + (size_t)(c.Cout % 128 == 0 ? 80 : 56) * c.Cout * c.Cin + 8, c.Cout, c.Cin, s);
+                if (rc) return rc;
+            }
         }
         if (c.p_bn >= 0) {
             rc = launch_fold_bn(n->pptr[c.p_bn], n->pptr[c.p_bn + 1], n->pptr[c.p_bn + 2], n->pptr[c.p_bn + 3], 1e-5f,
@@ -480,17 +484,19 @@ int launch_conv_plan(ConvArgs& a, const ConvPlan& p, int groups, hipStream_t s) 
             w.p[g] = a.p[g];
             // the split-precision image follows the f32 one, the 128-channel form's fragment-order image follows that
             w.p[g].w = a.wino_w[g] + ((p.wino == 5 || p.wino == 7) ? (size_t)16 * a.Cout * a.Cin : p.wino == 6 ? (size_t)40 * a.Cout * a.Cin
-                                      : p.wino == 8 ? (size_t)(a.Cout % 128 == 0 ? 64 : 40) * a.Cout * a.Cin : 0);      // ... the fp16 x 2 image last
+                                      : p.wino == 8 ? (size_t)(a.Cout % 128 == 0 ? 64 : 40) * a.Cout * a.Cin      // ... the fp16 x 2 image
+                                      : p.wino == 9 ? (size_t)(a.Cout % 128 == 0 ? 80 : 56) * a.Cout * a.Cin + 8 : 0);      // ... its pair-order form last
         }
         w.variant = p.wino == 3 ? 1 : (p.wino == 4 ? 2 : (p.wino == 5 ? 3 : 0));
         w.zeros = a.zeros;
         w.dbg = (long long*)a.dbg;
         w.groups = groups;
         w.B = a.B; w.H = a.Ho; w.W = a.Wo; w.Cin = a.Cin; w.Cout = a.Cout; w.relu = a.relu;
-        w.waves = (p.wino == 2 || p.wino == 4 || p.wino == 5 || p.wino == 7 || p.wino == 8) ? 8 : 4;
+        w.waves = (p.wino == 2 || p.wino == 4 || p.wino == 5 || p.wino == 7 || p.wino == 8 || p.wino == 9) ? 8 : 4;
         w.tbx = cdiv(cdiv(a.Wo, 2), 8); w.tby = cdiv(cdiv(a.Ho, 2), w.waves);
         if (p.wino == 6) return a.Cout % 128 == 0 ? launch_conv_wino_c128(w, groups, s) : FPC_EINVAL;      // 8 x 4 tiles x 128 channels (wino128.hip)
         if (p.wino == 7) return launch_conv_wino_w4(w, groups, s);
+        if (p.wino == 9) return launch_conv_wino_h3(w, groups, s);      // three fp16 piece products over pairs of K-steps (wino_h3.hip)
         if (p.wino == 8) return launch_conv_wino_h2(w, groups, s);      // the same on two fp16 pieces per operand (wino_h2.hip)      // 8 x 8 tiles x 64 channels as four waves of 512 registers (wino_w4.hip)
         return launch_conv_wino(w, groups, s);
     }
@@ -505,7 +511,7 @@ int launch_conv_plan(ConvArgs& a, const ConvPlan& p, int groups, hipStream_t s) 
 
 // number of GroupNorm partial rows per image a plan writes
 int plan_gn_rows(const ConvPlan& p, int Ho, int Wo) {
-    return p.wino ? cdiv(cdiv(Wo, 2), 8) * cdiv(cdiv(Ho, 2), (p.wino == 2 || p.wino == 4 || p.wino == 5 || p.wino == 7 || p.wino == 8) ? 8 : 4) : p.mtiles * p.bm / 32;
+    return p.wino ? cdiv(cdiv(Wo, 2), 8) * cdiv(cdiv(Ho, 2), (p.wino == 2 || p.wino == 4 || p.wino == 5 || p.wino == 7 || p.wino == 8 || p.wino == 9) ? 8 : 4) : p.mtiles * p.bm / 32;
 }
 
 // Runs conv site `ci` with its current plan; in tuning mode first times every candidate tiling
@@ -539,7 +545,12 @@ int run_conv(fpc_net* n, ConvArgs& a, int groups, int ci, hipStream_t s) {
             if (n->split_precision && a.zeros) { wq.wino = 5; cands.push_back(wq); }      // split-precision products, 8 waves
             if (n->split_precision && a.Cout % 128 == 0) { wq.wino = 6; cands.push_back(wq); }      // ... 128 channels per workgroup, 4 waves
             if (n->split_precision) { wq.wino = 7; cands.push_back(wq); }      // ... 64 channels, four waves of 512 registers, weights direct
-            if (n->split_precision >= 2) { wq.wino = 8; cands.push_back(wq); }      // ... on two fp16 pieces (range-limited: fpc.h)
+            // ... on two fp16 pieces (range-limited: fpc.h): all four piece products, or (level 3, Cin a multiple of 16) three of them over
+            // pairs of K-steps.  Where the second form is allowed it REPLACES the first as a candidate: one launch timed from a cold
+            // clock ranks them by their entry costs, the forward in steady state by their power (all sites on form 9 against all on
+            // form 8: 14.05 / 14.58 and 14.21 / 15.04 ms on two boxes, while per-site timing picked form 9 for 2 of 33 sites)
+            if (n->split_precision >= 3 && a.Cin % 16 == 0) { wq.wino = 9; cands.push_back(wq); }
+            else if (n->split_precision >= 2) { wq.wino = 8; cands.push_back(wq); }
         }
         for (const ConvPlan& q : cands) {
             if (splitk_floats_for(q, groups, a.B, a.Npad) > cap) continue;
@@ -560,9 +571,9 @@ int run_conv(fpc_net* n, ConvArgs& a, int groups, int ci, hipStream_t s) {
             if (n->tune_mode >= 1) {
                 double nblk = q.stem ? 512.0      // (a persistent 512-thread, 86 KB workgroup per CU: the whole chip, whatever its grid)
                               : q.lat ? (double)cdiv(a.Ho * a.Wo, 128) * a.B * q.lat
-                              : q.wino ? (double)cdiv(cdiv(a.Wo, 2), 8) * cdiv(cdiv(a.Ho, 2), (q.wino == 2 || q.wino == 4 || q.wino == 5 || q.wino == 7 || q.wino == 8) ? 8 : 4) * a.B * (a.Cout / (q.wino == 6 ? 128 : 64)) * groups
+                              : q.wino ? (double)cdiv(cdiv(a.Wo, 2), 8) * cdiv(cdiv(a.Ho, 2), (q.wino == 2 || q.wino == 4 || q.wino == 5 || q.wino == 7 || q.wino == 8 || q.wino == 9) ? 8 : 4) * a.B * (a.Cout / (q.wino == 6 ? 128 : 64)) * groups
                                      : (double)q.mtiles * q.ntiles * q.nsplit * a.B * groups;
-                double slots = 256.0 * ((q.wino == 2 || q.wino == 4 || q.wino == 5 || q.wino == 6 || q.wino == 7 || q.wino == 8) ? 1.0 : 2.0);
+                double slots = 256.0 * ((q.wino == 2 || q.wino == 4 || q.wino == 5 || q.wino == 6 || q.wino == 7 || q.wino == 8 || q.wino == 9) ? 1.0 : 2.0);
                 double share = nblk / slots;
                 if (share > 1.0) share = 1.0;
                 if (share < 0.125) share = 0.125;
@@ -857,11 +868,11 @@ extern "C" int fpc_net_conv_plan(const fpc_net_t* n, int i, int* out5) {
 // other sites keep their plan): tests run the whole network on ONE form (e.g. 8: every eligible product on fp16 x 2 pieces) and
 // hold it to the float64 bars.  Returns the number of sites changed, or a negative code.  Drops the recorded graph.
 extern "C" int fpc_net_force_winograd(fpc_net_t* n, int form) {
-    if (!n || form < 1 || form > 8) return FPC_EINVAL;
+    if (!n || form < 1 || form > 9) return FPC_EINVAL;
     int changed = 0;
     for (size_t i = 0; i < n->convs.size(); ++i) {
         const PackedConv& c = n->convs[i];
-        if (!c.wino_ok || !n->c_groups[i] || (form == 6 && c.Cout % 128 != 0)) continue;
+        if (!c.wino_ok || !n->c_groups[i] || (form == 6 && c.Cout % 128 != 0) || (form == 9 && c.Cin % 16 != 0)) continue;
         ConvPlan q = n->cplan[i];
         q.wino = form; q.lat = 0; q.stem = 0;
         n->cplan[i] = q;
@@ -939,7 +950,7 @@ extern "C" size_t fpc_conv2d_workspace_bytes(int B, int Ho, int Wo, int Cin, int
     int K = Cin * Kh * Kw, Kpad = cdiv(K, kConvBK) * kConvBK, Npad = cdiv(Cout, kConvNAlign) * kConvNAlign;
     size_t packed = conv_packed_floats(Npad, Kpad);
     size_t splitk = (size_t)32 * B * (cdiv(Ho * Wo, 128) * 128) * Npad;
-    size_t wino = (size_t)80 * Cout * Cin + 128;      // f32 + split-precision (two layouts) Winograd images + a zero page for the all-DMA form
+    size_t wino = (size_t)96 * Cout * Cin + 128;      // f32 + split-precision (two layouts) Winograd images + a zero page for the all-DMA form
     return (packed + splitk + wino + kConvTickets) * sizeof(float);
 }
 
@@ -951,7 +962,7 @@ extern "C" int fpc_conv2d_plan(int B, int Ho, int Wo, int Cin, int Cout, int Kh,
     if (nsplit >= 1000) nsplit -= 1000;      // fpc_conv2d's split-precision / two-launch hooks do not change the tiling
     if (nsplit >= 100) nsplit -= 100;
     ConvPlan p = plan_conv(Ho * Wo, B, Cout, Kpad / kConvBK, 1, bm, bn, nsplit);
-    if (nsplit <= -1 && nsplit >= -8) { p.wino = -nsplit; p.nsplit = nsplit; }
+    if (nsplit <= -1 && nsplit >= -9) { p.wino = -nsplit; p.nsplit = nsplit; }
     out4[0] = p.bm; out4[1] = p.bn; out4[2] = p.nsplit; out4[3] = plan_gn_rows(p, Ho, Wo);
     return FPC_OK;
 }
@@ -968,7 +979,8 @@ Conv2dRequest conv2d_request(int nsplit) {
     // -1: 4 waves, -2: 8 waves, -3: wave-private, -4: all-DMA 3-stage, -5: 8 waves split precision, -6: split precision, 128 channels per workgroup
     // -7: split precision, 64 channels, four waves of 512 registers (the -5 image)
     // -8: the -7 form on two fp16 pieces per operand (its own image)
-    r.wino = r.nsplit <= -1 && r.nsplit >= -8;
+    // -9: three of the four products of -8, over pairs of K-steps (its own image; Cin a multiple of 16)
+    r.wino = r.nsplit <= -1 && r.nsplit >= -9;
     return r;
 }
 // workspace of ONE fpc_conv2d call (floats): [packed weights | split-K partials of this plan | Winograd images + zero page |
@@ -979,7 +991,7 @@ Conv2dLayout conv2d_layout(int B, int Cin, int Cout, int Kh, int Kw, const ConvP
     Conv2dLayout L;
     L.packed = r.wino ? 0 : conv_packed_floats(Npad, Kpad);
     L.splitk = r.wino ? 0 : (splitk_floats_for(p, 1, B, Npad) + 63) / 64 * 64;
-    L.wino = r.wino ? (size_t)(r.nsplit == -8 ? (Cout % 128 == 0 ? 80 : 56) : r.nsplit == -6 ? 64 : (r.nsplit == -5 || r.nsplit == -7) ? 40 : 16) * Cout * Cin + 128 : 0;
+    L.wino = r.wino ? (size_t)(r.nsplit == -9 ? (Cout % 128 == 0 ? 96 : 72) : r.nsplit == -8 ? (Cout % 128 == 0 ? 80 : 56) : r.nsplit == -6 ? 64 : (r.nsplit == -5 || r.nsplit == -7) ? 40 : 16) * Cout * Cin + 128 : 0;
     L.tickets = (!r.wino && p.fused && p.nsplit > 1) ? kConvTickets : 0;
     L.total = L.packed + L.splitk + L.wino + L.tickets;
     return L;
@@ -1072,6 +1084,7 @@ extern "C" int fpc_conv2d(const float* in, int64_t sb, int64_t sh, int64_t sw, i
         if (nsplit > -5) FPC_TRY(launch_wino_pack(w_oihw, wp, Cout, Cin, s));
         if (nsplit == -5 || nsplit == -7) FPC_TRY(launch_wino_pack_bf3(w_oihw, wp + (size_t)16 * Cout * Cin, Cout, Cin, s));
         if (nsplit == -6) FPC_TRY(launch_wino_pack_c128(w_oihw, wp + (size_t)40 * Cout * Cin, Cout, Cin, s));
+        if (nsplit == -9) FPC_TRY(launch_wino_pack_h3(w_oihw, wp + (size_t)(Cout % 128 == 0 ? 80 : 56) * Cout * Cin + 8, Cout, Cin, s));
         if (nsplit == -8) FPC_TRY(launch_wino_pack_h2(w_oihw, wp + (size_t)(Cout % 128 == 0 ? 64 : 40) * Cout * Cin, Cout, Cin, s));
         a.wino_w[0] = wp;
         a.zeros = zero_page();       // (the workspace's last 64 floats stay reserved for it: fpc_conv2d_workspace_bytes is unchanged)

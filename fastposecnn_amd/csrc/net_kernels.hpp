@@ -150,6 +150,11 @@ int launch_conv_wino_w4(const WinoArgs& a, int groups, hipStream_t s);
 // incl. its two-float tail: 16 * Cout * Cin + 2 floats)
 int launch_conv_wino_h2(const WinoArgs& a, int groups, hipStream_t s);
 int launch_wino_pack_h2(const float* w_oihw, float* packed, int Cout, int Cin, hipStream_t s);
+int launch_absmax_bits(const float* w, long long n, unsigned* out_bits, hipStream_t s);      // max |w| as the bits of a non-negative float (atomicMax into *out_bits)
+// wino_h3.hip: k_conv_wino_h2 with three of the four piece products, over pairs of K-steps (Cin a multiple of 16); its own image:
+// 16 * Cout * Cin + 2 floats
+int launch_conv_wino_h3(const WinoArgs& a, int groups, hipStream_t s);
+int launch_wino_pack_h3(const float* w_oihw, float* packed, int Cout, int Cin, hipStream_t s);
 int launch_conv(const ConvArgs& a, int groups, hipStream_t s);
 int launch_conv_splitk_epilogue(const ConvArgs& a, int groups, hipStream_t s);
 int launch_maxpool3x3s2(const float* in, float* out, int B, int Hi, int Wi, int C, int Ho, int Wo, hipStream_t s);

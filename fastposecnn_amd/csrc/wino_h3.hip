@@ -1,27 +1,27 @@
-// wino_h2.hip — k_conv_wino_h2: the four-wave Winograd F(2x2, 3x3) convolution (wino_w4.hip) on TWO fp16 pieces per operand
-// instead of three bf16 pieces: four products in two matrix instructions per K-step instead of six in three (round 6).
+// wino_h3.hip — k_conv_wino_h3: wino_h2.hip's four-wave Winograd F(2x2, 3x3) convolution on two fp16 pieces per operand with THREE
+// piece products instead of four, over PAIRS of 8-channel K-steps (round 6, last form).
 //
-// Why.  The split-precision forms are bound by instruction issue and by chip power: per K-step of 8 channels and
-// 64 x 64 (tiles x channels) the bf16 x 3 form issues 48 matrix instructions, ~330 vector instructions (176 of them the three-way
-// split, 96 operand moves) and streams 48 KB of weights.  With fp16 pieces an f32 operand needs TWO: x = h1 + h2 + rest with
-// |rest| <= 2^-22 |x| (11 + 11 significant bits; truncating conversions, residuals exact in f32).  All four piece products are
-// kept: A = {h1, h1} x B = {g1, g2} and A = {h2, h2} x B = {g1, g2} — (h1 + h2)(g1 + g2) exactly, f32 accumulation; the SAME
-// 16-byte weight fragment serves both, so a K-step is 32 matrix instructions, ~200 vector instructions (a pair of values
-// splits in 8: v_cvt_pkrtz_f16_f32, two conversions back, two subtractions, v_cvt_pkrtz again, two copies) and 32 KB of
-// weights; no {b3} fragment, no operand rebuild.
+// Why.  k_conv_wino_h2 runs at the chip's power limit: taking its barrier out saves 10 % of its cycles and none of its time (the clock
+// drops from 1.93 to 1.77 GHz), taking a quarter of its matrix instructions out saves no cycles and 11 % of its time (the clock rises to
+// 2.15 GHz) — profiles/r06_wino_forms.md.  What shortens it is less work per product, not fewer stalls.
+//   x w = (h1 + h2 + rx)(g1 + g2 + rw),  |h2| <= 2^-11 |x|, |g2| <= 2^-11 |w|, |rx| <= 2^-22 |x|, |rw| <= 2^-22 |w|
+// The form keeps h1 g1 + h2 g1 + h1 g2 and drops h2 g2 (<= 2^-22 |x w|: the size of the two terms every two-piece form already
+// drops, x rw and rx w).  Three products do not fit two matrix instructions per 8 channels, but they fit THREE per 16: the K dimension
+// of v_mfma_f32_32x32x16_f16 carries 4 channels of the even K-step and 4 of the odd one,
+//   A1 = {h1 even, h1 odd}   A2 = {h2 even, h2 odd}      B1 = {g1 even, g1 odd}   B2 = {g2 even, g2 odd}
+//   acc += A1 B1 + A2 B1 + A1 B2
+// so that 16 channels cost 48 matrix instructions per wave instead of 64, and — the pieces of a value are written ONCE, into the half of
+// the operand tuple that belongs to its K-step — none of the 32 operand copies per step of the {h1, h1} / {h2, h2} form.
 //
-// Range (what fp16 pieces cost).  fp16 spans 2^-24 .. 65504.  WEIGHTS: k_wino_pack_h2 scales the transformed weights of a
-// convolution by a power of two s (from max |w| of the convolution, found on the device) so that max |U s| < 2^13, and the kernel
-// multiplies its sums by 1 / s — exact.  ACTIVATIONS are not scaled: a transformed input value v (a signed sum of four activations)
-// is represented to 2^-22 |v| while |v| >= 2^-3 and to 2^-25 ABSOLUTE below (the second piece turns subnormal), and SATURATES at
-// |v| > 131 008 (round-toward-zero conversions never produce infinity).  Against a tensor of scale ~1 that is f32-level accuracy
-// (tests/test_gpu_net.py holds this form to the 2e-5 bar of every other form and the network to the 1e-4 float64 bars); a tensor
-// whose values are all tiny (scale 1e-2) keeps ~3e-6 of ITS scale, one with values beyond 1.3e5 is wrong.  The bf16 x 3 forms have
-// neither limit and stay selectable: fpc_net_set_split_precision(net, 1) never picks this form, 2 allows it.
-//
-// Everything else — one wave per SIMD with 512 registers, a matrix instruction followed by its own item of the step's other work,
-// weights straight into the operand registers one step ahead, the permuted LDS input image and its counted wait, operands written
-// in place, the one-pass output transform — is wino_w4.hip's; see there.
+// Schedule of a pair p (K-steps 2p, 2p + 1), one barrier:
+//   top      LDS-DMA of the inputs of steps 2p + 3 and 2p + 4 (ring of four 18 KB buffers inside the output image's space)
+//   E        vector work only: the pending split of xi 3 (even half), then step 2p + 1's fragment reads, transform and split -> the odd
+//            halves of every operand
+//   O        48 matrix instructions (xi j: A1 B1 x 4, A2 B1 x 4, A1 B2 x 4) with one item of work behind each of the first 40: step
+//            2p + 2's fragment reads, transform, and the split of xi 0-2 into the even halves once xi j's last matrix instruction has
+//            issued (xi 3 waits for the next E); each weight fragment is reloaded in place for the next pair after its last use
+//   end      counted wait for this wave's ten pieces (the 16 weight loads behind them stay in flight), barrier
+// Range, scaling, the input image's layout, the entry and the output transform are wino_h2.hip's; Cin must be a multiple of 16.
 // Reference: the 3x3 / stride-1 convolutions of F/lib/pose_regressor.py:709-743 (smp encoder + FPN decoder, not vendored).
 #include <algorithm>
 #include <cstdlib>
@@ -42,9 +42,10 @@ constexpr int kBN = 64;                          // output channels per workgrou
 constexpr int kNT = kTX * kTY;                   // 64 tiles = two M halves
 constexpr int kInPieces = 18;                    // 1 KB LDS-DMA pieces of one K-step's input image (k_conv_wino's permuted image)
 constexpr int kInFloats = kInPieces * 256;       // 4608 floats per input buffer
-constexpr int kStepBytes = 16 * 64 * 32;         // k_wino_pack_h2's image of one K-step: [xi 16][tile 2][lane 64] x 16 bytes {g1 x 4 ch, g2 x 4 ch}
+constexpr int kRing = 4;                         // input buffers: step s lives in buffer s & 3
+constexpr int kPairBytes = 16 * 2 * 2 * 64 * 16; // k_wino_pack_h3's image of one pair of K-steps: [xi 16][tile 2][piece 2][lane 64] x 16 bytes {4 ch of the even step, 4 ch of the odd step}
 constexpr int kLdsFloats = 4 * 2 * kNT * kBN;    // output transform image = 128 KB
-static_assert(kLdsFloats >= 2 * kInFloats, "the K loop's two input buffers live in the output image's space");
+static_assert(kLdsFloats >= kRing * kInFloats, "the K loop's input ring lives in the output image's space");
 
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base) {
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, 0x7FFFFFFF, 0x00020000);
@@ -60,10 +61,9 @@ __device__ __forceinline__ f32x4 add_s4(f32x4 a, f32x4 b) { return f32x4{a[0] + 
 
 }  // namespace
 
-// MODE (diagnostic instantiations, FPC_H2_MODE at launch): bit 0 = the K loop reloads no weights, bit 1 = it stages no input and has
-// no barrier — wrong results, the same instruction stream otherwise
-template <int MODE>
-__global__ __launch_bounds__(256, 1) void k_conv_wino_h2(const WinoArgs a) {
+// VAR (diagnostic, FPC_H3_VAR at launch): 1 = a piece's residual by conversion + subtraction instead of v_fma_mix_f32 (the same bits)
+template <int VAR>
+__global__ __launch_bounds__(256, 1) void k_conv_wino_h3(const WinoArgs a) {
     __shared__ __attribute__((aligned(16))) float lds[kLdsFloats];
     const long long t_entry = a.dbg ? clock64() : 0;
     const int t = threadIdx.x, lane = t & 63;
@@ -86,19 +86,23 @@ __global__ __launch_bounds__(256, 1) void k_conv_wino_h2(const WinoArgs a) {
     const int ty0 = by * kTY, tx0 = bx * kTX;
     const int y_in0 = 2 * ty0 - 1, x_in0 = 2 * tx0 - 1;
 
+    const int npair = nkb >> 1;      // (the launcher refuses an odd number of K-steps)
+
     f32x16 acc[4][2][2];      // [xi column j][tile half mt][32-channel tile nt]; zeroed while the first operands are on their way
-    // ---- weights: buffer loads of this wave's fragments, one 16-byte {g1, g2} per (xi, 32-channel tile, lane) and K-step
-    const __amdgpu_buffer_rsrc_t rs_w = make_rsrc(reinterpret_cast<const char*>(P.w) + (size_t)nb * nkb * kStepBytes);
-    const float inv_s = P.w[(size_t)nnb * nkb * (kStepBytes / 4)];      // 1 / (the power of two the weights were scaled by)
+    // ---- weights: buffer loads of this wave's fragments, per pair of K-steps one 16-byte B1 = {g1 even, g1 odd} and one B2 = {g2 even,
+    // g2 odd} per (xi, 32-channel tile, lane)
+    const __amdgpu_buffer_rsrc_t rs_w = make_rsrc(reinterpret_cast<const char*>(P.w) + (size_t)nb * npair * kPairBytes);
+    const float inv_s = P.w[(size_t)nnb * npair * (kPairBytes / 4)];      // 1 / (the power of two the weights were scaled by)
     const int vo_u = lane * 16;
-    int so_u = wi * 4 * 2048;      // this wave's four xi; + kStepBytes per K-step
-    u32x4 U[4][2];
-#define FPC_H2_LOAD_U(J, NT) U[J][NT] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_w, vo_u, so_u + (J) * 2048 + (NT) * 1024, 0))
+    int so_u = wi * 4 * 4096;      // this wave's four xi; + kPairBytes per pair
+    u32x4 U1[4][2], U2[4][2];
+#define FPC_H3_LOAD_U1(J, NT) U1[J][NT] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_w, vo_u, so_u + (J) * 4096 + (NT) * 2048, 0))
+#define FPC_H3_LOAD_U2(J, NT) U2[J][NT] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_w, vo_u, so_u + (J) * 4096 + (NT) * 2048 + 1024, 0))
 #pragma unroll
     for (int j = 0; j < 4; ++j)
 #pragma unroll
-        for (int nt = 0; nt < 2; ++nt) FPC_H2_LOAD_U(j, nt);
-    if (nkb > 1) so_u += kStepBytes;
+        for (int nt = 0; nt < 2; ++nt) { FPC_H3_LOAD_U1(j, nt); FPC_H3_LOAD_U2(j, nt); }
+    if (npair > 1) so_u += kPairBytes;
 
     // ---- input staging: LDS-DMA pieces (wave + 4 i), i < 5 (18 pieces).  The 16-byte unit a lane's data lands in decides the
     // global address it fetches (k_conv_wino, PERM): unit = (cell * 8 + block) * 16 + 4 * (qh & 3) + (ah & 3), cell = (ah >> 2) * 3 +
@@ -127,7 +131,7 @@ __global__ __launch_bounds__(256, 1) void k_conv_wino_h2(const WinoArgs a) {
     unsigned long long imask[5];
 #pragma unroll
     for (int i = 0; i < 5; ++i) imask[i] = __ballot(iok[i]);
-#define FPC_H2_ISSUE_IN(BUF)                                                                                  \
+#define FPC_H3_ISSUE_IN(BUF, PTR)                                                                             \
     do {                                                                                                      \
         unsigned long long sv_;                                                                               \
         const unsigned l0_ = FPC_LDS_ADDR(lds + (BUF) * kInFloats + wi * 256);                                \
@@ -141,7 +145,7 @@ __global__ __launch_bounds__(256, 1) void k_conv_wino_h2(const WinoArgs a) {
                      : "=&s"(sv_)                                                                             \
                      : "s"(imask[0]), "s"(imask[1]), "s"(imask[2]), "s"(imask[3]), "s"(imask[4]),             \
                        "s"(l0_), "s"(l0_ + 4096), "s"(l0_ + 8192), "s"(l0_ + 12288), "s"(l0_ + 16384),        \
-                       "v"(ivo[0]), "v"(ivo[1]), "v"(ivo[2]), "v"(ivo[3]), "v"(ivo[4]), "s"(isb)              \
+                       "v"(ivo[0]), "v"(ivo[1]), "v"(ivo[2]), "v"(ivo[3]), "v"(ivo[4]), "s"(PTR)              \
                      : "memory", "m0");                                                                       \
     } while (0)
 
@@ -160,17 +164,21 @@ __global__ __launch_bounds__(256, 1) void k_conv_wino_h2(const WinoArgs a) {
     constexpr int in_ms = 3 * 8 * 16 * 4;      // + 4 tile rows (tile half 1): the next row of cells
     const int in_a[2] = {unit(ra, 0), unit(ra, 1)}, in_b[2] = {unit(rb, 0), unit(rb, 1)};
 
-    // a patch that reaches over the image border zeroes both input buffers once (inactive DMA lanes leave them alone); an
+    // a patch that reaches over the image border zeroes the input ring once (inactive DMA lanes leave it alone); an
     // interior patch rewrites every unit the fragment reads touch with every step's DMA
     if (y_in0 < 0 || x_in0 < 0 || y_in0 + kRH > H || x_in0 + kRW > W) {
-        for (int i = t; i < 2 * kInFloats / 4; i += 256) reinterpret_cast<f32x4*>(lds)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int i = t; i < kRing * kInFloats / 4; i += 256) reinterpret_cast<f32x4*>(lds)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __syncthreads();
     }
-    FPC_H2_ISSUE_IN(0);
-    if (nkb > 1) isb += 8;
-    FPC_H2_ISSUE_IN(1);
+    // steps 0, 1, 2 -> buffers 0, 1, 2 (a step past the last one re-reads the last: the same count of pieces whatever Cin)
+    FPC_H3_ISSUE_IN(0, isb);
+    isb += 8;                      // (nkb >= 2)
+    FPC_H3_ISSUE_IN(1, isb);
     if (nkb > 2) isb += 8;
+    FPC_H3_ISSUE_IN(2, isb);
+    if (nkb > 3) isb += 8;
+    int sn = 3;                    // the next step to stage
 #pragma unroll
     for (int j = 0; j < 4; ++j)
 #pragma unroll
@@ -186,27 +194,33 @@ __global__ __launch_bounds__(256, 1) void k_conv_wino_h2(const WinoArgs a) {
     __syncthreads();
     const long long t_synced = a.dbg ? clock64() : 0;
 
-    // operands of the current step's transformed fragments, as the matrix instructions take them: TA1[j][mt] = {h1, h1},
-    // TA2[j][mt] = {h2, h2} (four channels per piece); transformed values vn[mt][j] of the step
-    // whose pieces are being built (xi 3's wait there across the loop's back edge)
+    // operands as the matrix instructions take them: TA1[j][mt] = {h1 of the pair's even step, h1 of its odd step}, TA2[j][mt] = {h2
+    // even, h2 odd} (four channels per piece and half); vn[mt][j]: the transformed values of the step whose pieces are being built
+    // (xi 3's wait there from the end of O to the next E)
     u32x4 TA1[4][2], TA2[4][2];
     f32x4 vn[2][4];
-    // one pair of values of vn[MT][J] -> its fp16 pieces (pinned to its slot by the volatile asm that reads them, as wino_w4.hip's items)
-#define FPC_H2_SPLIT_PAIR(J, MT, PAIR)                                                                        \
+    float m1;
+    asm volatile("s_mov_b32 %0, 0xbf800000" : "=s"(m1));      // -1.0f, opaque
+    // one pair of values of vn[MT][J] -> its fp16 pieces, into half HALF of the operands (pinned to its slot by the volatile asm that
+    // reads them, as wino_w4.hip's items)
+#define FPC_H3_SPLIT_PAIR(J, MT, PAIR, HALF)                                                                  \
     do {                                                                                                      \
         const float x0_ = vn[MT][J][2 * (PAIR)], x1_ = vn[MT][J][2 * (PAIR) + 1];                             \
         const fp16x2 h_ = __builtin_amdgcn_cvt_pkrtz(x0_, x1_);                                               \
-        const float r0_ = x0_ - (float)h_[0], r1_ = x1_ - (float)h_[1];                                       \
+        /* x - h1 in ONE instruction: v_fma_mix_f32 reads the fp16 piece in place (m1 = -1 in a scalar register the compiler cannot  \
+           fold); exact like the conversion + subtraction it replaces (VAR 1) */                                                  \
+        const float r0_ = VAR == 1 ? x0_ - (float)h_[0] : __builtin_fmaf((float)h_[0], m1, x0_);              \
+        const float r1_ = VAR == 1 ? x1_ - (float)h_[1] : __builtin_fmaf((float)h_[1], m1, x1_);              \
         const unsigned k1_ = __builtin_bit_cast(unsigned, h_);                                                \
         const unsigned k2_ = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(r0_, r1_));              \
         asm volatile("" :: "v"(k1_), "v"(k2_));                                                               \
-        TA1[J][MT][PAIR] = k1_; TA1[J][MT][2 + (PAIR)] = k1_; TA2[J][MT][PAIR] = k2_; TA2[J][MT][2 + (PAIR)] = k2_; \
+        TA1[J][MT][2 * (HALF) + (PAIR)] = k1_; TA2[J][MT][2 * (HALF) + (PAIR)] = k2_;                         \
     } while (0)
 #pragma unroll
     for (int j = 0; j < 4; ++j)
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt) { TA1[j][mt] = u32x4{0u, 0u, 0u, 0u}; TA2[j][mt] = u32x4{0u, 0u, 0u, 0u}; }
-    {
+    {      // step 0 -> the even halves of xi 0-2; xi 3 stays in vn for E of pair 0
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt) {
             f32x4 e[4];
@@ -216,43 +230,74 @@ __global__ __launch_bounds__(256, 1) void k_conv_wino_h2(const WinoArgs a) {
                               *reinterpret_cast<const f32x4*>(lds + in_a[c >> 1] + (c & 1) * in_cs + mt * in_ms));
             vn[mt][0] = sub_s4(e[0], e[2]); vn[mt][1] = add_s4(e[1], e[2]); vn[mt][2] = sub_s4(e[2], e[1]); vn[mt][3] = sub_s4(e[1], e[3]);
 #pragma unroll
-            for (int j = 0; j < 3; ++j) { FPC_H2_SPLIT_PAIR(j, mt, 0); FPC_H2_SPLIT_PAIR(j, mt, 1); }
+            for (int j = 0; j < 3; ++j) { FPC_H3_SPLIT_PAIR(j, mt, 0, 0); FPC_H3_SPLIT_PAIR(j, mt, 1, 0); }
         }
     }
-    __syncthreads();       // buffer 0 is refilled by step 0's DMA
+    __syncthreads();       // buffer 0 is refilled by the pieces of step 4, issued at the top of pair 0
 
-#define FPC_H2_MFMA(J, MT, NT, A, B) acc[J][MT][NT] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, A), __builtin_bit_cast(f16x8, B), acc[J][MT][NT], 0, 0, 0)
-#define FPC_H2_PIN4(V) asm volatile("" :: "v"(V))
-    int cur = 0;
+#define FPC_H3_MFMA(J, MT, NT, A, B) acc[J][MT][NT] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, A), __builtin_bit_cast(f16x8, B), acc[J][MT][NT], 0, 0, 0)
+#define FPC_H3_PIN4(V) asm volatile("" :: "v"(V))
+#define FPC_H3_SPLIT_Q(J, Q, HALF) do { if ((Q) == 0) FPC_H3_SPLIT_PAIR(J, 0, 0, HALF); if ((Q) == 1) FPC_H3_SPLIT_PAIR(J, 0, 1, HALF); if ((Q) == 2) FPC_H3_SPLIT_PAIR(J, 1, 0, HALF); if ((Q) == 3) FPC_H3_SPLIT_PAIR(J, 1, 1, HALF); } while (0)
     const long long c_begin = a.dbg ? clock64() : 0, r_begin = a.dbg ? wall_clock64() : 0;
 #pragma unroll 1
-    for (int kb = 0; kb < nkb; ++kb) {
-        // input of step kb + 2 -> the buffer step kb's fragments were read from during step kb - 1 (oldest in the queue: see the wait below)
-        if (!(MODE & 2) && !(MODE & 8)) FPC_H2_ISSUE_IN(cur);
-        const float* In = lds + (cur ^ 1) * kInFloats;
+    for (int p = 0; p < npair; ++p) {
+        // inputs of steps 2p + 3 and 2p + 4 -> the buffers steps 2p - 1 and 2p were read from before the last barrier
+        FPC_H3_ISSUE_IN((sn & 3), isb);
+        if (sn + 1 < nkb) isb += 8;
+        FPC_H3_ISSUE_IN(((sn + 1) & 3), isb);
+        if (sn + 2 < nkb) isb += 8;
+        sn += 2;
+        // ---- E: step 2p + 1's fragment reads and transform; the odd halves of xi 0 (xi 1-3 follow behind O's first matrix instructions).
+        // No matrix instruction is in flight behind the barrier: plain code, the sixteen fragment reads issued together.
+        {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) FPC_H3_SPLIT_Q(3, q, 0);      // xi 3 of step 2p: its operands were in use until the end of O
+            const float* InE = lds + ((2 * p + 1) & 3) * kInFloats;
+            f32x4 ea[2][4], eb[2][4];
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    ea[mt][c] = *reinterpret_cast<const f32x4*>(InE + in_a[c >> 1] + (c & 1) * in_cs + mt * in_ms);
+                    eb[mt][c] = *reinterpret_cast<const f32x4*>(InE + in_b[c >> 1] + (c & 1) * in_cs + mt * in_ms);
+                }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) {
+                f32x4 e[4];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) e[c] = fma_s4(sgn, eb[mt][c], ea[mt][c]);
+                vn[mt][0] = sub_s4(e[0], e[2]); vn[mt][1] = add_s4(e[1], e[2]); vn[mt][2] = sub_s4(e[2], e[1]); vn[mt][3] = sub_s4(e[1], e[3]);
+                FPC_H3_SPLIT_PAIR(0, mt, 0, 1); FPC_H3_SPLIT_PAIR(0, mt, 1, 1);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- O: the pair's 48 matrix instructions; slot sl = 12 j + 4 g + 2 mt + nt, g = 0: A1 B1, 1: A2 B1, 2: A1 B2.  One item per slot:
+        //   sl  0- 3  fragment reads of step 2p + 2       sl  4-11  row transform e       sl 12-19  column transform vn
+        //   sl  0- 3 / 4-7 / 8-11  ALSO the split of xi 1 / 2 / 3 of step 2p + 1 into the odd halves (before xi 1's first matrix instruction, slot 12,
+        //             and before slot 12 overwrites vn)
+        //   sl 20-23 / 24-27 / 36-39  split of xi 0 / 1 / 2 of step 2p + 2 into the even halves (xi j's last matrix instruction: slot 12 j + 11)
+        // A weight fragment's last matrix instruction is followed by its reload for the next pair.
+        const float* In = lds + ((2 * p + 2) & 3) * kInFloats;
         f32x4 da[2][4], db[2][4], e[2][4];
         __builtin_amdgcn_s_setprio(1);
-        // Slot sl = 8 j + 4 g + 2 mt + nt: g = 0: h1 g1 + h1 g2, g = 1: h2 g1 + h2 g2.  One item per slot:
-        //   sl  0- 3  fragment reads of step kb + 1 (two columns of one tile half each) + the split of THIS step's xi 3 (one pair of
-        //             values each: half 0 pairs 0, 1, half 1 pairs 0, 1)
-        //   sl  4-11  row transform e = da + sgn db (one column of one half each)      sl 12-19  column transform vn (one xi of one half each)
-        //   sl 20-31  split of step kb + 1's xi 0, 1, 2 (four pairs each) — xi j's operands are overwritten after xi j's last matrix
-        //             instruction (slot 8 j + 7)
-        // The last matrix instruction of a weight fragment (g = 1, half 1) is followed by the fragment's reload for step kb + 1.
-#define FPC_H2_SPLIT_Q(J, Q) do { if ((Q) == 0) FPC_H2_SPLIT_PAIR(J, 0, 0); if ((Q) == 1) FPC_H2_SPLIT_PAIR(J, 0, 1); if ((Q) == 2) FPC_H2_SPLIT_PAIR(J, 1, 0); if ((Q) == 3) FPC_H2_SPLIT_PAIR(J, 1, 1); } while (0)
 #pragma unroll
         for (int j = 0; j < 4; ++j)
 #pragma unroll
-            for (int g = 0; g < 2; ++g)
+            for (int g = 0; g < 3; ++g)
 #pragma unroll
                 for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
                     for (int nt = 0; nt < 2; ++nt) {
-                        const int sl = 8 * j + 4 * g + 2 * mt + nt;
-                        if (g == 0) FPC_H2_MFMA(j, mt, nt, TA1[j][mt], U[j][nt]);
+                        const int sl = 12 * j + 4 * g + 2 * mt + nt;
+                        if (g == 0) FPC_H3_MFMA(j, mt, nt, TA1[j][mt], U1[j][nt]);
                         if (g == 1) {
-                            FPC_H2_MFMA(j, mt, nt, TA2[j][mt], U[j][nt]);
-                            if (mt == 1 && !(MODE & 1)) FPC_H2_LOAD_U(j, nt);
+                            FPC_H3_MFMA(j, mt, nt, TA2[j][mt], U1[j][nt]);
+                            if (mt == 1) FPC_H3_LOAD_U1(j, nt);
+                        }
+                        if (g == 2) {
+                            FPC_H3_MFMA(j, mt, nt, TA1[j][mt], U2[j][nt]);
+                            if (mt == 1) FPC_H3_LOAD_U2(j, nt);
                         }
                         if (sl < 4) {
 #pragma unroll
@@ -260,43 +305,41 @@ __global__ __launch_bounds__(256, 1) void k_conv_wino_h2(const WinoArgs a) {
                                 da[sl >> 1][c] = *reinterpret_cast<const f32x4*>(In + in_a[c >> 1] + (c & 1) * in_cs + (sl >> 1) * in_ms);
                                 db[sl >> 1][c] = *reinterpret_cast<const f32x4*>(In + in_b[c >> 1] + (c & 1) * in_cs + (sl >> 1) * in_ms);
                             }
-                            FPC_H2_SPLIT_Q(3, sl);
                         }
                         if (sl >= 4 && sl < 12) {
                             const int m_ = (sl - 4) >> 2, c = (sl - 4) & 3;
                             e[m_][c] = fma_s4(sgn, db[m_][c], da[m_][c]);
-                            FPC_H2_PIN4(e[m_][c]);
+                            FPC_H3_PIN4(e[m_][c]);
                         }
+                        if (sl < 4) FPC_H3_SPLIT_Q(1, sl, 1);
+                        if (sl >= 4 && sl < 8) FPC_H3_SPLIT_Q(2, sl - 4, 1);
+                        if (sl >= 8 && sl < 12) FPC_H3_SPLIT_Q(3, sl - 8, 1);
                         if (sl >= 12 && sl < 20) {
                             const int m_ = (sl - 12) >> 2, jx = (sl - 12) & 3;
                             if (jx == 0) vn[m_][0] = sub_s4(e[m_][0], e[m_][2]);
                             if (jx == 1) vn[m_][1] = add_s4(e[m_][1], e[m_][2]);
                             if (jx == 2) vn[m_][2] = sub_s4(e[m_][2], e[m_][1]);
                             if (jx == 3) vn[m_][3] = sub_s4(e[m_][1], e[m_][3]);
-                            FPC_H2_PIN4(vn[m_][jx]);
+                            FPC_H3_PIN4(vn[m_][jx]);
                         }
-                        if (sl >= 20 && sl < 24) FPC_H2_SPLIT_Q(0, sl - 20);
-                        if (sl >= 24 && sl < 28) FPC_H2_SPLIT_Q(1, sl - 24);
-                        if (sl >= 28) FPC_H2_SPLIT_Q(2, sl - 28);
+                        if (sl >= 20 && sl < 24) FPC_H3_SPLIT_Q(0, sl - 20, 0);
+                        if (sl >= 24 && sl < 28) FPC_H3_SPLIT_Q(1, sl - 24, 0);
+                        if (sl >= 36 && sl < 40) FPC_H3_SPLIT_Q(2, sl - 36, 0);
                         __builtin_amdgcn_sched_barrier(0);
                     }
-#undef FPC_H2_SPLIT_Q
         __builtin_amdgcn_s_setprio(0);
-        so_u += kb + 2 < nkb ? kStepBytes : 0;
-        isb += kb + 3 < nkb ? 8 : 0;
-        // this wave's DMA pieces (issued before the step's 8 weight loads, which stay in flight) have landed
-        if (!(MODE & 2)) {
-            if (MODE & 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-            if (!(MODE & 4)) __syncthreads();                 // everybody's have; this step's fragment reads are done
-        }
-        cur ^= 1;
+        so_u += p + 2 < npair ? kPairBytes : 0;
+        // this wave's ten pieces (issued before the pair's 16 weight loads, which stay in flight) have landed
+        asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+        __syncthreads();                                       // everybody's have; this pair's fragment reads are done
     }
-#undef FPC_H2_MFMA
-#undef FPC_H2_SPLIT_PAIR
-#undef FPC_H2_PIN4
-#undef FPC_H2_ISSUE_IN
-#undef FPC_H2_LOAD_U
+#undef FPC_H3_MFMA
+#undef FPC_H3_SPLIT_PAIR
+#undef FPC_H3_SPLIT_Q
+#undef FPC_H3_PIN4
+#undef FPC_H3_ISSUE_IN
+#undef FPC_H3_LOAD_U1
+#undef FPC_H3_LOAD_U2
 #undef FPC_LDS_ADDR
 #pragma clang diagnostic pop
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the last steps' redundant staging has landed before LDS is reused
@@ -398,43 +441,14 @@ __global__ __launch_bounds__(256, 1) void k_conv_wino_h2(const WinoArgs a) {
     }
 }
 
-// max |w| of a convolution's weights as the bit pattern of a non-negative float (atomicMax on unsigned keeps the order): one atomic
-// per workgroup, at most 64 workgroups (4 096 same-address atomics — one per wave of 1 024 workgroups — took 48 us)
-__global__ __launch_bounds__(256) void k_absmax_bits(const float* __restrict__ w, long long n, unsigned* __restrict__ out) {
-    __shared__ unsigned s_m[4];
-    unsigned m = 0u;
-    const long long n4 = n >> 2;
-    for (long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x; g < n4; g += (long long)gridDim.x * blockDim.x) {
-        const f32x4 v = reinterpret_cast<const f32x4*>(w)[g];
-        m = max(max(m, __builtin_bit_cast(unsigned, fabsf(v[0]))), max(__builtin_bit_cast(unsigned, fabsf(v[1])),
-                max(__builtin_bit_cast(unsigned, fabsf(v[2])), __builtin_bit_cast(unsigned, fabsf(v[3])))));
-    }
-    if (blockIdx.x == 0)
-        for (long long g = 4 * n4 + threadIdx.x; g < n; g += blockDim.x) m = max(m, __builtin_bit_cast(unsigned, fabsf(w[g])));
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o, 64));
-    if ((threadIdx.x & 63) == 0) s_m[threadIdx.x >> 6] = m;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        m = max(max(s_m[0], s_m[1]), max(s_m[2], s_m[3]));
-        if (m) atomicMax(out, m);
-    }
-}
-
-int launch_absmax_bits(const float* w, long long n, unsigned* out, hipStream_t s) {
-    hipLaunchKernelGGL(k_absmax_bits, dim3((unsigned)std::min<long long>((n / 4 + 255) / 256 + 1, 64)), dim3(256), 0, s, w, n, out);
-    return check_launch();
-}
-
-// OIHW 3x3 weights -> U = G g G^T, scaled by s = 2^k (the largest power of two with 2.25 max |w| s < 2^13: |U| <= 2.25 max |w|) and
-// split into two fp16 pieces by truncation (U s = g1 + g2 + rest, |rest| <= 2^-22 |U s|), in the fragment order the lanes load:
-// [Cout/64][Cin/8][xi 16][tile 2][lane 64] x {g1 x 4 ch, g2 x 4 ch}, lane = (channel half) * 32 + (co & 31), tile = (co & 63) >> 5;
-// tail[0] = 1 / s (f32).  tail[1] holds max |w|'s bits (k_absmax_bits).
-__global__ __launch_bounds__(256) void k_wino_pack_h2(const float* __restrict__ w, unsigned short* __restrict__ out, float* __restrict__ tail,
+// k_wino_pack_h2's transform, scale and split; the fragment order of the PAIR form:
+// [Cout/64][Cin/16][xi 16][tile 2][piece 2][lane 64] x {4 ch of the even K-step, 4 ch of the odd one}, lane = (channel half) * 32 + (co & 31),
+// tile = (co & 63) >> 5; tail[0] = 1 / s (f32), tail[1] max |w|'s bits (k_absmax_bits, wino_h2.hip).
+__global__ __launch_bounds__(256) void k_wino_pack_h3(const float* __restrict__ w, unsigned short* __restrict__ out, float* __restrict__ tail,
                                                       int Cout, int Cin) {
     const float wmax = __builtin_bit_cast(float, reinterpret_cast<const unsigned*>(tail)[1]);
     int ex = 0;
-    if (wmax > 0.f && wmax < 3.0e38f) { (void)frexpf(2.25f * wmax, &ex); ex = 13 - ex; }      // 2.25 wmax = m 2^e, m in [0.5, 1): (2.25 wmax) 2^(13 - e) < 2^13
+    if (wmax > 0.f && wmax < 3.0e38f) { (void)frexpf(2.25f * wmax, &ex); ex = 13 - ex; }
     ex = max(-100, min(100, ex));
     const float sc = ldexpf(1.0f, ex);
     if (blockIdx.x == 0 && threadIdx.x == 0) tail[0] = ldexpf(1.0f, -ex);
@@ -445,7 +459,7 @@ __global__ __launch_bounds__(256) void k_wino_pack_h2(const float* __restrict__ 
         float gg[4][3];
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
-            const float g0 = k[c] * sc, g1 = k[3 + c] * sc, g2 = k[6 + c] * sc;      // (a power of two: commutes with the transform's roundings)
+            const float g0 = k[c] * sc, g1 = k[3 + c] * sc, g2 = k[6 + c] * sc;
             gg[0][c] = g0;
             gg[1][c] = 0.5f * (g0 + g1 + g2);
             gg[2][c] = 0.5f * (g0 - g1 + g2);
@@ -453,7 +467,7 @@ __global__ __launch_bounds__(256) void k_wino_pack_h2(const float* __restrict__ 
         }
         const int nb = co >> 6, col = co & 63, nt = col >> 5, kb = ci >> 3, cil = ci & 7, e = cil & 3;
         const int ln = (cil >> 2) * 32 + (col & 31);
-        unsigned short* img = out + ((size_t)nb * (Cin >> 3) + kb) * (kStepBytes / 2);
+        unsigned short* img = out + ((size_t)nb * (Cin >> 4) + (kb >> 1)) * (kPairBytes / 2);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const float r0 = gg[i][0], r1 = gg[i][1], r2 = gg[i][2];
@@ -464,43 +478,38 @@ __global__ __launch_bounds__(256) void k_wino_pack_h2(const float* __restrict__ 
                 const fp16x2 h = __builtin_amdgcn_cvt_pkrtz(x, 0.f);
                 const float r = x - (float)h[0];
                 const fp16x2 h2 = __builtin_amdgcn_cvt_pkrtz(r, 0.f);
-                unsigned short* frag = img + ((4 * i + jx) * 2048 + nt * 1024 + ln * 16) / 2;
-                frag[e] = (unsigned short)(__builtin_bit_cast(unsigned, h) & 0xFFFFu);
-                frag[4 + e] = (unsigned short)(__builtin_bit_cast(unsigned, h2) & 0xFFFFu);
+                unsigned short* frag = img + ((4 * i + jx) * 4096 + nt * 2048 + ln * 16) / 2;
+                frag[(kb & 1) * 4 + e] = (unsigned short)(__builtin_bit_cast(unsigned, h) & 0xFFFFu);
+                frag[512 + (kb & 1) * 4 + e] = (unsigned short)(__builtin_bit_cast(unsigned, h2) & 0xFFFFu);
             }
         }
     }
 }
 
-// .w = the k_wino_pack_h2 image (+ its tail), .waves = 8 (tby = ceil(ceil(H / 2) / 8): 8 x 8 tile patches)
-int launch_conv_wino_h2(const WinoArgs& a, int groups, hipStream_t s) {
-    if (groups < 1 || groups > kMaxGroup || a.Cin % 8 != 0 || a.Cout % kBN != 0) return FPC_EINVAL;
+// .w = the k_wino_pack_h3 image (+ its tail), tby = ceil(ceil(H / 2) / 8): 8 x 8 tile patches
+int launch_conv_wino_h3(const WinoArgs& a, int groups, hipStream_t s) {
+    if (groups < 1 || groups > kMaxGroup || a.Cin % 16 != 0 || a.Cout % kBN != 0) return FPC_EINVAL;      // pairs of 8-channel K-steps
     if ((long long)a.H * a.W * a.Cin * (long long)sizeof(float) >= (1LL << 32)) return FPC_EINVAL;      // 32-bit lane offsets inside one image
-    if ((long long)(a.Cin >> 3) * kStepBytes >= (1LL << 31)) return FPC_EINVAL;                          // 31-bit buffer offsets inside one block's images
+    if ((long long)(a.Cin >> 4) * kPairBytes >= (1LL << 31)) return FPC_EINVAL;                          // 31-bit buffer offsets inside one block's images
     if (a.tbx != cdiv(cdiv(a.W, 2), kTX) || a.tby != cdiv(cdiv(a.H, 2), kTY)) return FPC_EINVAL;
     const long long nblk = (long long)a.tbx * a.tby * a.B * (a.Cout / kBN) * groups;
     if (nblk < 1 || nblk >= (1LL << 31)) return FPC_EINVAL;
-    static const int mode = getenv("FPC_H2_MODE") ? atoi(getenv("FPC_H2_MODE")) : 0;      // diagnostic
-    if (mode == 1) hipLaunchKernelGGL(k_conv_wino_h2<1>, dim3((unsigned)nblk), dim3(256), 0, s, a);
-    else if (mode == 2) hipLaunchKernelGGL(k_conv_wino_h2<2>, dim3((unsigned)nblk), dim3(256), 0, s, a);
-    else if (mode == 3) hipLaunchKernelGGL(k_conv_wino_h2<3>, dim3((unsigned)nblk), dim3(256), 0, s, a);
-    else if (mode == 5) hipLaunchKernelGGL(k_conv_wino_h2<5>, dim3((unsigned)nblk), dim3(256), 0, s, a);      // no weights, DMA, no barrier
-    else if (mode == 9) hipLaunchKernelGGL(k_conv_wino_h2<9>, dim3((unsigned)nblk), dim3(256), 0, s, a);      // no weights, barrier, no DMA
-    else if (mode == 4) hipLaunchKernelGGL(k_conv_wino_h2<4>, dim3((unsigned)nblk), dim3(256), 0, s, a);      // everything but the barrier
-    else hipLaunchKernelGGL(k_conv_wino_h2<0>, dim3((unsigned)nblk), dim3(256), 0, s, a);
+    static const int var = getenv("FPC_H3_VAR") ? atoi(getenv("FPC_H3_VAR")) : 0;      // diagnostic
+    if (var == 1) hipLaunchKernelGGL(k_conv_wino_h3<1>, dim3((unsigned)nblk), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL(k_conv_wino_h3<0>, dim3((unsigned)nblk), dim3(256), 0, s, a);
     return check_launch();
 }
 
-// fp16 x 2 fragment-order image: 16 * Cout * Cin floats + a tail of 2 (1 / scale, max |w| bits); every byte is written
-int launch_wino_pack_h2(const float* w_oihw, float* packed, int Cout, int Cin, hipStream_t s) {
-    if (Cin % 8 != 0 || Cout % kBN != 0) return FPC_EINVAL;
+// pair-order fp16 x 2 image: 16 * Cout * Cin floats + a tail of 2 (1 / scale, max |w| bits); every byte is written
+int launch_wino_pack_h3(const float* w_oihw, float* packed, int Cout, int Cin, hipStream_t s) {
+    if (Cin % 16 != 0 || Cout % kBN != 0) return FPC_EINVAL;
     float* tail = packed + (size_t)16 * Cout * Cin;
     if (hipMemsetAsync(tail, 0, 2 * sizeof(float), s) != hipSuccess) return FPC_ELAUNCH;
-    const long long nw = (long long)Cout * Cin * 9, work = (long long)Cout * Cin;
     if ((uintptr_t)w_oihw & 15) return FPC_EINVAL;
-    const int rc = launch_absmax_bits(w_oihw, nw, reinterpret_cast<unsigned*>(tail) + 1, s);
+    const int rc = launch_absmax_bits(w_oihw, (long long)Cout * Cin * 9, reinterpret_cast<unsigned*>(tail) + 1, s);
     if (rc) return rc;
-    hipLaunchKernelGGL(k_wino_pack_h2, dim3((unsigned)std::min<long long>((work + 255) / 256, 4096)), dim3(256), 0, s, w_oihw,
+    const long long work = (long long)Cout * Cin;
+    hipLaunchKernelGGL(k_wino_pack_h3, dim3((unsigned)std::min<long long>((work + 255) / 256, 4096)), dim3(256), 0, s, w_oihw,
                        reinterpret_cast<unsigned short*>(packed), tail, Cout, Cin);
     return check_launch();
 }

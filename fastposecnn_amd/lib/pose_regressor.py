@@ -252,7 +252,8 @@ class PoseRegressor(Model, torch.nn.Module):
                             # 0: f32 matrix products only; 1: + the bf16 x 3 forms; 2: + the fp16 x 2 Winograd form (range-limited
                             # operands, csrc/wino_h2.hip) — HPARAM.ENGINE_SPLIT_PRECISION / ENGINE_SPLIT_F16
                             split_precision=(0 if not getattr(self.HPARAM, 'ENGINE_SPLIT_PRECISION', True)
-                                             else (2 if getattr(self.HPARAM, 'ENGINE_SPLIT_F16', True) else 1)))
+                                             else (1 if not getattr(self.HPARAM, 'ENGINE_SPLIT_F16', True)
+                                                   else (3 if getattr(self.HPARAM, 'ENGINE_SPLIT_F16_3P', True) else 2))))
             eng.generation = self._weights_gen[0]
             self._engines[key] = eng
         elif eng.stale() or eng.generation != self._weights_gen[0]:

@@ -12,7 +12,7 @@ if len(sys.argv) > 6:      # python tools_dev/wino_stamps.py VAR B Cin H W Cout
 x = torch.randn((B, Hi, Wi, Cin), device=dev); w = torch.randn((Cout, Cin, k, k), device=dev) * 0.05
 out = torch.empty((B, Hi, Wi, Cout), device=dev)
 ws = torch.empty(L.fpc_conv2d_workspace_bytes(B, Hi, Wi, Cin, Cout, k, k), dtype=torch.uint8, device=dev)
-nblk = (-(-(Wi // 2) // 8) * (-(-(Hi // 2) // (8 if VAR in (-4, -2, -5, -7, -8) else 4)))) * B * (Cout // (128 if VAR == -6 else 64))
+nblk = (-(-(Wi // 2) // 8) * (-(-(Hi // 2) // (8 if VAR in (-4, -2, -5, -7, -8, -9) else 4)))) * B * (Cout // (128 if VAR == -6 else 64))
 dbg = torch.zeros((nblk, NWAVE, 8), dtype=torch.int64, device=dev)
 sb, sh, sw, sc = x.stride(); st = torch.cuda.current_stream().cuda_stream
 for _ in range(200):
