@@ -27,7 +27,10 @@ FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-ffp-contract=
 FILE_FLAGS = {"vote_count.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form", "-fno-slp-vectorize"],
               # one wave per SIMD beside its own MFMAs: a packed f32 instruction costs ~13 cycles more than the two scalar ones it
               # replaces (MI355X_MICROARCH.md, "price of one filler beside MFMAs"); plain -O3 SLP-packs the splits' subtractions
-              "wino_w4.hip": ["-fno-slp-vectorize"], "wino128.hip": ["-fno-slp-vectorize"], "wino_h2.hip": ["-fno-slp-vectorize"], "wino_h3.hip": ["-fno-slp-vectorize"]}
+              "wino_w4.hip": ["-fno-slp-vectorize"], "wino128.hip": ["-fno-slp-vectorize"], "wino_h2.hip": ["-fno-slp-vectorize"], # wino_h3.hip: its 48-slot loop body is unrolled from four nested loops whose body names every slot's item; the size estimate
+              # BEFORE the slot conditions fold exceeds the default pragma-unroll threshold (the loop then stays rolled and the accumulators
+              # go to scratch)
+              "wino_h3.hip": ["-fno-slp-vectorize", "-mllvm", "-pragma-unroll-threshold=4000000"]}
 
 
 def sources():

@@ -96,8 +96,10 @@ __global__ __launch_bounds__(256, 1) void k_conv_wino_h3(const WinoArgs a) {
     const int vo_u = lane * 16;
     int so_u = wi * 4 * 4096;      // this wave's four xi; + kPairBytes per pair
     u32x4 U1[4][2], U2[4][2];
-#define FPC_H3_LOAD_U1(J, NT) U1[J][NT] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_w, vo_u, so_u + (J) * 4096 + (NT) * 2048, 0))
-#define FPC_H3_LOAD_U2(J, NT) U2[J][NT] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_w, vo_u, so_u + (J) * 4096 + (NT) * 2048 + 1024, 0))
+#define FPC_H3_LOAD_U1_AT(SO, J, NT) U1[J][NT] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_w, vo_u, (SO) + (J) * 4096 + (NT) * 2048, 0))
+#define FPC_H3_LOAD_U2_AT(SO, J, NT) U2[J][NT] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_w, vo_u, (SO) + (J) * 4096 + (NT) * 2048 + 1024, 0))
+#define FPC_H3_LOAD_U1(J, NT) FPC_H3_LOAD_U1_AT(so_u, J, NT)
+#define FPC_H3_LOAD_U2(J, NT) FPC_H3_LOAD_U2_AT(so_u, J, NT)
 #pragma unroll
     for (int j = 0; j < 4; ++j)
 #pragma unroll
@@ -203,9 +205,10 @@ __global__ __launch_bounds__(256, 1) void k_conv_wino_h3(const WinoArgs a) {
     asm volatile("s_mov_b32 %0, 0xbf800000" : "=s"(m1));      // -1.0f, opaque
     // one pair of values of vn[MT][J] -> its fp16 pieces, into half HALF of the operands (pinned to its slot by the volatile asm that
     // reads them, as wino_w4.hip's items)
-#define FPC_H3_SPLIT_PAIR(J, MT, PAIR, HALF)                                                                  \
+#define FPC_H3_SPLIT_PAIR(J, MT, PAIR, HALF) FPC_H3_SPLIT_PAIR_V(vn, J, MT, PAIR, HALF)
+#define FPC_H3_SPLIT_PAIR_V(V, J, MT, PAIR, HALF)                                                             \
     do {                                                                                                      \
-        const float x0_ = vn[MT][J][2 * (PAIR)], x1_ = vn[MT][J][2 * (PAIR) + 1];                             \
+        const float x0_ = V[MT][J][2 * (PAIR)], x1_ = V[MT][J][2 * (PAIR) + 1];                               \
         const fp16x2 h_ = __builtin_amdgcn_cvt_pkrtz(x0_, x1_);                                               \
         /* x - h1 in ONE instruction: v_fma_mix_f32 reads the fp16 piece in place (m1 = -1 in a scalar register the compiler cannot  \
            fold); exact like the conversion + subtraction it replaces (VAR 1) */                                                  \
@@ -241,17 +244,10 @@ __global__ __launch_bounds__(256, 1) void k_conv_wino_h3(const WinoArgs a) {
     const long long c_begin = a.dbg ? clock64() : 0, r_begin = a.dbg ? wall_clock64() : 0;
 #pragma unroll 1
     for (int p = 0; p < npair; ++p) {
-        // inputs of steps 2p + 3 and 2p + 4 -> the buffers steps 2p - 1 and 2p were read from before the last barrier
-        FPC_H3_ISSUE_IN((sn & 3), isb);
-        if (sn + 1 < nkb) isb += 8;
-        FPC_H3_ISSUE_IN(((sn + 1) & 3), isb);
-        if (sn + 2 < nkb) isb += 8;
-        sn += 2;
         // ---- E: step 2p + 1's fragment reads and transform; the odd halves of xi 0 (xi 1-3 follow behind O's first matrix instructions).
         // No matrix instruction is in flight behind the barrier: plain code, the sixteen fragment reads issued together.
         {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) FPC_H3_SPLIT_Q(3, q, 0);      // xi 3 of step 2p: its operands were in use until the end of O
+            // the sixteen fragment reads first: 64 KB per workgroup = 512 cycles of the LDS pipe, under the staging burst and xi 3's split
             const float* InE = lds + ((2 * p + 1) & 3) * kInFloats;
             f32x4 ea[2][4], eb[2][4];
 #pragma unroll
@@ -261,6 +257,15 @@ __global__ __launch_bounds__(256, 1) void k_conv_wino_h3(const WinoArgs a) {
                     ea[mt][c] = *reinterpret_cast<const f32x4*>(InE + in_a[c >> 1] + (c & 1) * in_cs + mt * in_ms);
                     eb[mt][c] = *reinterpret_cast<const f32x4*>(InE + in_b[c >> 1] + (c & 1) * in_cs + mt * in_ms);
                 }
+            __builtin_amdgcn_sched_barrier(0);
+            // inputs of steps 2p + 3 and 2p + 4 -> the buffers steps 2p - 1 and 2p were read from before the last barrier
+            FPC_H3_ISSUE_IN((sn & 3), isb);
+            if (sn + 1 < nkb) isb += 8;
+            FPC_H3_ISSUE_IN(((sn + 1) & 3), isb);
+            if (sn + 2 < nkb) isb += 8;
+            sn += 2;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) FPC_H3_SPLIT_Q(3, q, 0);      // xi 3 of step 2p: its operands were in use until the end of O
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int mt = 0; mt < 2; ++mt) {
@@ -335,11 +340,14 @@ __global__ __launch_bounds__(256, 1) void k_conv_wino_h3(const WinoArgs a) {
     }
 #undef FPC_H3_MFMA
 #undef FPC_H3_SPLIT_PAIR
+#undef FPC_H3_SPLIT_PAIR_V
 #undef FPC_H3_SPLIT_Q
 #undef FPC_H3_PIN4
 #undef FPC_H3_ISSUE_IN
 #undef FPC_H3_LOAD_U1
 #undef FPC_H3_LOAD_U2
+#undef FPC_H3_LOAD_U1_AT
+#undef FPC_H3_LOAD_U2_AT
 #undef FPC_LDS_ADDR
 #pragma clang diagnostic pop
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the last steps' redundant staging has landed before LDS is reused
