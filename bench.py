@@ -482,7 +482,7 @@ def check_gather(model_gpu, gatherer, cat, Bq, world, rank, cap, dev):
 
 
 def run_inference(args, encoder, Bq, hn, steps, warmup, world, rank, dev, want_backbone=True, split_precision=None, coalesce=1, tune_trials=1,
-                  split_f16=None):
+                  split_f16=None, split_f16_3p=None):
     """The timed hot path for one (encoder, batch) configuration.  Returns a dict of measurements and the objects
     later sections reuse."""
     import torch
@@ -500,6 +500,8 @@ def run_inference(args, encoder, Bq, hn, steps, warmup, world, rank, dev, want_b
                                  if split_precision is None else bool(split_precision))
     hp.ENGINE_SPLIT_F16 = (bool(int(os.environ.get('FPC_SPLIT_F16', '1')))      # 0: split-precision sites use the bf16 x 3 forms only
                            if split_f16 is None else bool(split_f16))
+    hp.ENGINE_SPLIT_F16_3P = (bool(int(os.environ.get('FPC_SPLIT_F16_3P', '1')))      # 0: the fp16 forms keep all four piece products
+                              if split_f16_3p is None else bool(split_f16_3p))
     hp.ENGINE_GRAPH = bool(int(os.environ.get('FPC_ENGINE_GRAPH', '1')))      # HIP graph replay of the frame-invariant launches
     torch.manual_seed(0)
     model = L.pose_regressor.MODELS[hp.MODEL].load_from_ckpt(None, hp).eval()
@@ -846,7 +848,7 @@ def promote_config3(line, c3, r3, args):
                    "img_per_s_from_png_files": r3.get("png_files_img_per_s"), **shared},
         "roofline": c3["roofline"],
     }
-    for k in ("backbone", "cpu_baseline", "bf16x3_products"):
+    for k in ("backbone", "cpu_baseline", "bf16x3_products", "fp16_four_products"):
         if k in c3:
             top[k] = c3[k]
     for k in ("higher_is_better", "scaling", "vs_baseline", "dtype", "data", "unit"):
@@ -938,13 +940,17 @@ def main():
                                            "faster a convolution's products run in SPLIT PRECISION on the 16-bit matrix instructions: (a) the "
                                            "exact three-way bf16 split of both operands, six partial products on v_mfma_f32_32x32x16_bf16, "
                                            "dropped terms < 2^-23 — any operand range; (b) round 6, 3x3 / stride-1 sites only "
-                                           "(csrc/wino_h2.hip): two fp16 pieces per operand (22 significant bits), three products in two "
-                                           "v_mfma_f32_32x32x16_f16, weights scaled by a power of two on the device, activations as they "
+                                           "(csrc/wino_h2.hip, wino_h3.hip): two fp16 pieces per operand (22 significant bits) on "
+                                           "v_mfma_f32_32x32x16_f16 — all four piece products in two instructions per 8 channels, or (the "
+                                           "default where Cin is a multiple of 16) three of them in three instructions per 16 channels: the "
+                                           "dropped h2 g2 is <= 2^-22 of the term, the size of the two terms any two-piece form drops; "
+                                           "weights scaled by a power of two on the device, activations as they "
                                            "come: 2^-22 relative for |v| >= 2^-3, 2^-25 absolute below, saturation beyond 1.3e5 — f32-level "
                                            "for activations of ordinary scale, held to the same bars (2e-5 per convolution, 1e-4 of the "
                                            "logits against float64 with EVERY eligible site forced onto it: tests/test_gpu_net.py).  "
-                                           "FPC_SPLIT_F16=0 (HPARAM.ENGINE_SPLIT_F16 = False) keeps (a) only — `bf16x3_products` is that "
-                                           "measurement; FPC_SPLIT_PRECISION=0 keeps every product on v_mfma_f32_32x32x2_f32")
+                                           "FPC_SPLIT_F16_3P=0 (HPARAM.ENGINE_SPLIT_F16_3P = False) keeps all four products — "
+                                           "`fp16_four_products`; FPC_SPLIT_F16=0 (HPARAM.ENGINE_SPLIT_F16 = False) keeps (a) only — `bf16x3_products`; "
+                                           "FPC_SPLIT_PRECISION=0 keeps every product on v_mfma_f32_32x32x2_f32")
                                           if os.environ.get("FPC_SPLIT_PRECISION", "1") != "0" else
                                           "plain f32 matrix products (v_mfma_f32_32x32x2_f32) everywhere: FPC_SPLIT_PRECISION=0",
                        "post_network_input": "synthetic vote-bench fixture (SURVEY.md 8d), not the random-weight network's output",
@@ -1043,6 +1049,14 @@ def main():
                                                  "(no operand-range limit); a shorter timed region than `value`'s"}
                 del rb3, ctxb3
                 torch.cuda.empty_cache()
+                if os.environ.get("FPC_SPLIT_F16_3P", "1") != "0":
+                    rb4, ctxb4 = run_inference(args, "resnet34", 32, args.hn, max(6, st // 3), 2, 1, 0, dev, split_f16_3p=False)
+                    c3["fp16_four_products"] = {"value": rb4["value"], "unit": "img/s", "ms_per_step": rb4["ms_per_step"], "steps": rb4["steps"],
+                                                "backbone": {k: rb4["backbone"][k] for k in ("ms", "achieved", "frac")} if "backbone" in rb4 else None,
+                                                "note": "HPARAM.ENGINE_SPLIT_F16_3P = False: the fp16-pieces sites keep all four piece products "
+                                                        "(csrc/wino_h2.hip); a shorter timed region than `value`'s"}
+                    del rb4, ctxb4
+                    torch.cuda.empty_cache()
             if args.promote and not args.no_cpu_baseline:
                 one3 = {k: v[:1] for k, v in ctx3["cat_cpu"].items()}
                 c3["cpu_baseline"] = cpu_baseline(ctx3["model"].to("cpu"), ctx3["image"][:1], one3, args.hn,

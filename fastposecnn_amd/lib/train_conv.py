@@ -89,6 +89,8 @@ def conv_nhwc(x, w, bias, stride, pad, up=None, allow_f16=False):
                 if allow_f16 and SPLIT_F16:
                     cands.append(-8)    # two fp16 pieces per operand (wino_h2.hip): FORWARD convolutions only — their operand is an
                     #                     activation of ordinary scale; a data gradient's operand is dy, whose values are tiny
+                    #                     (the three-product form, -9, measured on the batch-8 step: forward 10.3-10.5 ms against 8.6-9.3 — its
+                    #                     entry stages three K-steps and sixteen weight fragments; not a candidate here)
         if SPLIT_PRECISION and Kh == 1 and Kw == 1 and stride == 1 and pad == 0 and Cin in (64, 128) and Cout % 32 == 0:
             cands += [2000 + p for p in (1, 2, 4) if (Cout // 32) % p == 0]      # pixel-resident lateral product (lateral.hip)
         best = (float("inf"), 0)

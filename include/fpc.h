@@ -363,11 +363,14 @@ int fpc_net_autotune_next(fpc_net_t* net, int mode /* 0: minimise each conv's la
  * float64, like another summation order) without being bit-identical to the f32 product chain.  Set before
  * fpc_net_autotune_next.  fpc_net_conv_plan reports -5 / -6 / -7 for a split-precision Winograd site (8 waves / 128 channels per
  * workgroup / four waves of 512 registers).
- * 2 (round 6): additionally the fp16 x 2 Winograd form (csrc/wino_h2.hip, reported as -8): two fp16 pieces per operand, three
- * products in two matrix instructions.  Weights are scaled by a power of two on the device; a transformed ACTIVATION v is
+ * 2 (round 6): additionally the fp16 x 2 Winograd form (csrc/wino_h2.hip, reported as -8): two fp16 pieces per operand, all four
+ * piece products in two matrix instructions per 8 channels.  Weights are scaled by a power of two on the device; a transformed ACTIVATION v is
  * represented to 2^-22 |v| while |v| >= 2^-3, to 2^-25 absolute below, and saturates beyond 1.3e5 — f32-level accuracy for
  * activations of ordinary scale (the tests hold it to the bars of every other form), NOT for tensors of tiny or huge values.  The
- * Python front end uses 2 unless HPARAM.ENGINE_SPLIT_F16 is False. */
+ * 3: additionally (and, where Cin is a multiple of 16, INSTEAD of -8) its three-product form (csrc/wino_h3.hip, reported as -9):
+ * h1 g1 + h2 g1 + h1 g2 in three matrix instructions per 16 channels; the dropped h2 g2 is <= 2^-22 of the term — the size of the
+ * two terms every two-piece form drops — and the same tests hold it to the same bars.
+ * The Python front end uses 3 unless HPARAM.ENGINE_SPLIT_F16_3P (then 2) or HPARAM.ENGINE_SPLIT_F16 (then 1) is False. */
 int fpc_net_set_split_precision(fpc_net_t* net, int on);
 /* HIP graph replay (default 0).  1: after autotuning, the frame-invariant launches of fpc_net_forward (everything
  * between the image conversion and the final upsample / class compression, ~57 kernels on the plan's workspace) are
