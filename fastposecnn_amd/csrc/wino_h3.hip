@@ -191,7 +191,7 @@ __global__ __launch_bounds__(256, 1) void k_conv_wino_h3(const WinoArgs a) {
                 for (int r = 0; r < 16; ++r) acc[j][mt][nt][r] = 0.f;
 
     const long long t_issued = a.dbg ? clock64() : 0;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt vmcnt(10)" ::: "memory");      // the weight fragments and step 0 (steps 1, 2 land under step 0's transform)
     const long long t_landed = a.dbg ? clock64() : 0;
     __syncthreads();
     const long long t_synced = a.dbg ? clock64() : 0;
@@ -236,7 +236,8 @@ __global__ __launch_bounds__(256, 1) void k_conv_wino_h3(const WinoArgs a) {
             for (int j = 0; j < 3; ++j) { FPC_H3_SPLIT_PAIR(j, mt, 0, 0); FPC_H3_SPLIT_PAIR(j, mt, 1, 0); }
         }
     }
-    __syncthreads();       // buffer 0 is refilled by the pieces of step 4, issued at the top of pair 0
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // steps 1 and 2
+    __syncthreads();       // everybody's have landed; buffer 0 is refilled by the pieces of step 4, issued at the top of pair 0
 
 #define FPC_H3_MFMA(J, MT, NT, A, B) acc[J][MT][NT] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, A), __builtin_bit_cast(f16x8, B), acc[J][MT][NT], 0, 0, 0)
 #define FPC_H3_PIN4(V) asm volatile("" :: "v"(V))
