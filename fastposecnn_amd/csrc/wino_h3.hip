@@ -173,13 +173,13 @@ __global__ __launch_bounds__(256, 1) void k_conv_wino_h3(const WinoArgs a) {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __syncthreads();
     }
-    // steps 0, 1, 2 -> buffers 0, 1, 2 (a step past the last one re-reads the last: the same count of pieces whatever Cin)
+    // steps 0, 1, 2 -> buffers 0, 1, 2
     FPC_H3_ISSUE_IN(0, isb);
     isb += 8;                      // (nkb >= 2)
     FPC_H3_ISSUE_IN(1, isb);
-    if (nkb > 2) isb += 8;
-    FPC_H3_ISSUE_IN(2, isb);
-    if (nkb > 3) isb += 8;
+    isb += 8;
+    FPC_H3_ISSUE_IN(2, nkb > 2 ? isb : isb - 8);      // (nkb = 2: step 1 again — the same count of pieces in front of the first wait)
+    isb += 8;
     int sn = 3;                    // the next step to stage
 #pragma unroll
     for (int j = 0; j < 4; ++j)
@@ -260,10 +260,10 @@ __global__ __launch_bounds__(256, 1) void k_conv_wino_h3(const WinoArgs a) {
                 }
             __builtin_amdgcn_sched_barrier(0);
             // inputs of steps 2p + 3 and 2p + 4 -> the buffers steps 2p - 1 and 2p were read from before the last barrier
-            FPC_H3_ISSUE_IN((sn & 3), isb);
-            if (sn + 1 < nkb) isb += 8;
-            FPC_H3_ISSUE_IN(((sn + 1) & 3), isb);
-            if (sn + 2 < nkb) isb += 8;
+            // (a step past the last is not staged: the end-of-pair wait counts the sixteen weight loads BEHIND the pieces, so fewer
+            // pieces in front of them keep it exact)
+            if (sn < nkb) { FPC_H3_ISSUE_IN((sn & 3), isb); isb += 8; }
+            if (sn + 1 < nkb) { FPC_H3_ISSUE_IN(((sn + 1) & 3), isb); isb += 8; }
             sn += 2;
 #pragma unroll
             for (int q = 0; q < 4; ++q) FPC_H3_SPLIT_Q(3, q, 0);      // xi 3 of step 2p: its operands were in use until the end of O
