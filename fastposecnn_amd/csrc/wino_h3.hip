@@ -351,7 +351,8 @@ __global__ __launch_bounds__(256, 1) void k_conv_wino_h3(const WinoArgs a) {
 #undef FPC_H3_LOAD_U2_AT
 #undef FPC_LDS_ADDR
 #pragma clang diagnostic pop
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the last steps' redundant staging has landed before LDS is reused
+    // (no staging is in flight here: a step past the last is never issued, every real step was waited for at the end of its pair; the
+    // last pair's redundant weight reloads target registers, whose reuse the compiler guards itself)
     const long long t_kend = a.dbg ? clock64() : 0;
     if (a.dbg && lane == 0) {      // tools_dev/wino_stamps.py: shader-clock ticks and 100 MHz reference ticks of the K loop, entry -> loop
         long long* o = a.dbg + ((size_t)blockIdx.x * 4 + wi) * 8;
