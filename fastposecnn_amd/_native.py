@@ -31,6 +31,8 @@ _SIGNATURES = {
     "fpc_ransac_voting_v3": (_i, [_vp, _vp, _i64, _i64, _i64, _i64, _i, _vp, _i, _i, _i, _vp, _vp, _u64, _f, _i, _i,
                                   _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "fpc_ransac_voting_v3_bits": (_i, [_vp, _vp, _vp, _i64, _i64, _i64, _i64, _i, _vp, _i, _i, _i, _vp, _vp, _u64, _f, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "fpc_ransac_voting_v3_pose": (_i, [_vp, _vp, _vp, _i64, _i64, _i64, _i64, _i, _vp, _i, _i, _i, _vp, _vp, _u64, _f, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
+                                       _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "fpc_vote_set_prune": (_i, [_i, _i, ctypes.POINTER(ctypes.c_int32)]),
     "fpc_vote_prune_info": (_i, [_vp, _sz, _i, _i, _i, _i, _vp, _vp]),
     "fpc_class_compress": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),

@@ -11,36 +11,7 @@ __global__ void k_pose_rt(const float* __restrict__ q, const float* __restrict__
                           float* __restrict__ RT) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    float zz = div_ieee(z[i], 1000.0f);
-    float px = xy[2 * i] * zz, py = xy[2 * i + 1] * zz;
-    float t[3];
-#pragma unroll
-    for (int r = 0; r < 3; ++r) t[r] = kinv[3 * r] * px + kinv[3 * r + 1] * py + kinv[3 * r + 2] * zz;
-    float q1 = q[4 * i], q2 = q[4 * i + 1], q3 = q[4 * i + 2], q4 = q[4 * i + 3];
-    float nrm = sqrtf(q1 * q1 + q2 * q2 + q3 * q3 + q4 * q4);
-    if (!(nrm > 0.0f)) nrm = 1.0f;
-    q1 = div_ieee(q1, nrm); q2 = div_ieee(q2, nrm); q3 = div_ieee(q3, nrm); q4 = div_ieee(q4, nrm);
-    float a = q1 * q1, b = q2 * q2, c = q3 * q3, d = q4 * q4;
-    // M as written at gpu_tensor_funcs.py:316-324; the function returns its transpose
-    float M[9] = {a - b - c + d, 2 * (q1 * q2 + q3 * q4), 2 * (q1 * q3 - q2 * q4),
-                  2 * (q1 * q2 - q3 * q4), -a + b - c + d, 2 * (q2 * q3 + q1 * q4),
-                  2 * (q1 * q3 + q2 * q4), 2 * (q2 * q3 - q1 * q4), -a - b + c + d};
-    float Ri[9];
-#pragma unroll
-    for (int r = 0; r < 3; ++r)
-#pragma unroll
-        for (int cc = 0; cc < 3; ++cc) Ri[3 * r + cc] = M[3 * cc + r];
-#pragma unroll
-    for (int k = 0; k < 9; ++k) R[9 * (size_t)i + k] = Ri[k];
-#pragma unroll
-    for (int r = 0; r < 3; ++r) T[3 * (size_t)i + r] = t[r];
-    float* G = RT + 16 * (size_t)i;
-#pragma unroll
-    for (int r = 0; r < 3; ++r) {
-        G[4 * r] = Ri[3 * r]; G[4 * r + 1] = Ri[3 * r + 1]; G[4 * r + 2] = Ri[3 * r + 2];
-        G[4 * r + 3] = -(Ri[3 * r] * t[0] + Ri[3 * r + 1] * t[1] + Ri[3 * r + 2] * t[2]);
-    }
-    G[12] = 0.0f; G[13] = 0.0f; G[14] = 0.0f; G[15] = 1.0f;
+    pose_rt_one((size_t)i, xy[2 * i], xy[2 * i + 1], q, z, kinv, R, T, RT);
 }
 
 // Pose records of one rank for the multi-GPU gather (fastposecnn_amd/parallel.py): out f32 [capacity + 1][40].

@@ -675,6 +675,7 @@ __global__ __launch_bounds__(64 * kFinWaves) void k_vote_final(const VoteParams 
     for (int inst = blockIdx.x * blockDim.x + threadIdx.x; inst < n_act; inst += gridDim.x * blockDim.x)
         if (p.plan[(size_t)inst * kPlanI + 6] == 0) {
             p.out_xy[inst * 2] = 0.0f; p.out_xy[inst * 2 + 1] = 0.0f;
+            if (p.pose_RT) pose_rt_one((size_t)inst, 0.0f, 0.0f, p.pose_q, p.pose_z, p.pose_kinv, p.pose_R, p.pose_T, p.pose_RT);
             if (p.out_tn) p.out_tn[inst] = p.plan[(size_t)inst * kPlanI + 1];
             if (p.out_win_idx) p.out_win_idx[inst] = -1;
             if (p.out_win_count) p.out_win_count[inst] = 0;
@@ -807,6 +808,7 @@ __global__ __launch_bounds__(64 * kFinWaves) void k_vote_final(const VoteParams 
             solve2_sym(tot[1], tot[2], tot[3], tot[4], tot[5], x0, x1);
             p.out_xy[inst * 2] = (float)x0;
             p.out_xy[inst * 2 + 1] = (float)x1;
+            if (p.pose_RT) pose_rt_one((size_t)inst, (float)x0, (float)x1, p.pose_q, p.pose_z, p.pose_kinv, p.pose_R, p.pose_T, p.pose_RT);
             if (p.out_tn) p.out_tn[inst] = p.plan[(size_t)inst * kPlanI + 1];
             if (p.out_win_idx) p.out_win_idx[inst] = wi;
             if (p.out_win_count) p.out_win_count[inst] = wc;
@@ -906,6 +908,21 @@ extern "C" int fpc_ransac_voting_v3_bits(const float* mask, const uint64_t* mask
                                          int32_t* out_win_count, int32_t* out_inl_count, float* out_hyp,
                                          int32_t* out_counts, double* out_refine, void* ws, size_t ws_bytes,
                                          fpc_stream_t stream) {
+    return fpc_ransac_voting_v3_pose(mask, mask_bits, vertex, vs_n, vs_h, vs_w, vs_c, n, n_dev, H, W, hn, idxs, keep, seed, inlier_thresh,
+                                     min_num, max_num, out_xy, out_tn, out_win_idx, out_win_count, out_inl_count, out_hyp, out_counts,
+                                     out_refine, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, ws, ws_bytes, stream);
+}
+
+extern "C" int fpc_ransac_voting_v3_pose(const float* mask, const uint64_t* mask_bits, const float* vertex, int64_t vs_n,
+                                         int64_t vs_h, int64_t vs_w, int64_t vs_c, int n, const int32_t* n_dev, int H, int W, int hn,
+                                         const int32_t* idxs, const uint8_t* keep, uint64_t seed, float inlier_thresh,
+                                         int min_num, int max_num, float* out_xy, int32_t* out_tn, int32_t* out_win_idx,
+                                         int32_t* out_win_count, int32_t* out_inl_count, float* out_hyp,
+                                         int32_t* out_counts, double* out_refine, const float* pose_q, const float* pose_z,
+                                         const float* pose_kinv, float* pose_R, float* pose_T, float* pose_RT, void* ws,
+                                         size_t ws_bytes, fpc_stream_t stream) {
+    const bool pose = pose_q || pose_z || pose_kinv || pose_R || pose_T || pose_RT;
+    if (pose && !(pose_q && pose_z && pose_kinv && pose_R && pose_T && pose_RT)) return FPC_EINVAL;      // all six or none
     if (n < 0 || H < 1 || W < 1 || hn < 1 || hn > kMaxHn || max_num < 1) return FPC_EINVAL;
     if ((int64_t)H * W > (1 << 30) || H > 65535 || W > 65535) return FPC_EINVAL;
     if (n == 0) return FPC_OK;
@@ -923,6 +940,7 @@ extern "C" int fpc_ransac_voting_v3_bits(const float* mask, const uint64_t* mask
     p.idxs = idxs; p.keep = keep; p.seed = seed; p.thresh = inlier_thresh; p.min_num = min_num; p.max_num = max_num;
     p.out_xy = out_xy; p.out_tn = out_tn; p.out_win_idx = out_win_idx; p.out_win_count = out_win_count;
     p.out_inl = out_inl_count; p.out_refine = out_refine;
+    p.pose_q = pose_q; p.pose_z = pose_z; p.pose_kinv = pose_kinv; p.pose_R = pose_R; p.pose_T = pose_T; p.pose_RT = pose_RT;
     p.want_tn = out_tn ? 1 : 0;
 
     // the cones need th' = th - 1e-6 > 0; otherwise every pair takes the reference's arithmetic

@@ -33,6 +33,8 @@ struct VoteParams {
     int n; const int32_t* n_dev; int W, HW, hn;
     const int32_t* idxs; const uint8_t* keep; uint64_t seed; float thresh; int min_num, max_num;
     float* out_xy; int32_t* out_tn; int32_t* out_win_idx; int32_t* out_win_count; int32_t* out_inl; double* out_refine;
+    // optional (fpc_ransac_voting_v3_pose): the RT assembly of each instance appended to its voted centre by k_vote_final
+    const float* pose_q; const float* pose_z; const float* pose_kinv; float* pose_R; float* pose_T; float* pose_RT;
     // derived
     int nch, ntiles, hnp, nux, nrx, lds_table, want_tn, all_wild, task_target;
     int run_entries;                  // foreground ranks per refinement run (k_vote_final task)

@@ -92,8 +92,10 @@ class Model(object):
         if seed is None:
             seed = int(torch.randint(0, 2 ** 62, (1,)).item())      # one draw, also if the stages are re-run
         agg, n_dev = self.aggregation_layer.forward_deferred(categorical_data, cap)
-        agg = self.hough_voting_layer(agg, n_dev=n_dev, seed=seed)
-        if self.HPARAM.PERFORM_RT_CALCULATION:
+        rt = self.HPARAM.PERFORM_RT_CALCULATION
+        agg = self.hough_voting_layer(agg, n_dev=n_dev, seed=seed,
+                                      inv_intrinsics=self._inv_k(agg['quaternion'].device) if rt else None)
+        if rt and 'RT' not in agg:      # (an empty frame: the vote has nothing to append to)
             agg = gtf.samplewise_get_RT(agg, self._inv_k(agg['quaternion'].device))
         # asynchronous read-back of the instance count into pinned memory + an event to wait on
         pool = self.__dict__.setdefault('_pinned_counts', [])

@@ -55,11 +55,14 @@ def b_inv(b_mat):
 
 def ransac_voting_layer_v3(mask, vertex, round_hyp_num, inlier_thresh=0.999, confidence=0.99, max_iter=20,
                            min_num=5, max_num=30000, *, idxs=None, keep=None, seed=None, return_debug=False, n_dev=None,
-                           refine_out=None, mask_bits=None):
+                           refine_out=None, mask_bits=None, pose=None):
     """
     :param mask:      [b,h,w]   foreground where != 0
     :param vertex:    [b,h,w,vn,2]  (any strides; the permuted view of hough_voting.py:51 is read in place)
     :param round_hyp_num: hypotheses per instance
+    :param pose: (not in the reference) dict(q=[b,4], z=[b] or [b,1], kinv=[3,3], R=[b,3,3], T=[b,3], RT=[b,4,4]) of contiguous f32
+                 tensors on the masks' device, vn == 1: the RT assembly of gtf.batchwise_get_RT is appended to the vote's last kernel
+                 (fpc_ransac_voting_v3_pose) — R / T / RT are written for the instances the vote processes
     :return: [b,vn,2]  (x = column, y = row)
     """
     nat.require_gpu(mask, vertex, what="ransac_voting_layer_v3")
@@ -110,13 +113,23 @@ def ransac_voting_layer_v3(mask, vertex, round_hyp_num, inlier_thresh=0.999, con
                          hyp=torch.empty((b, hn, 2), dtype=torch.float32, device=dev))
                 if return_debug != "winner":     # the count rows of EVERY hypothesis: the exhaustive count runs (include/fpc.h)
                     d["counts"] = torch.empty((b, hn), dtype=torch.int32, device=dev)
-            nat.check(L.fpc_ransac_voting_v3_bits(
+            pp = [None] * 6
+            if pose is not None:
+                if vn != 1:
+                    raise RuntimeError("ransac_voting_layer_v3: pose needs vn == 1")
+                for k_, shp in (("q", (b, 4)), ("z", (b,)), ("kinv", (3, 3)), ("R", (b, 3, 3)), ("T", (b, 3)), ("RT", (b, 4, 4))):
+                    t_ = pose[k_]
+                    if t_.dtype != torch.float32 or not t_.is_contiguous() or t_.device != dev or t_.numel() != int(torch.Size(shp).numel()):
+                        raise RuntimeError("ransac_voting_layer_v3: pose[%r] must be a contiguous f32 tensor of %s on the masks' device" % (k_, shp))
+                pp = [nat.ptr(pose[k_]) for k_ in ("q", "z", "kinv", "R", "T", "RT")]
+            nat.check(L.fpc_ransac_voting_v3_pose(
                 nat.ptr(mask), nat.ptr(mask_bits), v.data_ptr(), sn, sh, sw, sc, b, nat.ptr(n_dev), h, w, hn, nat.ptr(ii), nat.ptr(keep),
                 (seed + vi) & (2 ** 64 - 1), float(inlier_thresh), int(min_num), int(max_num), nat.ptr(xy),
                 nat.ptr(d["tn"]) if d else None, nat.ptr(d["win_idx"]) if d else None,
                 nat.ptr(d["win_count"]) if d else None, nat.ptr(d["inlier_count"]) if d else None,
                 nat.ptr(d["hyp"]) if d else None, nat.ptr(d.get("counts")) if d else None, nat.ptr(refine),
-                nat.ptr(ws), ws.numel(), nat.stream()), "fpc_ransac_voting_v3_bits")
+                pp[0], pp[1], pp[2], pp[3], pp[4], pp[5],
+                nat.ptr(ws), ws.numel(), nat.stream()), "fpc_ransac_voting_v3_pose")
             if vn != 1:
                 out[:, vi, :] = xy
                 if refine is not None:

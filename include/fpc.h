@@ -120,6 +120,23 @@ int fpc_ransac_voting_v3_bits(const float* mask, const uint64_t* mask_bits, cons
                               float* out_hyp, int32_t* out_counts, double* out_refine,
                               void* ws, size_t ws_bytes, fpc_stream_t stream);
 
+/* The same with the RT assembly of fpc_pose_rt appended (round 6: one launch less per frame — the post-network path at batch 1 is a
+ * chain of launch latencies): when the six pose pointers are given (all or none), the workgroup of k_vote_final that writes an
+ * instance's out_xy also writes R [n][9], T [n][3], RT [n][16] from (out_xy, pose_q [n][4] scalar-last, pose_z [n], pose_kinv [9]) —
+ * the same function, the same bits as fpc_pose_rt on the same operands (F/lib/gpu_tensor_funcs.py:204-235 after
+ * F/lib/hough_voting.py:33-63).  Rows at or beyond *n_dev are not written. */
+int fpc_ransac_voting_v3_pose(const float* mask, const uint64_t* mask_bits, const float* vertex,
+                              int64_t vs_n, int64_t vs_h, int64_t vs_w, int64_t vs_c,
+                              int n, const int32_t* n_dev, int H, int W, int hn,
+                              const int32_t* idxs, const uint8_t* keep, uint64_t seed,
+                              float inlier_thresh, int min_num, int max_num,
+                              float* out_xy, int32_t* out_tn, int32_t* out_win_idx,
+                              int32_t* out_win_count, int32_t* out_inl_count,
+                              float* out_hyp, int32_t* out_counts, double* out_refine,
+                              const float* pose_q, const float* pose_z, const float* pose_kinv,
+                              float* pose_R, float* pose_T, float* pose_RT,
+                              void* ws, size_t ws_bytes, fpc_stream_t stream);
+
 /* The progressive count (OFF by default).  Unless the caller asks for out_counts, only the WINNER of the vote is an output
  * (RV/ransac_voting_gpu.py:566-574: arg-max of the inlier counts, first maximum).  With fpc_vote_set_prune(1, ...) the count
  * runs in passes over disjoint sets of each instance's pixels; between two passes every hypothesis h with

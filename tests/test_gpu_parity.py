@@ -482,6 +482,11 @@ def test_config3_post_network_batch32_vs_oracle(lib, oracle, dev):
     assert_rel(agg["xy"].cpu().numpy(), wxy[:, 0], what="centres")
     R, T, RT = oracle.pose_rt(want["quaternion"], wxy[:, 0], want["z"], model.inv_intrinsics.cpu().numpy())
     assert_pose(agg["R"].cpu().numpy(), agg["T"].cpu().numpy(), agg["RT"].cpu().numpy(), R, T, RT, what="batch 32")
+    # the deferred path appends the RT assembly to the vote's last kernel (fpc_ransac_voting_v3_pose): the same bits as the separate
+    # launch (gtf.batchwise_get_RT -> fpc_pose_rt) on the same operands
+    import gpu_tensor_funcs as gtf
+    R2, T2, RT2 = gtf.batchwise_get_RT(agg["quaternion"], agg["xy"], agg["z"], model.inv_intrinsics)
+    assert torch.equal(R2, agg["R"]) and torch.equal(T2, agg["T"]) and torch.equal(RT2, agg["RT"])
 
 
 def test_config3_vote_batch32_hn1000_every_count_vs_oracle(lib, oracle, dev):
