@@ -43,7 +43,7 @@
 extern "C" {
 #endif
 
-#define FPC_ABI_VERSION 10
+#define FPC_ABI_VERSION 11
 
 #define FPC_OK 0
 #define FPC_EINVAL (-1)      /* bad argument (shape, null pointer, ...) */

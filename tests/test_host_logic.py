@@ -36,7 +36,7 @@ def test_abi_exports_every_declared_symbol(hiplib):
     for name in sorted(declared):
         assert hasattr(raw, name), f"{name} is declared in include/fpc.h but not exported"
     assert declared == set(_native.EXPORTED), declared ^ set(_native.EXPORTED)
-    assert hiplib.fpc_abi_version() == 10
+    assert hiplib.fpc_abi_version() == 11
     assert hiplib.fpc_error_string(-2).decode().startswith("workspace")
 
 
