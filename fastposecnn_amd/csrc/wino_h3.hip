@@ -14,13 +14,17 @@
 // the operand tuple that belongs to its K-step — none of the 32 operand copies per step of the {h1, h1} / {h2, h2} form.
 //
 // Schedule of a pair p (K-steps 2p, 2p + 1), one barrier:
-//   top      LDS-DMA of the inputs of steps 2p + 3 and 2p + 4 (ring of four 18 KB buffers inside the output image's space)
-//   E        vector work only: the pending split of xi 3 (even half), then step 2p + 1's fragment reads, transform and split -> the odd
-//            halves of every operand
-//   O        48 matrix instructions (xi j: A1 B1 x 4, A2 B1 x 4, A1 B2 x 4) with one item of work behind each of the first 40: step
-//            2p + 2's fragment reads, transform, and the split of xi 0-2 into the even halves once xi j's last matrix instruction has
-//            issued (xi 3 waits for the next E); each weight fragment is reloaded in place for the next pair after its last use
-//   end      counted wait for this wave's ten pieces (the 16 weight loads behind them stay in flight), barrier
+//   E        no matrix instruction: the sixteen fragment reads of step 2p + 1 (64 KB per workgroup = 512 cycles of the LDS pipe) are
+//            issued first; under them the LDS-DMA burst of steps 2p + 3 and 2p + 4 (ring of four 18 KB buffers inside the output image's
+//            space; a step past the last is not staged) and the pending split of xi 3 (even half); then the transform and xi 0's split
+//            into the odd halves
+//   O        48 matrix instructions (xi j: A1 B1 x 4, A2 B1 x 4, A1 B2 x 4) with one item of work behind each of the first 40 — two
+//            behind the first twelve: the odd step's xi 1-3 splits (before xi 1's first instruction) beside step 2p + 2's fragment
+//            reads and row transform; then its column transform, and the split of xi 0-2 into the even halves once xi j's last
+//            matrix instruction has issued (xi 3 waits for the next E); each weight fragment is reloaded in place for the next pair
+//            after its last use
+//   end      counted wait for this wave's staging pieces (the 16 weight loads behind them stay in flight), barrier
+// Entry: the weight fragments of pair 0 and steps 0, 1, 2 are requested together; step 0's transform runs while steps 1 and 2 land.
 // Range, scaling, the input image's layout, the entry and the output transform are wino_h2.hip's; Cin must be a multiple of 16.
 // Reference: the 3x3 / stride-1 convolutions of F/lib/pose_regressor.py:709-743 (smp encoder + FPN decoder, not vendored).
 #include <algorithm>
