@@ -923,6 +923,11 @@ def main():
         roof["note"] = ("HIP events on the launch stream around the whole call, live in this run; `traffic` and `valu` are PMC "
                         "counters of a separate profiled run of the same call (`from_profile` names the file and the commit it was "
                         "taken at): rocprofv3 cannot collect them inside this process")
+        if args.batch == 1:
+            roof["bound_note"] = ("launch latency: four dependent launches (scan, plan, count, final: 6.5 + 10.3 + 14.6 + 10.2 us on one frame's "
+                                  "six instances, profiles/r06_vote_bits_b1_hn1000_kernel_stats.csv) for ~3 us of HBM time; fewer launches were "
+                                  "built in round 4 and were slower (tools_dev/r4_vote_fused/README.md); since round 6 the RT assembly rides on "
+                                  "the last of the four (fpc_ransac_voting_v3_pose)")
         line = {
             "metric": "img/s end-to-end 640x480 inference; hough-vote kernel HBM GB/s vs roofline",
             "value": res["value"], "unit": "img/s", "n_gpus": world, "steps": args.steps,
